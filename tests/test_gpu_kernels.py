@@ -1,0 +1,111 @@
+"""GPU parity: single HIP kernels (NTT, computeH, MSM G1/G2) against the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+from oracle import r1cs_format as rf
+
+R = rf.R_MOD
+pytestmark = pytest.mark.gpu
+
+
+def _rand_fr(rng, n):
+    out = np.zeros((n, 32), np.uint8)
+    for i in range(n):
+        out[i] = np.frombuffer((int.from_bytes(rng.bytes(32), "little") % R).to_bytes(32, "little"), np.uint8)
+    return out
+
+
+@pytest.mark.parametrize("logn,batch", [(1, 1), (3, 2), (6, 64), (10, 5), (13, 64)])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_ntt_matches_oracle(zk, oracle, logn, batch, mode):
+    rng = np.random.default_rng(100 * logn + mode)
+    n = 1 << logn
+    data = np.stack([_rand_fr(rng, n) for _ in range(batch)])
+    exp = np.stack([oracle.ntt(data[b], inverse=bool(mode & 1)) for b in range(batch)])
+    got = data.copy()
+    assert zk.lib.zkp_ntt(logn, batch, got.ctypes.data, mode) == 0, zk.last_error()
+    assert np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("logn,ncons,batch", [(4, 11, 3), (10, 1000, 64), (12, 4096, 2)])
+def test_compute_h_matches_oracle(zk, oracle, logn, ncons, batch):
+    rng = np.random.default_rng(7 + logn)
+    n = 1 << logn
+    a = np.stack([_rand_fr(rng, ncons) for _ in range(batch)])
+    b = np.stack([_rand_fr(rng, ncons) for _ in range(batch)])
+    # c = a*b on the constraint rows so that the quotient is a polynomial (as in a satisfied R1CS)
+    c = np.zeros_like(a)
+    for bb in range(batch):
+        A = oracle.le32_to_ints(a[bb]); Bv = oracle.le32_to_ints(b[bb])
+        c[bb] = oracle.ints_to_le32([x * y % R for x, y in zip(A, Bv)])
+    exp = np.stack([oracle.compute_h(a[i], b[i], c[i], n) for i in range(batch)])
+    got = np.zeros((batch, n, 32), np.uint8)
+    rc = zk.lib.zkp_compute_h(logn, batch, ncons, a.ctypes.data, b.ctypes.data, c.ctypes.data, got.ctypes.data)
+    assert rc == 0, zk.last_error()
+    assert np.array_equal(got, exp)
+    # degree bound: top coefficient of H is zero
+    assert not got[:, n - 1].any()
+
+
+def _scalars_mix(rng, n, batch):
+    """wire-like mix: zeros, ones, small and full-width values"""
+    out = np.zeros((batch, n, 32), np.uint8)
+    for b in range(batch):
+        kinds = rng.integers(0, 10, size=n)
+        for i in range(n):
+            k = kinds[i]
+            if k < 4:
+                v = 0
+            elif k < 7:
+                v = 1
+            elif k == 7:
+                v = int(rng.integers(2, 1 << 32))
+            elif k == 8:
+                v = R - int(rng.integers(1, 1 << 20))
+            else:
+                v = int.from_bytes(rng.bytes(32), "little") % R
+            out[b, i] = np.frombuffer(v.to_bytes(32, "little"), np.uint8)
+    return out
+
+
+@pytest.mark.parametrize("n,batch,c", [(1, 1, 8), (50, 3, 8), (700, 64, 10), (3000, 2, 13), (1200, 65, 16)])
+def test_msm_g1_matches_oracle(zk, oracle, n, batch, c):
+    rng = np.random.default_rng(n + c)
+    pts = oracle.g1_fixed_base(_rand_fr(rng, n))
+    if n > 10:
+        pts[3] = 0          # a point at infinity among the bases
+    sc = _scalars_mix(rng, n, batch)
+    if n > 10:
+        sc[0, 5] = np.frombuffer((R - 1).to_bytes(32, "little"), np.uint8)
+    exp = np.stack([oracle.msm_g1(pts, sc[b]) for b in range(batch)])
+    got = np.zeros((batch, 64), np.uint8)
+    rc = zk.lib.zkp_msm_g1(n, batch, pts.ctypes.data, sc.ctypes.data, got.ctypes.data, c)
+    assert rc == 0, zk.last_error()
+    assert np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("n,batch,c", [(1, 1, 8), (40, 2, 8), (500, 64, 12)])
+def test_msm_g2_matches_oracle(zk, oracle, n, batch, c):
+    rng = np.random.default_rng(1000 + n)
+    pts = oracle.g2_fixed_base(_rand_fr(rng, n))
+    sc = _scalars_mix(rng, n, batch)
+    exp = np.stack([oracle.msm_g2(pts, sc[b]) for b in range(batch)])
+    got = np.zeros((batch, 128), np.uint8)
+    rc = zk.lib.zkp_msm_g2(n, batch, pts.ctypes.data, sc.ctypes.data, got.ctypes.data, c)
+    assert rc == 0, zk.last_error()
+    assert np.array_equal(got, exp)
+
+
+def test_msm_all_zero_and_all_one(zk, oracle):
+    rng = np.random.default_rng(5)
+    n, batch = 300, 4
+    pts = oracle.g1_fixed_base(_rand_fr(rng, n))
+    sc = np.zeros((batch, n, 32), np.uint8)
+    sc[1, :, 0] = 1
+    sc[2, ::2, 0] = 1
+    sc[3] = _rand_fr(rng, n)
+    exp = np.stack([oracle.msm_g1(pts, sc[b]) for b in range(batch)])
+    got = np.zeros((batch, 64), np.uint8)
+    assert zk.lib.zkp_msm_g1(n, batch, pts.ctypes.data, sc.ctypes.data, got.ctypes.data, 9) == 0
+    assert np.array_equal(got, exp)
+    assert not got[0].any()      # empty sum = infinity = (0,0)

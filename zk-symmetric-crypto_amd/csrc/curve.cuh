@@ -1,0 +1,119 @@
+// BN254 G1 (over Fp) / G2 (over Fp2) group arithmetic for gfx950, extended-Jacobian ("XYZZ")
+// accumulators with affine addends: x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2.
+//
+// Device replacement for the bucket arithmetic of gnark-crypto v0.19.2 ecc/bn254 (g1JacExtended /
+// g2JacExtended, used by MultiExp) reached from groth16.Prove, provers.go:179,269.
+// Infinity: affine (0,0) (gnark-crypto convention); XYZZ with ZZ == 0.
+#pragma once
+#include "field.cuh"
+
+namespace zk {
+
+template <class F>
+struct Affine {
+    F x, y;
+    ZK_HD bool is_inf() const { return x.is_zero() && y.is_zero(); }
+    static ZK_HD Affine inf() { return Affine{F::zero(), F::zero()}; }
+    ZK_HD Affine neg() const { return Affine{x, y.neg()}; }
+};
+
+template <class F>
+struct XYZZ {
+    F X, Y, ZZ, ZZZ;
+    ZK_HD bool is_inf() const { return ZZ.is_zero(); }
+    static ZK_HD XYZZ inf() { return XYZZ{F::zero(), F::zero(), F::zero(), F::zero()}; }
+    static ZK_HD XYZZ from_affine(const Affine<F> &p) {
+        if (p.is_inf()) return inf();
+        return XYZZ{p.x, p.y, F::one(), F::one()};
+    }
+    ZK_HD XYZZ neg() const { return XYZZ{X, Y.neg(), ZZ, ZZZ}; }
+
+    // 2*p for affine p (mdbl-2008-s-1)
+    static ZK_HD XYZZ dbl_affine(const Affine<F> &p) {
+        F U = p.y.dbl(), V = U.sqr(), W = U * V, S = p.x * V;
+        F t = p.x.sqr();
+        F M = t.dbl() + t;
+        XYZZ r;
+        r.X = M.sqr() - S.dbl();
+        r.Y = M * (S - r.X) - W * p.y;
+        r.ZZ = V;
+        r.ZZZ = W;
+        return r;
+    }
+    // dbl-2008-s-1
+    ZK_HD XYZZ dbl() const {
+        if (is_inf()) return *this;
+        F U = Y.dbl(), V = U.sqr(), W = U * V, S = X * V;
+        F t = X.sqr();
+        F M = t.dbl() + t;
+        XYZZ r;
+        r.X = M.sqr() - S.dbl();
+        r.Y = M * (S - r.X) - W * Y;
+        r.ZZ = V * ZZ;
+        r.ZZZ = W * ZZZ;
+        return r;
+    }
+    // this += q (affine), madd-2008-s with the special cases
+    ZK_HD void madd(const Affine<F> &q) {
+        if (q.is_inf()) return;
+        if (is_inf()) {
+            X = q.x; Y = q.y; ZZ = F::one(); ZZZ = F::one();
+            return;
+        }
+        F U2 = q.x * ZZ, S2 = q.y * ZZZ;
+        F Pv = U2 - X, R = S2 - Y;
+        if (Pv.is_zero()) {
+            if (R.is_zero()) *this = dbl_affine(q);
+            else *this = inf();
+            return;
+        }
+        F PP = Pv.sqr(), PPP = Pv * PP, Q = X * PP;
+        F X3 = R.sqr() - PPP - Q.dbl();
+        Y = R * (Q - X3) - Y * PPP;
+        X = X3;
+        ZZ = ZZ * PP;
+        ZZZ = ZZZ * PPP;
+    }
+    // this += q (XYZZ), add-2008-s
+    ZK_HD void add(const XYZZ &q) {
+        if (q.is_inf()) return;
+        if (is_inf()) { *this = q; return; }
+        F U1 = X * q.ZZ, U2 = q.X * ZZ, S1 = Y * q.ZZZ, S2 = q.Y * ZZZ;
+        F Pv = U2 - U1, R = S2 - S1;
+        if (Pv.is_zero()) {
+            if (R.is_zero()) *this = dbl();
+            else *this = inf();
+            return;
+        }
+        F PP = Pv.sqr(), PPP = Pv * PP, Q = U1 * PP;
+        F X3 = R.sqr() - PPP - Q.dbl();
+        Y = R * (Q - X3) - S1 * PPP;
+        X = X3;
+        ZZ = ZZ * q.ZZ * PP;
+        ZZZ = ZZZ * q.ZZZ * PPP;
+    }
+    ZK_HD Affine<F> to_affine() const {
+        if (is_inf()) return Affine<F>::inf();
+        F zi3 = ZZZ.inv();
+        F zi2 = zi3.sqr() * ZZ.sqr();   // 1/ZZ = ZZ^2 / ZZZ^2
+        return Affine<F>{X * zi2, Y * zi3};
+    }
+};
+
+// k * p, k = plain 256-bit integer (8 LE limbs); MSB-first double-and-add
+template <class F>
+ZK_HD XYZZ<F> scalar_mul(const Affine<F> &p, const uint32_t *k, int nbits = 254) {
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (int i = nbits - 1; i >= 0; i--) {
+        acc = acc.dbl();
+        if ((k[i >> 5] >> (i & 31)) & 1) acc.madd(p);
+    }
+    return acc;
+}
+
+using G1Affine = Affine<Fp>;
+using G2Affine = Affine<Fp2>;
+using G1XYZZ = XYZZ<Fp>;
+using G2XYZZ = XYZZ<Fp2>;
+
+}  // namespace zk

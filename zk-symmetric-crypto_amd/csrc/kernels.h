@@ -1,0 +1,71 @@
+// Internal C++ interface between the HIP kernel translation units and the prover host code.
+#pragma once
+#include <vector>
+#include "common.h"
+#include "curve.cuh"
+
+namespace zk {
+
+// ------------------------------------------------------------------------------------------ NTT
+struct NttDomain {
+    int logn = 0;
+    size_t n = 0;
+    DevBuf<Fr> consts, tw_fwd, tw_inv, coset_pre, coset_post;
+    void init(int logn, hipStream_t s);
+    // data layout [n][B]; see ntt.hip
+    void dif(Fr *data, size_t B, bool inverse, const Fr *postmul, hipStream_t s) const;
+    void dit(Fr *data, size_t B, bool inverse, const Fr *premul, hipStream_t s) const;
+    void compute_h(Fr *a, Fr *b, Fr *c, size_t B, hipStream_t s) const;
+    void scale_ninv(Fr *a, size_t B, hipStream_t s) const;
+};
+void fr_to_mont(Fr *a, size_t total, hipStream_t s);
+void fr_from_mont(Fr *a, size_t total, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------ MSM
+// One fixed base set (a slice of the proving key) prepared for batched bucket MSMs.
+//   table[j * W + w] = 2^(c*w) * P_j   (affine, Montgomery)  -- precomputed window multiples so that
+//   all windows of a scalar share ONE bucket set (single bucket reduction, no Horner doublings).
+template <class F>
+struct MsmBases {
+    size_t n = 0;          // number of base points
+    int c = 0;             // window bits (signed digits, 2^(c-1) buckets)
+    int W = 0;             // windows
+    DevBuf<Affine<F>> table;
+    DevBuf<uint32_t> scalar_row;   // row index of the scalar of point j in the [row][B] scalar matrix
+};
+using MsmBasesG1 = MsmBases<Fp>;
+using MsmBasesG2 = MsmBases<Fp2>;
+
+// points: n affine points in Montgomery form on the device (infinity = (0,0) allowed)
+void msm_bases_build(MsmBasesG1 &mb, const G1Affine *d_points, size_t n, const uint32_t *h_scalar_rows, int c, hipStream_t s);
+void msm_bases_build(MsmBasesG2 &mb, const G2Affine *d_points, size_t n, const uint32_t *h_scalar_rows, int c, hipStream_t s);
+
+// Scratch shared by all MSMs of a batch (sized for the largest).
+struct MsmScratch {
+    DevBuf<uint32_t> entries;        // [B][max_entries]
+    DevBuf<uint32_t> bucket_start;   // [B][nb + 1]
+    DevBuf<G1XYZZ> part1;            // partial sums G1
+    DevBuf<G2XYZZ> part2;            // partial sums G2
+    size_t B = 0;
+    void reserve(size_t B, size_t max_entries_per_inst, size_t max_nb, size_t max_part);
+};
+
+// out[b] (+)= sum_j scalars[row_j][b] * P_j for b in [0,B).  scalars: [rows][B] Fr Montgomery.
+// If accumulate is false out[b] is overwritten.
+void msm_batch(const MsmBasesG1 &mb, const Fr *scalars, size_t B, MsmScratch &sc, G1XYZZ *out, hipStream_t s);
+void msm_batch(const MsmBasesG2 &mb, const Fr *scalars, size_t B, MsmScratch &sc, G2XYZZ *out, hipStream_t s);
+
+// number of XYZZ partial slots per instance that msm_batch needs in MsmScratch::part*
+size_t msm_part_stride(size_t n, int c);
+
+// affine import helpers: canonical big-endian coordinate bytes -> Montgomery affine on device
+void g1_from_be_bytes(G1Affine *d_out, const uint8_t *d_in /* n*64 */, size_t n, hipStream_t s);
+void g2_from_be_bytes(G2Affine *d_out, const uint8_t *d_in /* n*128: X.A1|X.A0|Y.A1|Y.A0 */, size_t n, hipStream_t s);
+// compressed forms (gnark-crypto marshal): returns via d_ok[i] = 0 on invalid point
+void g1_decompress(G1Affine *d_out, const uint8_t *d_in /* n*32 */, size_t n, uint32_t *d_bad, hipStream_t s);
+void g2_decompress(G2Affine *d_out, const uint8_t *d_in /* n*64 */, size_t n, uint32_t *d_bad, hipStream_t s);
+// XYZZ -> canonical (non-Montgomery) affine, little-endian limbs; infinity -> zeros
+void g1_to_affine_canonical(const G1XYZZ *d_in, G1Affine *d_out, size_t n, hipStream_t s);
+void g2_to_affine_canonical(const G2XYZZ *d_in, G2Affine *d_out, size_t n, hipStream_t s);
+
+}  // namespace zk

@@ -1,0 +1,402 @@
+// Batched multi-scalar multiplication on BN254 G1 / G2 for gfx950.
+//
+// Replaces gnark-crypto v0.19.2 ecc/bn254 G1Jac.MultiExp / G2Jac.MultiExp (signed-digit bucket
+// method; `processChunkG1BatchAffine`, `msmReduceChunkG1Affine`, `partitionScalars` in the
+// reference's default.pgo -- the 68.6 % + 16.2 % of prove time), called by
+// groth16.Prove from gnark/libraries/prover/impl/provers.go:179,269.
+//
+// MI355X design (one launch sequence serves a whole batch of B proofs that share the bases):
+//   * fixed bases => window multiples 2^(c*w)*P_j are precomputed once per proving key
+//     (table[j*W + w], affine).  All W windows of a scalar then feed ONE bucket set, so there is a
+//     single bucket reduction per MSM and no Horner doubling chain.
+//   * scalars arrive straight from the solver / NTT in the [row][B] Montgomery layout.
+//     0 and 1 (84-88 % of the wire scalars) never enter the bucket pipeline:
+//     k_msm_ones does a conditional sum with lanes = instances (coalesced scalar rows, wave-uniform
+//     base point).
+//   * k_msm_sort: one workgroup per instance builds the bucket histogram in LDS (up to 128 KiB of
+//     the 160 KiB), scans it and scatters (table index | sign) entries into bucket order.
+//   * k_msm_segments: one thread per run of L consecutive buckets walks its (contiguous) entries
+//     from the top bucket down, fusing accumulation with the running-sum reduction.
+//   * k_sum_groups folds the per-chunk / per-segment partial sums.
+// Results are group elements; any correct schedule yields the same affine point, which is what the
+// parity tests compare bit-for-bit with the oracle.
+#include "kernels.h"
+
+namespace zk {
+
+static constexpr int SEG_LOG = 6;            // L = 64 buckets per segment
+static constexpr int ONES_CHUNK = 128;       // base points per conditional-sum thread
+static constexpr int SORT_THREADS = 1024;
+
+// ------------------------------------------------------------------------------ table precompute
+template <class F>
+__global__ __launch_bounds__(256) void k_window_multiples(const Affine<F> *__restrict__ pts, size_t n, int c, int W, XYZZ<F> *__restrict__ out) {
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    XYZZ<F> cur = XYZZ<F>::from_affine(pts[j]);
+    for (int w = 0; w < W; w++) {
+        out[j * W + w] = cur;
+        if (w + 1 < W)
+            for (int k = 0; k < c; k++) cur = cur.dbl();
+    }
+}
+template <class F>
+__global__ __launch_bounds__(256) void k_xyzz_to_affine(const XYZZ<F> *__restrict__ in, Affine<F> *__restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = in[i].to_affine();
+}
+
+template <class F>
+static void bases_build(MsmBases<F> &mb, const Affine<F> *d_points, size_t n, const uint32_t *h_rows, int c, hipStream_t s) {
+    mb.n = n; mb.c = c; mb.W = (254 + c - 1) / c;
+    mb.scalar_row.alloc(n ? n : 1);
+    if (n) ZK_HIP(hipMemcpyAsync(mb.scalar_row.p, h_rows, n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    size_t tot = n * mb.W;
+    mb.table.alloc(tot ? tot : 1);
+    if (!n) return;
+    // chunked to bound the XYZZ temp
+    const size_t CH = 1 << 16;
+    DevBuf<XYZZ<F>> tmp(CH * mb.W);
+    for (size_t off = 0; off < n; off += CH) {
+        size_t m = n - off < CH ? n - off : CH;
+        hipLaunchKernelGGL(k_window_multiples<F>, dim3(ceil_div(m, 256)), dim3(256), 0, s, d_points + off, m, c, mb.W, tmp.p);
+        hipLaunchKernelGGL(k_xyzz_to_affine<F>, dim3(ceil_div(m * mb.W, 256)), dim3(256), 0, s, tmp.p, mb.table.p + off * mb.W, m * mb.W);
+    }
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipStreamSynchronize(s));
+}
+void msm_bases_build(MsmBasesG1 &mb, const G1Affine *p, size_t n, const uint32_t *rows, int c, hipStream_t s) { bases_build<Fp>(mb, p, n, rows, c, s); }
+void msm_bases_build(MsmBasesG2 &mb, const G2Affine *p, size_t n, const uint32_t *rows, int c, hipStream_t s) { bases_build<Fp2>(mb, p, n, rows, c, s); }
+
+void MsmScratch::reserve(size_t B_, size_t max_entries, size_t max_nb, size_t max_part) {
+    B = B_;
+    entries.ensure(B * max_entries + 1);
+    bucket_start.ensure(B * (max_nb + 1));
+    part1.ensure(B * max_part + 1);
+    part2.ensure(B * max_part + 1);
+}
+
+// --------------------------------------------------------------------------------- digit helpers
+// scalar classes: 0 -> skip, 1 -> ones path, else bucket path
+__device__ __forceinline__ int classify(const Fr &s) {
+    if (s.is_zero()) return 0;
+    if (s == Fr::one()) return 1;
+    return 2;
+}
+// signed digit w of canonical scalar (window c); carry in/out
+__device__ __forceinline__ int signed_digit(const uint32_t *l, int w, int c, int &carry) {
+    const int bit = w * c;
+    const int li = bit >> 5, sh = bit & 31;
+    uint64_t v = l[li];
+    if (li + 1 < 8) v |= (uint64_t)l[li + 1] << 32;
+    int raw = (int)((v >> sh) & ((1u << c) - 1)) + carry;
+    if (raw > (1 << (c - 1))) { carry = 1; return raw - (1 << c); }
+    carry = 0;
+    return raw;
+}
+
+// one workgroup per instance.  dyn LDS: nb counters + SORT_THREADS scan slots
+__global__ __launch_bounds__(SORT_THREADS) void k_msm_sort(const Fr *__restrict__ scalars, size_t B, const uint32_t *__restrict__ rows, size_t n,
+                                                           int c, int W, uint32_t *__restrict__ bucket_start, uint32_t *__restrict__ entries,
+                                                           size_t max_entries) {
+    extern __shared__ uint32_t lds[];
+    const uint32_t nb = 1u << (c - 1);
+    uint32_t *hist = lds;
+    uint32_t *scan = lds + nb;
+    const size_t b = blockIdx.x;
+    const int tid = threadIdx.x;
+    for (uint32_t i = tid; i < nb; i += SORT_THREADS) hist[i] = 0;
+    __syncthreads();
+    for (size_t j = tid; j < n; j += SORT_THREADS) {
+        Fr s = scalars[(size_t)rows[j] * B + b];
+        if (classify(s) != 2) continue;
+        Fr cs = s.from_mont();
+        int carry = 0;
+        for (int w = 0; w < W; w++) {
+            int d = signed_digit(cs.l, w, c, carry);
+            if (d) atomicAdd(&hist[(d < 0 ? -d : d) - 1], 1u);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of hist (nb is a multiple of SORT_THREADS or smaller)
+    const uint32_t per = (nb + SORT_THREADS - 1) / SORT_THREADS;
+    const uint32_t lo = tid * per;
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < lo + per && i < nb; i++) sum += hist[i];
+    scan[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < SORT_THREADS; off <<= 1) {
+        uint32_t v = tid >= off ? scan[tid - off] : 0;
+        __syncthreads();
+        scan[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = scan[tid] - sum;   // exclusive prefix of this thread's chunk
+    uint32_t *bs = bucket_start + b * (nb + 1);
+    for (uint32_t i = lo; i < lo + per && i < nb; i++) {
+        uint32_t cnt = hist[i];
+        hist[i] = run;                // becomes the scatter cursor
+        bs[i] = run;
+        run += cnt;
+    }
+    if (tid == SORT_THREADS - 1) bs[nb] = scan[tid];
+    __syncthreads();
+    uint32_t *ent = entries + b * max_entries;
+    for (size_t j = tid; j < n; j += SORT_THREADS) {
+        Fr s = scalars[(size_t)rows[j] * B + b];
+        if (classify(s) != 2) continue;
+        Fr cs = s.from_mont();
+        int carry = 0;
+        for (int w = 0; w < W; w++) {
+            int d = signed_digit(cs.l, w, c, carry);
+            if (!d) continue;
+            uint32_t neg = d < 0;
+            uint32_t pos = atomicAdd(&hist[(neg ? -d : d) - 1], 1u);
+            ent[pos] = (uint32_t)(j * W + w) | (neg << 31);
+        }
+    }
+}
+
+// thread (b, seg): buckets [seg*L, seg*L + L) of instance b; lanes = consecutive segments
+template <class F>
+__global__ __launch_bounds__(64) void k_msm_segments(const Affine<F> *__restrict__ table, const uint32_t *__restrict__ bucket_start,
+                                                     const uint32_t *__restrict__ entries, size_t max_entries, int c, size_t B,
+                                                     XYZZ<F> *__restrict__ part, size_t part_stride, size_t part_off) {
+    const uint32_t nb = 1u << (c - 1);
+    const uint32_t L = nb < (1u << SEG_LOG) ? nb : (1u << SEG_LOG);
+    const uint32_t nseg = nb / L;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)nseg * B) return;
+    const size_t b = t / nseg;
+    const uint32_t seg = (uint32_t)(t % nseg);
+    const uint32_t *bs = bucket_start + b * (nb + 1);
+    const uint32_t *ent = entries + b * max_entries;
+    XYZZ<F> run = XYZZ<F>::inf(), tot = XYZZ<F>::inf();
+    const uint32_t s0 = seg * L;
+    uint32_t hi = bs[s0 + L];
+    for (int k = (int)L - 1; k >= 0; k--) {
+        const uint32_t lo = bs[s0 + k];
+        XYZZ<F> acc = XYZZ<F>::inf();
+        for (uint32_t e = lo; e < hi; e++) {
+            const uint32_t v = ent[e];
+            Affine<F> p = table[v & 0x7fffffffu];
+            if (v >> 31) p.y = p.y.neg();
+            acc.madd(p);
+        }
+        hi = lo;
+        run.add(acc);
+        tot.add(run);
+    }
+    // contribution = tot + s0 * run   (bucket index i carries weight i+1)
+    if (s0 != 0 && !run.is_inf()) {
+        XYZZ<F> m = XYZZ<F>::inf();
+        for (int bit = 31 - __clz(s0); bit >= 0; bit--) {
+            m = m.dbl();
+            if ((s0 >> bit) & 1) m.add(run);
+        }
+        tot.add(m);
+    }
+    part[b * part_stride + part_off + seg] = tot;
+}
+
+// thread (chunk, b): lanes = consecutive instances
+template <class F>
+__global__ __launch_bounds__(256) void k_msm_ones(const Affine<F> *__restrict__ table, int W, const Fr *__restrict__ scalars, size_t B,
+                                                  const uint32_t *__restrict__ rows, size_t n, XYZZ<F> *__restrict__ part,
+                                                  size_t part_stride, size_t part_off) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nchunks = (n + ONES_CHUNK - 1) / ONES_CHUNK;
+    if (t >= nchunks * B) return;
+    const size_t b = t % B, chunk = t / B;
+    const size_t j0 = chunk * ONES_CHUNK;
+    const size_t j1 = j0 + ONES_CHUNK < n ? j0 + ONES_CHUNK : n;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    const Fr one = Fr::one();
+    for (size_t j = j0; j < j1; j++) {
+        const Fr s = scalars[(size_t)rows[j] * B + b];
+        if (s == one) acc.madd(table[j * W]);
+    }
+    part[b * part_stride + part_off + chunk] = acc;
+}
+
+// out[b*out_stride + g] = sum_{i < group} in[b*in_stride + g*group + i]   (i bounded by count)
+template <class F>
+__global__ __launch_bounds__(64) void k_sum_groups(const XYZZ<F> *__restrict__ in, size_t in_stride, size_t count, size_t group,
+                                                   XYZZ<F> *__restrict__ out, size_t out_stride, size_t B) {
+    const size_t ngroups = (count + group - 1) / group;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ngroups * B) return;
+    const size_t b = t / ngroups, g = t % ngroups;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    const size_t i0 = g * group, i1 = i0 + group < count ? i0 + group : count;
+    for (size_t i = i0; i < i1; i++) acc.add(in[b * in_stride + i]);
+    out[b * out_stride + g] = acc;
+}
+
+template <class F>
+struct PartSel;
+template <>
+struct PartSel<Fp> { static G1XYZZ *get(MsmScratch &s) { return s.part1.p; } static size_t cap(MsmScratch &s) { return s.part1.n; } };
+template <>
+struct PartSel<Fp2> { static G2XYZZ *get(MsmScratch &s) { return s.part2.p; } static size_t cap(MsmScratch &s) { return s.part2.n; } };
+
+template <class F>
+static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, MsmScratch &sc, XYZZ<F> *out, hipStream_t s) {
+    const size_t n = mb.n;
+    const int c = mb.c, W = mb.W;
+    const uint32_t nb = 1u << (c - 1);
+    const uint32_t L = nb < (1u << SEG_LOG) ? nb : (1u << SEG_LOG);
+    const size_t nseg = nb / L;
+    const size_t nchunks = (n + ONES_CHUNK - 1) / ONES_CHUNK;
+    const size_t max_entries = n * W;
+    const size_t npart = nchunks + nseg;
+    const size_t GROUP = 32;
+    const size_t nlvl1 = (npart + GROUP - 1) / GROUP;
+    const size_t stride = npart + nlvl1;      // level-0 partials followed by level-1 partials
+    if (sc.entries.n < B * max_entries + 1 || sc.bucket_start.n < B * (nb + 1) || PartSel<F>::cap(sc) < B * stride + 1)
+        throw ZkError("msm scratch too small");
+    XYZZ<F> *part = PartSel<F>::get(sc);
+    if (n == 0) {
+        ZK_HIP(hipMemsetAsync(out, 0, B * sizeof(XYZZ<F>), s));
+        return;
+    }
+    size_t lds = (size_t)(nb + SORT_THREADS) * sizeof(uint32_t);
+    static bool attr_set = false;
+    if (!attr_set) {
+        ZK_HIP(hipFuncSetAttribute((const void *)k_msm_sort, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_msm_sort, dim3((unsigned)B), dim3(SORT_THREADS), lds, s, scalars, B, mb.scalar_row.p, n, c, W, sc.bucket_start.p,
+                       sc.entries.p, max_entries);
+    hipLaunchKernelGGL(k_msm_ones<F>, dim3(ceil_div(nchunks * B, 256)), dim3(256), 0, s, mb.table.p, W, scalars, B, mb.scalar_row.p, n, part,
+                       stride, (size_t)0);
+    hipLaunchKernelGGL(k_msm_segments<F>, dim3(ceil_div(nseg * B, 64)), dim3(64), 0, s, mb.table.p, sc.bucket_start.p, sc.entries.p, max_entries,
+                       c, B, part, stride, nchunks);
+    hipLaunchKernelGGL(k_sum_groups<F>, dim3(ceil_div(nlvl1 * B, 64)), dim3(64), 0, s, part, stride, npart, GROUP, part + npart, stride, B);
+    hipLaunchKernelGGL(k_sum_groups<F>, dim3(ceil_div(B, 64)), dim3(64), 0, s, part + npart, stride, nlvl1, nlvl1, out, (size_t)1, B);
+    ZK_HIP(hipGetLastError());
+}
+void msm_batch(const MsmBasesG1 &mb, const Fr *sc, size_t B, MsmScratch &scr, G1XYZZ *out, hipStream_t s) { msm_batch_impl<Fp>(mb, sc, B, scr, out, s); }
+void msm_batch(const MsmBasesG2 &mb, const Fr *sc, size_t B, MsmScratch &scr, G2XYZZ *out, hipStream_t s) { msm_batch_impl<Fp2>(mb, sc, B, scr, out, s); }
+
+size_t msm_part_stride(size_t n, int c) {
+    const uint32_t nb = 1u << (c - 1);
+    const uint32_t L = nb < (1u << SEG_LOG) ? nb : (1u << SEG_LOG);
+    size_t npart = (n + ONES_CHUNK - 1) / ONES_CHUNK + nb / L;
+    return npart + (npart + 31) / 32;
+}
+
+// ------------------------------------------------------------------------ point import / export
+static constexpr uint32_t P_PLUS1_DIV4[8] = {0xb61f3f52u, 0x4f082305u, 0x5a1c72a3u, 0x65e05aa4u, 0xa0605617u, 0x6e14116du, 0xb84c680au, 0x0c19139cu};
+static constexpr uint32_t HALF_P[8] = {0x6c3e7ea3u, 0x9e10460bu, 0xb438e546u, 0xcbc0b548u, 0x40c0ac2eu, 0xdc2822dbu, 0x7098d014u, 0x18322739u};
+
+__device__ __forceinline__ Fp fp_from_be(const uint8_t *p, bool mask_flags) {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint8_t *q = p + 28 - 4 * i;
+        r.l[i] = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3];
+    }
+    if (mask_flags) r.l[7] &= 0x3fffffffu;
+    return r;
+}
+__device__ __forceinline__ bool fp_lex_largest(const Fp &y_mont) {
+    Fp c = y_mont.from_mont();
+    for (int i = 7; i >= 0; i--) {
+        if (c.l[i] > HALF_P[i]) return true;
+        if (c.l[i] < HALF_P[i]) return false;
+    }
+    return false;
+}
+__device__ __forceinline__ bool fp_sqrt(const Fp &a, Fp &r) {
+    r = a.pow(P_PLUS1_DIV4, 254);
+    return r.sqr() == a;
+}
+__device__ bool fp2_sqrt(const Fp2 &a, Fp2 &r) {
+    if (a.is_zero()) { r = Fp2::zero(); return true; }
+    if (a.a1.is_zero()) {
+        Fp s;
+        if (fp_sqrt(a.a0, s)) { r = Fp2{s, Fp::zero()}; return true; }
+        if (fp_sqrt(a.a0.neg(), s)) { r = Fp2{Fp::zero(), s}; return true; }
+        return false;
+    }
+    Fp n;
+    if (!fp_sqrt(a.a0.sqr() + a.a1.sqr(), n)) return false;
+    const Fp inv2 = Fp::from_u32(2).inv();
+    for (int k = 0; k < 2; k++) {
+        Fp t = (k == 0 ? a.a0 + n : a.a0 - n) * inv2;
+        Fp x0;
+        if (!fp_sqrt(t, x0) || x0.is_zero()) continue;
+        Fp x1 = a.a1 * x0.dbl().inv();
+        Fp2 cand{x0, x1};
+        if (cand.sqr() == a) { r = cand; return true; }
+    }
+    return false;
+}
+
+__global__ void k_g1_from_be(G1Affine *out, const uint8_t *in, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = G1Affine{fp_from_be(in + 64 * i, false).to_mont(), fp_from_be(in + 64 * i + 32, false).to_mont()};
+}
+__global__ void k_g2_from_be(G2Affine *out, const uint8_t *in, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t *p = in + 128 * i;
+    G2Affine r;
+    r.x.a1 = fp_from_be(p, false).to_mont(); r.x.a0 = fp_from_be(p + 32, false).to_mont();
+    r.y.a1 = fp_from_be(p + 64, false).to_mont(); r.y.a0 = fp_from_be(p + 96, false).to_mont();
+    out[i] = r;
+}
+// gnark-crypto marshal flags: 0b10 smallest y, 0b11 largest y, 0b01 infinity
+__global__ void k_g1_decompress(G1Affine *out, const uint8_t *in, size_t n, uint32_t *bad) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t *p = in + 32 * i;
+    const uint32_t flag = p[0] >> 6;
+    if (flag == 1) { out[i] = G1Affine::inf(); return; }
+    if (flag == 0) { atomicAdd(bad, 1u); out[i] = G1Affine::inf(); return; }
+    Fp x = fp_from_be(p, true).to_mont();
+    Fp y;
+    if (!fp_sqrt(x.sqr() * x + Fp::from_u32(3), y)) { atomicAdd(bad, 1u); out[i] = G1Affine::inf(); return; }
+    if (fp_lex_largest(y) != (flag == 3)) y = y.neg();
+    out[i] = G1Affine{x, y};
+}
+__global__ void k_g2_decompress(G2Affine *out, const uint8_t *in, size_t n, uint32_t *bad) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t *p = in + 64 * i;
+    const uint32_t flag = p[0] >> 6;
+    if (flag == 1) { out[i] = G2Affine::inf(); return; }
+    if (flag == 0) { atomicAdd(bad, 1u); out[i] = G2Affine::inf(); return; }
+    Fp2 x{fp_from_be(p + 32, false).to_mont(), fp_from_be(p, true).to_mont()};
+    // twist coefficient b' = 3/(9+u)
+    const Fp2 xi{Fp::from_u32(9), Fp::one()};
+    const Fp2 bt = Fp2{Fp::from_u32(3), Fp::zero()} * xi.inv();
+    Fp2 y;
+    if (!fp2_sqrt(x.sqr() * x + bt, y)) { atomicAdd(bad, 1u); out[i] = G2Affine::inf(); return; }
+    const bool largest = y.a1.is_zero() ? fp_lex_largest(y.a0) : fp_lex_largest(y.a1);
+    if (largest != (flag == 3)) y = y.neg();
+    out[i] = G2Affine{x, y};
+}
+__global__ void k_g1_to_affine_canon(const G1XYZZ *in, G1Affine *out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    G1Affine a = in[i].to_affine();
+    out[i] = G1Affine{a.x.from_mont(), a.y.from_mont()};
+}
+__global__ void k_g2_to_affine_canon(const G2XYZZ *in, G2Affine *out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    G2Affine a = in[i].to_affine();
+    out[i] = G2Affine{a.x.from_mont(), a.y.from_mont()};
+}
+void g1_from_be_bytes(G1Affine *o, const uint8_t *in, size_t n, hipStream_t s) { if (n) hipLaunchKernelGGL(k_g1_from_be, dim3(ceil_div(n, 256)), dim3(256), 0, s, o, in, n); }
+void g2_from_be_bytes(G2Affine *o, const uint8_t *in, size_t n, hipStream_t s) { if (n) hipLaunchKernelGGL(k_g2_from_be, dim3(ceil_div(n, 256)), dim3(256), 0, s, o, in, n); }
+void g1_decompress(G1Affine *o, const uint8_t *in, size_t n, uint32_t *bad, hipStream_t s) { if (n) hipLaunchKernelGGL(k_g1_decompress, dim3(ceil_div(n, 128)), dim3(128), 0, s, o, in, n, bad); }
+void g2_decompress(G2Affine *o, const uint8_t *in, size_t n, uint32_t *bad, hipStream_t s) { if (n) hipLaunchKernelGGL(k_g2_decompress, dim3(ceil_div(n, 128)), dim3(128), 0, s, o, in, n, bad); }
+void g1_to_affine_canonical(const G1XYZZ *in, G1Affine *o, size_t n, hipStream_t s) { if (n) hipLaunchKernelGGL(k_g1_to_affine_canon, dim3(ceil_div(n, 128)), dim3(128), 0, s, in, o, n); }
+void g2_to_affine_canonical(const G2XYZZ *in, G2Affine *o, size_t n, hipStream_t s) { if (n) hipLaunchKernelGGL(k_g2_to_affine_canon, dim3(ceil_div(n, 128)), dim3(128), 0, s, in, o, n); }
+
+}  // namespace zk

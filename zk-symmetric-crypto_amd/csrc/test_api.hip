@@ -1,0 +1,214 @@
+// C-ABI entry points that expose single kernels of the prover for parity tests and micro-benchmarks
+// (declared in include/zkprove.h, section "kernel-level entry points").  Inputs/outputs are host
+// buffers of canonical little-endian 32-byte field elements in [instance][index] order; the entry
+// points transpose to the device layout [index][B], convert to Montgomery form on the GPU, run the
+// production kernels and convert back.
+#include <string.h>
+#include <vector>
+#include "kernels.h"
+
+using namespace zk;
+void fp_to_mont_dev(void *p, size_t count, hipStream_t s);
+
+static thread_local std::string g_last_error;
+extern "C" const char *zkp_last_error(void) { return g_last_error.c_str(); }
+
+#define ZKP_TRY try {
+#define ZKP_CATCH(rv)                         \
+    }                                         \
+    catch (const std::exception &e) {         \
+        g_last_error = e.what();              \
+        fprintf(stderr, "zkprove: %s\n", e.what()); \
+        return rv;                            \
+    }
+
+static void transpose_in(std::vector<Fr> &dst, const uint8_t *src, size_t B, size_t n) {
+    dst.resize(n * B);
+    for (size_t b = 0; b < B; b++)
+        for (size_t i = 0; i < n; i++) memcpy(&dst[i * B + b], src + (b * n + i) * 32, 32);
+}
+static void transpose_out(uint8_t *dst, const std::vector<Fr> &src, size_t B, size_t n) {
+    for (size_t b = 0; b < B; b++)
+        for (size_t i = 0; i < n; i++) memcpy(dst + (b * n + i) * 32, &src[i * B + b], 32);
+}
+static uint32_t brev(uint32_t v, int bits) {
+    uint32_t r = 0;
+    for (int i = 0; i < bits; i++) if (v & (1u << i)) r |= 1u << (bits - 1 - i);
+    return r;
+}
+
+extern "C" int zkp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// mode 0: forward via DIF, 1: inverse via DIF, 2: forward via DIT, 3: inverse via DIT.  natural order in/out.
+extern "C" int zkp_ntt(int logn, long batch, uint8_t *data, int mode) {
+    ZKP_TRY
+    const size_t n = (size_t)1 << logn, B = (size_t)batch;
+    NttDomain dom;
+    dom.init(logn, 0);
+    std::vector<Fr> h, tmp(n * B);
+    transpose_in(h, data, B, n);
+    const bool inverse = mode & 1, use_dit = mode & 2;
+    if (use_dit) {   // DIT consumes bit-reversed input
+        for (size_t i = 0; i < n; i++) memcpy(&tmp[(size_t)brev((uint32_t)i, logn) * B], &h[i * B], B * sizeof(Fr));
+        h.swap(tmp);
+    }
+    DevBuf<Fr> d(n * B);
+    d.upload(h.data(), n * B);
+    fr_to_mont(d.p, n * B, 0);
+    if (use_dit) dom.dit(d.p, B, inverse, nullptr, 0);
+    else dom.dif(d.p, B, inverse, nullptr, 0);
+    if (inverse) dom.scale_ninv(d.p, B, 0);
+    fr_from_mont(d.p, n * B, 0);
+    d.download(h.data(), n * B);
+    ZK_HIP(hipDeviceSynchronize());
+    if (!use_dit) {  // DIF produces bit-reversed output
+        for (size_t i = 0; i < n; i++) memcpy(&tmp[(size_t)brev((uint32_t)i, logn) * B], &h[i * B], B * sizeof(Fr));
+        h.swap(tmp);
+    }
+    transpose_out(data, h, B, n);
+    return 0;
+    ZKP_CATCH(-1)
+}
+
+// a,b,c: [batch][ncons] canonical; h_out: [batch][N] canonical, natural coefficient order
+extern "C" int zkp_compute_h(int logn, long batch, long ncons, const uint8_t *a, const uint8_t *b, const uint8_t *c, uint8_t *h_out) {
+    ZKP_TRY
+    const size_t n = (size_t)1 << logn, B = (size_t)batch;
+    NttDomain dom;
+    dom.init(logn, 0);
+    DevBuf<Fr> d[3];
+    const uint8_t *src[3] = {a, b, c};
+    std::vector<Fr> h(n * B);
+    for (int k = 0; k < 3; k++) {
+        memset(h.data(), 0, n * B * sizeof(Fr));
+        for (size_t bb = 0; bb < B; bb++)
+            for (size_t i = 0; i < (size_t)ncons; i++) memcpy(&h[i * B + bb], src[k] + (bb * ncons + i) * 32, 32);
+        d[k].alloc(n * B);
+        d[k].upload(h.data(), n * B);
+        ZK_HIP(hipDeviceSynchronize());
+        fr_to_mont(d[k].p, n * B, 0);
+    }
+    dom.compute_h(d[0].p, d[1].p, d[2].p, B, 0);
+    fr_from_mont(d[0].p, n * B, 0);
+    d[0].download(h.data(), n * B);
+    ZK_HIP(hipDeviceSynchronize());
+    std::vector<Fr> nat(n * B);
+    for (size_t i = 0; i < n; i++) memcpy(&nat[(size_t)brev((uint32_t)i, logn) * B], &h[i * B], B * sizeof(Fr));
+    transpose_out(h_out, nat, B, n);
+    return 0;
+    ZKP_CATCH(-1)
+}
+
+template <class F>
+static int msm_test(long n_, long batch, const uint8_t *points, const uint8_t *scalars, uint8_t *out, int c) {
+    const size_t n = (size_t)n_, B = (size_t)batch;
+    constexpr size_t PB = sizeof(Affine<F>);          // 64 or 128
+    // points arrive canonical LE (x|y) resp. (x0|x1|y0|y1): upload and convert to Montgomery on device
+    DevBuf<Affine<F>> dp(n ? n : 1);
+    if (n) ZK_HIP(hipMemcpy(dp.p, points, n * PB, hipMemcpyHostToDevice));
+    fp_to_mont_dev(dp.p, n * (PB / 32), 0);
+    std::vector<uint32_t> rows(n);
+    for (size_t j = 0; j < n; j++) rows[j] = (uint32_t)j;
+    MsmBases<F> mb;
+    msm_bases_build(mb, dp.p, n, rows.data(), c, 0);
+    std::vector<Fr> hs;
+    transpose_in(hs, scalars, B, n);
+    DevBuf<Fr> ds(n * B + 1);
+    ds.upload(hs.data(), n * B);
+    fr_to_mont(ds.p, n * B, 0);
+    MsmScratch sc;
+    sc.reserve(B, n * mb.W, (size_t)1 << (c - 1), msm_part_stride(n, c));
+    DevBuf<XYZZ<F>> res(B);
+    DevBuf<Affine<F>> aff(B);
+    msm_batch(mb, ds.p, B, sc, res.p, 0);
+    if constexpr (sizeof(F) == 32) g1_to_affine_canonical((const G1XYZZ *)res.p, (G1Affine *)aff.p, B, 0);
+    else g2_to_affine_canonical((const G2XYZZ *)res.p, (G2Affine *)aff.p, B, 0);
+    ZK_HIP(hipMemcpy(out, aff.p, B * PB, hipMemcpyDeviceToHost));
+    return 0;
+}
+// points: n*64 canonical LE (x|y); scalars [batch][n]; out: batch*64 canonical LE affine, (0,0)=inf
+extern "C" int zkp_msm_g1(long n, long batch, const uint8_t *points, const uint8_t *scalars, uint8_t *out, int c) {
+    ZKP_TRY
+    return msm_test<Fp>(n, batch, points, scalars, out, c);
+    ZKP_CATCH(-1)
+}
+// points: n*128 canonical LE (x.a0|x.a1|y.a0|y.a1)
+extern "C" int zkp_msm_g2(long n, long batch, const uint8_t *points, const uint8_t *scalars, uint8_t *out, int c) {
+    ZKP_TRY
+    return msm_test<Fp2>(n, batch, points, scalars, out, c);
+    ZKP_CATCH(-1)
+}
+
+namespace zk {
+__global__ void k_fp_to_mont(Fp *a, size_t total) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) a[i] = a[i].to_mont();
+}
+}
+void fp_to_mont_dev(void *p, size_t count, hipStream_t s) {
+    if (count) hipLaunchKernelGGL(zk::k_fp_to_mont, dim3(ceil_div(count, 256)), dim3(256), 0, s, (Fp *)p, count);
+}
+
+// -------- micro-benchmarks: raw field-multiplication / point-addition throughput on the device
+namespace zk {
+template <class F>
+__global__ __launch_bounds__(256) void k_bench_mul(F *x, int iters) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    F a = x[i], b = x[i + 1];
+    for (int k = 0; k < iters; k++) { a = a * b; b = b * a; }
+    x[i] = a + b;
+}
+template <class F>
+__global__ __launch_bounds__(256) void k_bench_madd(XYZZ<F> *acc, const Affine<F> *pts, int iters) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    XYZZ<F> a = acc[i];
+    for (int k = 0; k < iters; k++) a.madd(pts[(i + k) & 1023]);
+    acc[i] = a;
+}
+}
+// returns milliseconds for `threads` threads x `iters` iterations; kind 0: 2 Fp mul / iter, 1: G1 madd, 2: G2 madd
+extern "C" double zkp_microbench(int kind, long threads, int iters) {
+    ZKP_TRY
+    size_t T = (size_t)threads;
+    hipEvent_t e0, e1;
+    ZK_HIP(hipEventCreate(&e0)); ZK_HIP(hipEventCreate(&e1));
+    float ms = 0;
+    if (kind == 0) {
+        DevBuf<Fp> x(T + 1);
+        std::vector<Fp> h(T + 1);
+        for (size_t i = 0; i <= T; i++) for (int k = 0; k < 8; k++) h[i].l[k] = (uint32_t)(i * 2654435761u + k * 40503u) & (k == 7 ? 0x0fffffffu : 0xffffffffu);
+        x.upload(h.data(), T + 1);
+        hipLaunchKernelGGL(k_bench_mul<Fp>, dim3(T / 256), dim3(256), 0, 0, x.p, 4);
+        ZK_HIP(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(k_bench_mul<Fp>, dim3(T / 256), dim3(256), 0, 0, x.p, iters);
+        ZK_HIP(hipEventRecord(e1, 0));
+    } else if (kind == 1) {
+        DevBuf<G1XYZZ> acc(T); acc.zero();
+        std::vector<G1Affine> hp(1024);
+        // points = small multiples of the generator computed on device is overkill here: use (1,2) for all (madd hits the doubling path once, then generic)
+        for (auto &p : hp) { p.x = Fp::one(); p.y = Fp::one() + Fp::one(); }
+        DevBuf<G1Affine> pts(1024); pts.upload(hp.data(), 1024);
+        hipLaunchKernelGGL(k_bench_madd<Fp>, dim3(T / 256), dim3(256), 0, 0, acc.p, pts.p, 2);
+        ZK_HIP(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(k_bench_madd<Fp>, dim3(T / 256), dim3(256), 0, 0, acc.p, pts.p, iters);
+        ZK_HIP(hipEventRecord(e1, 0));
+    } else {
+        DevBuf<G2XYZZ> acc(T); acc.zero();
+        std::vector<G2Affine> hp(1024);
+        for (auto &p : hp) { p.x = Fp2::one(); p.y = Fp2{Fp::one() + Fp::one(), Fp::one()}; }
+        DevBuf<G2Affine> pts(1024); pts.upload(hp.data(), 1024);
+        hipLaunchKernelGGL(k_bench_madd<Fp2>, dim3(T / 256), dim3(256), 0, 0, acc.p, pts.p, 2);
+        ZK_HIP(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(k_bench_madd<Fp2>, dim3(T / 256), dim3(256), 0, 0, acc.p, pts.p, iters);
+        ZK_HIP(hipEventRecord(e1, 0));
+    }
+    ZK_HIP(hipEventSynchronize(e1));
+    ZK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return ms;
+    ZKP_CATCH(-1.0)
+}
