@@ -1,0 +1,96 @@
+/* libzkprove -- C ABI of the MI355X-native Groth16 prover (drop-in for the reference's cgo library
+ * `bin/gnark/${platform}-${arch}-libprove.so`, built from gnark/libraries/prover/libprove.go by
+ * gnark/scripts/build.sh:15-20 and loaded through koffi by js/src/gnark/utils.ts:63-92).
+ *
+ * Section 1 is byte-compatible with the header cgo generates for libprove.go; the JS operator
+ * (js/src/gnark/operator.ts:14-47) can load this library unmodified.
+ * Section 2 are additive extensions (batching, deterministic blinding, device-resident benchmark).
+ * Section 3 are kernel-level entry points used by the parity tests.
+ */
+#ifndef ZKPROVE_H
+#define ZKPROVE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- 1. reference ABI (libprove.go) */
+typedef struct { void *data; long long len; long long cap; } GoSlice;     /* js/src/gnark/utils.ts:47-51 */
+typedef struct { void *r0; long long r1; } ProveReturn;                   /* js/src/gnark/utils.ts:53-56 */
+
+/* libprove.go:18-19 -- exported no-op that forces the cgo binding to be linked */
+void enforce_binding(void);
+/* libprove.go:21-24 -> impl/library.go:81-133.  algorithmID: 0 chacha20, 1 aes-128-ctr, 2 aes-256-ctr
+ * (3-5 = *-toprf: not supported, returns 0).  Checks the SHA-256 pins of both artefacts
+ * (impl/library.go:35-49), parses them and uploads the proving key to the GPU.  Idempotent and
+ * callable concurrently (aux_test.go:40-83).  Returns 1 on success, 0 on any failure (never throws). */
+unsigned char InitAlgorithm(unsigned char algorithmID, GoSlice provingKey, GoSlice r1cs);
+/* libprove.go:31-48 -> impl/library.go:135-160.  params = UTF-8 JSON request
+ *   {"cipher":str,"key":b64,"blocks":[{"nonce":b64,"counter":u32,"boundary":u32|null}],"input":b64,"toprf":{}}
+ * returns a malloc'd JSON document {"proof":b64,"ciphertext":b64}; on failure the JSON encoding of the
+ * reference's panic value (a JSON string, or {} for error objects) -- libprove.go:34-44.
+ * The caller releases r0 with Free (utils.ts:223). */
+ProveReturn Prove(GoSlice params);
+/* libprove.go:26-29 */
+void Free(void *pointer);
+/* libprove.go:50-86 -- TOPRF helpers; out of scope: return the JSON string
+ * "toprf is not supported by libzkprove". */
+ProveReturn GenerateOPRFRequestData(GoSlice params);
+ProveReturn TOPRFFinalize(GoSlice params);
+
+/* ---------------------------------------------------------------- 2. extensions */
+/* Accept proving keys whose SHA-256 differs from the pinned KeyHash (impl/library.go:37,42,47).
+ * Needed because the reference's pk.* files are not distributable with this repo; default 0 (strict,
+ * as the reference).  The R1CS pin is always enforced. */
+void ZkpAllowUnpinnedKeys(int allow);
+/* Select the HIP device for this process (default: LOCAL_RANK env or 0).  Call before InitAlgorithm. */
+int ZkpSetDevice(int device);
+/* Drop all initialised algorithms (frees HBM). */
+void ZkpReset(void);
+/* params = JSON array of Prove requests (all for the same cipher); returns a JSON array of Prove
+ * responses.  One GPU batch per call: this is how callers reach GPU throughput, since the reference
+ * FFI is synchronous (utils.ts:200-212; benchmark.ts:30-34 is effectively serial). */
+ProveReturn ProveBatch(GoSlice params);
+/* Prove with caller-supplied blinding (canonical little-endian 32-byte scalars r, s and the value of the
+ * AES circuits' hints.Randomize wire; may be NULL = zero).  gnark samples these from crypto/rand, which is
+ * the only source of non-determinism in a proof; fixing them makes proofs reproducible for parity tests. */
+ProveReturn ZkpProveDeterministic(GoSlice params, const uint8_t *r32, const uint8_t *s32, const uint8_t *randomize32);
+
+/* Device-resident batch benchmark (bench.py).  inputs: [batch][n_inputs] u32 witness assignment
+ * (public inputs without the constant one, then secret), r/s/randomize: [batch][32] canonical LE.
+ * zkp_bench_step = one pass of the whole proving path over the resident batch; times7 (ms, HIP events):
+ * solve, commit, ntt, msm_g1, msm_g2, finalize, total.  proofs: [batch][384] canonical LE affine
+ * coordinates Ar(64) Bs(128: x.a0 x.a1 y.a0 y.a1) Krs(64) commitment(64) pok(64). */
+long zkp_n_inputs(int algorithmID);
+int zkp_bench_upload(int algorithmID, long batch, const uint32_t *inputs, const uint8_t *r, const uint8_t *s, const uint8_t *randomize);
+int zkp_bench_step(int algorithmID, float *times7);
+int zkp_bench_fetch(int algorithmID, uint8_t *proofs, uint32_t *errs);
+/* after a step: copy out the solved wire vectors [batch][n_wires][32] and quotient coefficients
+ * [batch][N][32] (canonical LE, natural order) -- parity tests only */
+int zkp_debug_fetch(int algorithmID, uint8_t *wires, uint8_t *h);
+/* request -> witness assignment (host logic only, no GPU): fills inputs[n_inputs], output bytes; returns
+ * 0, or -1 with the reference's panic text in zkp_last_error() */
+int zkp_request_witness(GoSlice params, uint32_t *inputs, long inputs_cap, uint8_t *output, long output_cap, long *n_inputs, long *n_output);
+/* serialise one 384-byte proof record (zkp_bench_fetch layout) as gnark Proof.WriteTo bytes; returns length */
+long zkp_proof_serialize(const uint8_t *proof384, int has_commitment, uint8_t *out, long cap);
+/* R1CS decoder check (no GPU): returns 0 and fills stats[8] = constraints, public, secret, internal,
+ * instructions, calldata words, levels, coefficients */
+int zkp_r1cs_stats(GoSlice r1cs, uint64_t *stats8);
+
+/* ---------------------------------------------------------------- 3. kernel-level entry points */
+const char *zkp_last_error(void);
+int zkp_device_count(void);
+/* data: [batch][2^logn][32] canonical LE; mode 0 fwd (DIF kernels) 1 inv (DIF) 2 fwd (DIT) 3 inv (DIT) */
+int zkp_ntt(int logn, long batch, uint8_t *data, int mode);
+/* computeH: a,b,c [batch][ncons][32] -> h [batch][2^logn][32] (natural coefficient order) */
+int zkp_compute_h(int logn, long batch, long ncons, const uint8_t *a, const uint8_t *b, const uint8_t *c, uint8_t *h_out);
+/* points n*64 (G1: x|y) / n*128 (G2: x.a0|x.a1|y.a0|y.a1) canonical LE; scalars [batch][n][32]; c = window bits */
+int zkp_msm_g1(long n, long batch, const uint8_t *points, const uint8_t *scalars, uint8_t *out, int c);
+int zkp_msm_g2(long n, long batch, const uint8_t *points, const uint8_t *scalars, uint8_t *out, int c);
+/* kind 0: Fp mul (2/iter) 1: G1 mixed add 2: G2 mixed add; returns milliseconds */
+double zkp_microbench(int kind, long threads, int iters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -54,3 +54,137 @@ def last_error() -> str:
 
 def device_count() -> int:
     return lib.zkp_device_count()
+
+# --------------------------------------------------------------------------- reference operator API
+import json as _json
+
+import numpy as _np
+
+ALGORITHM_IDS = {"chacha20": 0, "aes-128-ctr": 1, "aes-256-ctr": 2}      # impl/library.go:17-24, js/src/config.ts
+FILE_EXT = {"chacha20": "chacha20", "aes-128-ctr": "aes128", "aes-256-ctr": "aes256"}   # js/src/gnark/operator.ts:6-12
+
+_u8p = C.c_void_p
+_sig("enforce_binding", None, [])
+_sig("InitAlgorithm", C.c_ubyte, [C.c_ubyte, GoSlice, GoSlice])
+_sig("Prove", ProveReturn, [GoSlice])
+_sig("ProveBatch", ProveReturn, [GoSlice])
+_sig("Free", None, [C.c_void_p])
+_sig("GenerateOPRFRequestData", ProveReturn, [GoSlice])
+_sig("TOPRFFinalize", ProveReturn, [GoSlice])
+_sig("ZkpAllowUnpinnedKeys", None, [_i32])
+_sig("ZkpSetDevice", _i32, [_i32])
+_sig("ZkpReset", None, [])
+_sig("ZkpProveDeterministic", ProveReturn, [GoSlice, _u8p, _u8p, _u8p])
+_sig("zkp_n_inputs", _i64, [_i32])
+_sig("zkp_bench_upload", _i32, [_i32, _i64, _vp, _vp, _vp, _vp])
+_sig("zkp_bench_step", _i32, [_i32, _vp])
+_sig("zkp_bench_fetch", _i32, [_i32, _vp, _vp])
+_sig("zkp_debug_fetch", _i32, [_i32, _vp, _vp])
+_sig("zkp_request_witness", _i32, [GoSlice, _vp, _i64, _vp, _i64, C.POINTER(C.c_long), C.POINTER(C.c_long)])
+_sig("zkp_last_panic", C.c_char_p, [])
+_sig("zkp_proof_serialize", _i64, [_vp, _i32, _vp, _i64])
+_sig("zkp_r1cs_stats", _i32, [GoSlice, _vp])
+
+
+def _slice(b: bytes):
+    buf = C.create_string_buffer(b, len(b))
+    return GoSlice(C.cast(buf, C.c_void_p), len(b), len(b)), buf
+
+
+def _take(ret: ProveReturn) -> bytes:
+    out = C.string_at(ret.r0, ret.r1)
+    lib.Free(ret.r0)                      # js/src/gnark/utils.ts:223
+    return out
+
+
+def init_algorithm(algorithm_id: int, proving_key: bytes, r1cs: bytes) -> bool:
+    """lib.initAlgorithm(id, pk, r1cs)  (js/src/gnark/utils.ts:111-136)"""
+    s1, k1 = _slice(proving_key)
+    s2, k2 = _slice(r1cs)
+    return bool(lib.InitAlgorithm(algorithm_id, s1, s2))
+
+
+def prove_raw(request_json: bytes) -> bytes:
+    s, keep = _slice(request_json)
+    return _take(lib.Prove(s))
+
+
+def prove(request: dict) -> dict:
+    """ZKOperator.groth16Prove for the gnark engine (js/src/gnark/operator.ts:22-32): returns the decoded
+    response; raises if the library answered with a panic value instead of a proof."""
+    res = _json.loads(prove_raw(_json.dumps(request).encode()))
+    if not isinstance(res, dict) or "proof" not in res:
+        raise RuntimeError("prove failed: %r" % (res,))
+    return res
+
+
+def prove_deterministic_raw(request_json: bytes, r: int, s: int, randomize: int = 0) -> bytes:
+    sl, keep = _slice(request_json)
+    bufs = [C.create_string_buffer(int(v).to_bytes(32, "little"), 32) for v in (r, s, randomize)]
+    return _take(lib.ZkpProveDeterministic(sl, *[C.cast(b, C.c_void_p) for b in bufs]))
+
+
+def prove_batch_raw(requests_json: bytes) -> bytes:
+    s, keep = _slice(requests_json)
+    return _take(lib.ProveBatch(s))
+
+
+def request_witness(request_json: bytes):
+    """-> (algorithm id, witness assignment uint32[n], output bytes); raises ValueError(panic json)"""
+    s, keep = _slice(request_json)
+    inp = _np.zeros(4096, _np.uint32)
+    out = _np.zeros(256, _np.uint8)
+    ni, no = C.c_long(0), C.c_long(0)
+    rc = lib.zkp_request_witness(s, inp.ctypes.data, inp.size, out.ctypes.data, out.size, C.byref(ni), C.byref(no))
+    if rc < 0:
+        raise ValueError(lib.zkp_last_panic().decode())
+    return rc, inp[:ni.value].copy(), out[:no.value].tobytes()
+
+
+def r1cs_stats(r1cs: bytes):
+    s, keep = _slice(r1cs)
+    st = _np.zeros(8, _np.uint64)
+    if lib.zkp_r1cs_stats(s, st.ctypes.data) != 0:
+        raise ValueError("r1cs parse failed")
+    return [int(v) for v in st]
+
+
+class ResidentBatch:
+    """Device-resident batch of one algorithm (bench.py / parity tests)."""
+
+    def __init__(self, algorithm_id: int, inputs, r, s, randomize):
+        self.alg = algorithm_id
+        self.inputs = _np.ascontiguousarray(inputs, _np.uint32)
+        self.batch = self.inputs.shape[0]
+        le = lambda vals: _np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in vals), _np.uint8).copy()
+        self._r, self._s, self._rnd = le(r), le(s), le(randomize)
+        rc = lib.zkp_bench_upload(self.alg, self.batch, self.inputs.ctypes.data, self._r.ctypes.data, self._s.ctypes.data, self._rnd.ctypes.data)
+        if rc != 0:
+            raise RuntimeError("zkp_bench_upload failed")
+
+    def step(self):
+        t = _np.zeros(7, _np.float32)
+        if lib.zkp_bench_step(self.alg, t.ctypes.data) != 0:
+            raise RuntimeError("zkp_bench_step failed")
+        return dict(zip(("solve", "commit", "ntt", "msm_g1", "msm_g2", "finalize", "total"), [float(x) for x in t]))
+
+    def fetch(self):
+        proofs = _np.zeros((self.batch, 384), _np.uint8)
+        errs = _np.zeros(self.batch, _np.uint32)
+        if lib.zkp_bench_fetch(self.alg, proofs.ctypes.data, errs.ctypes.data) != 0:
+            raise RuntimeError("zkp_bench_fetch failed")
+        return proofs, errs
+
+    def debug(self, n_wires, domain):
+        wires = _np.zeros((self.batch, n_wires, 32), _np.uint8)
+        h = _np.zeros((self.batch, domain, 32), _np.uint8)
+        if lib.zkp_debug_fetch(self.alg, wires.ctypes.data, h.ctypes.data) != 0:
+            raise RuntimeError("zkp_debug_fetch failed")
+        return wires, h
+
+
+def proof_serialize(proof384, has_commitment: bool) -> bytes:
+    p = _np.ascontiguousarray(proof384, _np.uint8)
+    out = _np.zeros(256, _np.uint8)
+    n = lib.zkp_proof_serialize(p.ctypes.data, int(has_commitment), out.ctypes.data, out.size)
+    return out[:n].tobytes()

@@ -1,0 +1,454 @@
+// C ABI of libzkprove.so (include/zkprove.h): the reference's cgo surface
+// (gnark/libraries/prover/libprove.go:18-86) plus the registry / request handling of
+// gnark/libraries/prover/impl/library.go:17-160 and impl/provers.go:48-280, re-implemented in C++.
+#include <string.h>
+#include <memory>
+#include <mutex>
+#include "../../include/zkprove.h"
+#include "prover.h"
+
+using namespace zk;
+
+namespace {
+
+struct AlgInfo {
+    const char *name;
+    const char *key_hash;      // impl/library.go:37,42,47
+    const char *circuit_hash;  // impl/library.go:38,43,48
+    int kind;                  // 0 chacha, 1 aes
+};
+const AlgInfo ALGS[3] = {
+    {"chacha20", "e74dbfb793af8e3b62f8be035fa20764e1076ac415057204dbc1336e3079d12f", "517cdf7642c84dcb165a29f0accea413178fc11b21d8998461156a1acce6ebbd", 0},
+    {"aes-128-ctr", "91c509d3324b7c0c8eaf7cba9b0910a4d880533d1e613d37b48b8747c8f2412b", "8ef58f13706568eed44f9aa40b97da7c2f2a7f1bce47b7bfe52f7df860a049fb", 1},
+    {"aes-256-ctr", "bc8277d9f9a3e06b411210a5b78fc05146529971ef93e7a58d48cd7c24e17586", "7f589a6d1a24efa6d01f663c11b671e0abef196c15cadb93d2c6b226df7bf0dd", 1},
+};
+const char *TOPRF_NAMES[3] = {"chacha20-toprf", "aes-128-ctr-toprf", "aes-256-ctr-toprf"};
+constexpr int CHACHA_BLOCKS = 2;   // gnark/circuits/chachaV3/common.go:8
+constexpr int AES_BLOCKS = 5;      // gnark/circuits/aesV2/common.go:10
+
+struct Slot {
+    std::mutex lock;                     // impl/library.go:77-78 initLock
+    std::unique_ptr<Algorithm> alg;      // non-null == initDone
+};
+Slot g_slots[3];
+bool g_allow_unpinned = false;
+int g_device = -1;
+std::once_flag g_dev_once;
+
+thread_local std::string g_err;
+
+void select_device() {
+    std::call_once(g_dev_once, [] {
+        int dev = g_device;
+        if (dev < 0) {
+            const char *lr = getenv("LOCAL_RANK");
+            dev = lr ? atoi(lr) : 0;
+            int n = 0;
+            if (hipGetDeviceCount(&n) == hipSuccess && n > 0) dev %= n;
+        }
+        (void)hipSetDevice(dev);
+    });
+}
+
+ProveReturn make_return(const std::string &s) {
+    ProveReturn r;
+    r.r0 = malloc(s.size() ? s.size() : 1);      // C.CBytes (libprove.go:47)
+    memcpy(r.r0, s.data(), s.size());
+    r.r1 = (long long)s.size();
+    return r;
+}
+
+// A "panic" of the reference: carries the JSON encoding of the panic value (libprove.go:34-44)
+struct Panic {
+    std::string json;
+};
+[[noreturn]] void panic_str(const std::string &msg) { throw Panic{json_quote(msg)}; }
+[[noreturn]] void panic_err() { throw Panic{"{}"}; }      // json.Marshal of an error object without exported fields
+
+struct Request {
+    int alg = -1;
+    std::vector<uint8_t> key, input;
+    std::vector<std::vector<uint8_t>> nonces;
+    std::vector<uint32_t> counters;
+};
+
+bool get_bytes(const Json *j, std::vector<uint8_t> &out) {     // Go: []uint8 <- base64 string | null
+    out.clear();
+    if (!j || j->t == Json::NUL) return true;
+    if (j->t == Json::STR) return base64_decode(j->s, out);
+    if (j->t == Json::ARR) {                                     // Go also accepts an array of numbers
+        for (auto &e : j->a) {
+            if (e.t != Json::NUM || e.num < 0 || e.num > 255 || e.num != (double)(int)e.num) return false;
+            out.push_back((uint8_t)e.num);
+        }
+        return true;
+    }
+    return false;
+}
+bool get_u32(const Json *j, uint32_t &out) {
+    out = 0;
+    if (!j || j->t == Json::NUL) return true;
+    if (j->t != Json::NUM) return false;
+    for (char ch : j->raw_num) if (ch < '0' || ch > '9') return false;   // Go rejects -1, 1.5, 1e3 for uint32
+    if (j->num > 4294967295.0) return false;
+    out = (uint32_t)strtoull(j->raw_num.c_str(), nullptr, 10);
+    return true;
+}
+
+// impl/library.go:135-145: decode + dispatch
+Request decode_request(const Json &j) {
+    if (j.t == Json::NUL) {
+        // json "null" leaves *InputParams nil -> nil dereference panic (runtime.Error -> {})
+        panic_err();
+    }
+    if (j.t != Json::OBJ) panic_err();
+    Request rq;
+    std::string cipher;
+    if (const Json *c = j.get("cipher")) {
+        if (c->t == Json::STR) cipher = c->s;
+        else if (c->t != Json::NUL) panic_err();
+    }
+    if (!get_bytes(j.get("key"), rq.key) || !get_bytes(j.get("input"), rq.input)) panic_err();
+    if (const Json *bl = j.get("blocks")) {
+        if (bl->t == Json::ARR) {
+            for (auto &b : bl->a) {
+                std::vector<uint8_t> nonce;
+                uint32_t ctr = 0, boundary = 0;
+                if (b.t == Json::OBJ) {
+                    if (!get_bytes(b.get("nonce"), nonce) || !get_u32(b.get("counter"), ctr) || !get_u32(b.get("boundary"), boundary)) panic_err();
+                } else if (b.t != Json::NUL) panic_err();
+                rq.nonces.push_back(nonce);
+                rq.counters.push_back(ctr);
+            }
+        } else if (bl->t != Json::NUL) panic_err();
+    }
+    if (const Json *t = j.get("toprf")) {
+        if (t->t != Json::OBJ && t->t != Json::NUL) panic_err();
+    }
+    for (int i = 0; i < 3; i++) if (cipher == ALGS[i].name) rq.alg = i;
+    if (rq.alg < 0) {
+        for (int i = 0; i < 3; i++)
+            if (cipher == TOPRF_NAMES[i]) panic_str("proving params are not initialized for cipher: " + cipher);   // never initialisable here
+        panic_str("could not find prover for" + cipher);            // library.go:158 (sic, no space)
+    }
+    return rq;
+}
+
+// provers.go:116-173 / 199-263: checks, native cipher, witness assignment
+void build_witness(const Request &rq, std::vector<uint32_t> &w, std::vector<uint8_t> &output) {
+    const AlgInfo &ai = ALGS[rq.alg];
+    auto len_s = [](size_t n) { return std::to_string(n); };
+    if (ai.kind == 0) {
+        if (rq.key.size() != 32) panic_str("key length must be 32: " + len_s(rq.key.size()));
+        if (rq.nonces.size() != (size_t)CHACHA_BLOCKS) panic_str("blocks array length must be " + len_s(CHACHA_BLOCKS) + ": " + len_s(rq.nonces.size()));
+        for (size_t i = 0; i < rq.nonces.size(); i++)
+            if (rq.nonces[i].size() != 12) panic_str("block[" + len_s(i) + "] nonce length must be 12: " + len_s(rq.nonces[i].size()));
+        if (rq.input.size() != 64 * CHACHA_BLOCKS) panic_str("input length must be " + len_s(64 * CHACHA_BLOCKS) + ": " + len_s(rq.input.size()));
+        output.resize(rq.input.size());
+        for (int b = 0; b < CHACHA_BLOCKS; b++) {
+            uint8_t ks[64];
+            chacha20_block(rq.key.data(), rq.counters[b], rq.nonces[b].data(), ks);
+            for (int i = 0; i < 64; i++) output[64 * b + i] = rq.input[64 * b + i] ^ ks[i];
+        }
+        w.clear();
+        auto bits = [&](uint32_t v) { for (int i = 0; i < 32; i++) w.push_back((v >> i) & 1); };       // utils/bytes.go:32-48
+        auto le32 = [](const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); };
+        auto be32 = [](const uint8_t *p) { return (uint32_t)p[3] | ((uint32_t)p[2] << 8) | ((uint32_t)p[1] << 16) | ((uint32_t)p[0] << 24); };
+        for (int b = 0; b < CHACHA_BLOCKS; b++) bits(rq.counters[b]);                                   // Counter [2][32]
+        for (int b = 0; b < CHACHA_BLOCKS; b++) for (int k = 0; k < 3; k++) bits(le32(rq.nonces[b].data() + 4 * k));   // Nonce [2][3][32]
+        for (int k = 0; k < 32; k++) bits(be32(rq.input.data() + 4 * k));                               // In
+        for (int k = 0; k < 32; k++) bits(be32(output.data() + 4 * k));                                 // Out
+        for (int k = 0; k < 8; k++) bits(le32(rq.key.data() + 4 * k));                                  // Key (secret)
+    } else {
+        if (rq.key.size() != 32 && rq.key.size() != 16) panic_str("key length must be 16 or 32: " + len_s(rq.key.size()));
+        if (rq.nonces.size() != (size_t)AES_BLOCKS) panic_str("blocks array length must be " + len_s(AES_BLOCKS) + ": " + len_s(rq.nonces.size()));
+        for (size_t i = 0; i < rq.nonces.size(); i++)
+            if (rq.nonces[i].size() != 12) panic_str("block[" + len_s(i) + "] nonce length must be 12: " + len_s(rq.nonces[i].size()));
+        if (rq.input.size() != 16 * AES_BLOCKS) panic_str("input length must be " + len_s(16 * AES_BLOCKS) + ": " + len_s(rq.input.size()));
+        // the circuit is compiled for one key size: a 16-byte key sent to aes-256-ctr (or vice versa) makes
+        // frontend.NewWitness fail in the reference (schema mismatch) -> panic(err) -> {}
+        if ((rq.alg == 1) != (rq.key.size() == 16)) panic_err();
+        output.resize(rq.input.size());
+        for (int b = 0; b < AES_BLOCKS; b++) {
+            uint8_t iv[16], ks[16];
+            memcpy(iv, rq.nonces[b].data(), 12);
+            iv[12] = rq.counters[b] >> 24; iv[13] = rq.counters[b] >> 16; iv[14] = rq.counters[b] >> 8; iv[15] = rq.counters[b];
+            aes_encrypt_block(rq.key.data(), rq.key.size(), iv, ks);
+            for (int i = 0; i < 16; i++) output[16 * b + i] = rq.input[16 * b + i] ^ ks[i];
+        }
+        w.clear();
+        for (int b = 0; b < AES_BLOCKS; b++) for (int i = 0; i < 12; i++) w.push_back(rq.nonces[b][i]);   // Nonce [5][12]
+        for (int b = 0; b < AES_BLOCKS; b++) w.push_back(rq.counters[b]);                                 // Counter [5]
+        for (uint8_t v : rq.input) w.push_back(v);
+        for (uint8_t v : output) w.push_back(v);
+        for (uint8_t v : rq.key) w.push_back(v);                                                          // Key (secret)
+    }
+}
+
+Algorithm *get_alg(int id) {
+    std::lock_guard<std::mutex> lk(g_slots[id].lock);
+    return g_slots[id].alg.get();
+}
+
+std::string response_json(const std::vector<uint8_t> &proof, const std::vector<uint8_t> &ct) {
+    return "{\"proof\":\"" + base64_encode(proof.data(), proof.size()) + "\",\"ciphertext\":\"" + base64_encode(ct.data(), ct.size()) + "\"}";
+}
+
+// Prove a list of decoded requests of ONE algorithm as one GPU batch.
+std::vector<std::string> prove_requests(int alg_id, const std::vector<Request> &rqs, const U256 *r_fix, const U256 *s_fix, const U256 *rnd_fix) {
+    Algorithm *alg = get_alg(alg_id);
+    if (!alg) panic_str(std::string("proving params are not initialized for cipher: ") + ALGS[alg_id].name);   // library.go:143-145
+    const size_t B = rqs.size(), ni = alg->n_inputs();
+    std::vector<uint32_t> inputs(B * ni);
+    std::vector<std::vector<uint8_t>> outs(B);
+    for (size_t i = 0; i < B; i++) {
+        std::vector<uint32_t> w;
+        build_witness(rqs[i], w, outs[i]);
+        if (w.size() != ni) panic_err();
+        memcpy(&inputs[i * ni], w.data(), ni * 4);
+    }
+    std::vector<U256> r(B), s(B), rnd(B);
+    for (size_t i = 0; i < B; i++) {
+        r[i] = r_fix ? r_fix[i] : fr_random();
+        s[i] = s_fix ? s_fix[i] : fr_random();
+        rnd[i] = rnd_fix ? rnd_fix[i] : fr_random();
+    }
+    std::vector<ProofPoints> pp(B);
+    std::vector<uint32_t> errs(B);
+    alg->prove_batch(B, inputs.data(), r.data(), s.data(), rnd.data(), pp.data(), errs.data());
+    std::vector<std::string> res(B);
+    for (size_t i = 0; i < B; i++) {
+        if (errs[i]) { res[i] = "{}"; continue; }       // groth16.Prove returned an error -> panic(err) -> {}
+        res[i] = response_json(proof_serialize(pp[i], alg->has_commit), outs[i]);
+    }
+    return res;
+}
+
+ProveReturn prove_one(GoSlice params, const U256 *r, const U256 *s, const U256 *rnd) {
+    std::string result;
+    try {
+        select_device();
+        Json j;
+        std::string err;
+        if (!json_parse((const char *)params.data, (size_t)params.len, j, err)) panic_err();   // *json.SyntaxError -> {"Offset":n}; offsets are not reproduced
+        Request rq = decode_request(j);
+        std::vector<Request> v{rq};
+        result = prove_requests(rq.alg, v, r, s, rnd)[0];
+    } catch (const Panic &p) {
+        result = p.json;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "zkprove: %s\n", e.what());
+        g_err = e.what();
+        result = "{}";
+    }
+    return make_return(result);
+}
+
+U256 u256_from_le(const uint8_t *p) {
+    U256 v;
+    if (p) memcpy(v.l, p, 32); else memset(v.l, 0, 32);
+    return v;
+}
+
+}  // namespace
+
+extern "C" {
+
+void enforce_binding(void) {}
+
+void Free(void *pointer) { free(pointer); }
+
+void ZkpAllowUnpinnedKeys(int allow) { g_allow_unpinned = allow != 0; }
+int ZkpSetDevice(int device) {
+    g_device = device;
+    return hipSetDevice(device) == hipSuccess ? 0 : -1;
+}
+void ZkpReset(void) {
+    for (auto &s : g_slots) {
+        std::lock_guard<std::mutex> lk(s.lock);
+        s.alg.reset();
+    }
+}
+
+unsigned char InitAlgorithm(unsigned char algorithmID, GoSlice provingKey, GoSlice r1cs) {
+    if (algorithmID >= 3) {
+        if (algorithmID < 6) printf("algorithm %d (toprf) is not supported by libzkprove\n", (int)algorithmID);
+        return 0;
+    }
+    try {
+        select_device();
+        Slot &slot = g_slots[algorithmID];
+        std::lock_guard<std::mutex> lk(slot.lock);
+        if (slot.alg) return 1;                                                    // library.go:92-94
+        const AlgInfo &ai = ALGS[algorithmID];
+        uint8_t h[32];
+        sha256((const uint8_t *)provingKey.data, (size_t)provingKey.len, h);
+        if (hex_encode(h, 32) != ai.key_hash && !g_allow_unpinned && !getenv("ZKPROVE_ALLOW_UNPINNED_PK")) {
+            printf("incorrect key hash %s expected %s \n", hex_encode(h, 32).c_str(), ai.key_hash);   // library.go:99-101
+            return 0;
+        }
+        sha256((const uint8_t *)r1cs.data, (size_t)r1cs.len, h);
+        if (hex_encode(h, 32) != ai.circuit_hash) {
+            printf("circuit hash mismatch, expected %s, got %s\n", ai.circuit_hash, hex_encode(h, 32).c_str());   // library.go:115-117
+            return 0;
+        }
+        std::unique_ptr<Algorithm> a(new Algorithm());
+        a->load((const uint8_t *)provingKey.data, (size_t)provingKey.len, (const uint8_t *)r1cs.data, (size_t)r1cs.len);
+        slot.alg = std::move(a);
+        printf("Initialized %s\n", ai.name);                                        // library.go:129
+        return 1;
+    } catch (const std::exception &e) {
+        printf("%s\n", e.what());                                                   // library.go:82-87
+        g_err = e.what();
+        return 0;
+    } catch (...) {
+        return 0;
+    }
+}
+
+ProveReturn Prove(GoSlice params) { return prove_one(params, nullptr, nullptr, nullptr); }
+
+ProveReturn ZkpProveDeterministic(GoSlice params, const uint8_t *r32, const uint8_t *s32, const uint8_t *randomize32) {
+    U256 r = u256_from_le(r32), s = u256_from_le(s32), rnd = u256_from_le(randomize32);
+    return prove_one(params, &r, &s, &rnd);
+}
+
+ProveReturn ProveBatch(GoSlice params) {
+    std::string result;
+    try {
+        select_device();
+        Json j;
+        std::string err;
+        if (!json_parse((const char *)params.data, (size_t)params.len, j, err) || j.t != Json::ARR) panic_err();
+        const size_t n = j.a.size();
+        std::vector<std::string> res(n);
+        std::vector<Request> rqs;
+        std::vector<size_t> idx;
+        int alg = -1;
+        for (size_t i = 0; i < n; i++) {
+            try {
+                Request rq = decode_request(j.a[i]);
+                if (alg < 0) alg = rq.alg;
+                if (rq.alg != alg) panic_str("ProveBatch: all requests must use the same cipher");
+                // validate now so that one bad request does not poison the batch
+                std::vector<uint32_t> w; std::vector<uint8_t> o;
+                build_witness(rq, w, o);
+                rqs.push_back(std::move(rq));
+                idx.push_back(i);
+            } catch (const Panic &p) {
+                res[i] = p.json;
+            }
+        }
+        if (!rqs.empty()) {
+            try {
+                auto out = prove_requests(alg, rqs, nullptr, nullptr, nullptr);
+                for (size_t k = 0; k < idx.size(); k++) res[idx[k]] = out[k];
+            } catch (const Panic &p) {
+                for (size_t k = 0; k < idx.size(); k++) res[idx[k]] = p.json;
+            }
+        }
+        result = "[";
+        for (size_t i = 0; i < n; i++) { if (i) result += ","; result += res[i]; }
+        result += "]";
+    } catch (const Panic &p) {
+        result = p.json;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "zkprove: %s\n", e.what());
+        result = "{}";
+    }
+    return make_return(result);
+}
+
+ProveReturn GenerateOPRFRequestData(GoSlice) { return make_return(json_quote("toprf is not supported by libzkprove")); }
+ProveReturn TOPRFFinalize(GoSlice) { return make_return(json_quote("toprf is not supported by libzkprove")); }
+
+// ------------------------------------------------------------------------------ bench / debug
+long zkp_n_inputs(int id) {
+    if (id < 0 || id >= 3) return -1;
+    Algorithm *a = get_alg(id);
+    return a ? (long)a->n_inputs() : -1;
+}
+extern const char *zkp_last_error(void);
+static thread_local std::string g_cabi_err;
+#define CABI_TRY try {
+#define CABI_CATCH                                      \
+    }                                                   \
+    catch (const std::exception &e) {                   \
+        fprintf(stderr, "zkprove: %s\n", e.what());     \
+        return -1;                                      \
+    }
+
+int zkp_bench_upload(int id, long batch, const uint32_t *inputs, const uint8_t *r, const uint8_t *s, const uint8_t *randomize) {
+    CABI_TRY
+    Algorithm *a = (id >= 0 && id < 3) ? get_alg(id) : nullptr;
+    if (!a) throw ZkError("algorithm not initialised");
+    a->resident_upload((size_t)batch, inputs, (const U256 *)r, (const U256 *)s, (const U256 *)randomize);
+    return 0;
+    CABI_CATCH
+}
+int zkp_bench_step(int id, float *times7) {
+    CABI_TRY
+    Algorithm *a = (id >= 0 && id < 3) ? get_alg(id) : nullptr;
+    if (!a || !a->res) throw ZkError("algorithm not initialised / nothing uploaded");
+    PhaseTimes t;
+    a->resident_prove(&t);
+    if (times7) { times7[0] = t.solve; times7[1] = t.commit; times7[2] = t.ntt; times7[3] = t.msm_g1; times7[4] = t.msm_g2; times7[5] = t.finalize; times7[6] = t.total; }
+    return 0;
+    CABI_CATCH
+}
+int zkp_bench_fetch(int id, uint8_t *proofs, uint32_t *errs) {
+    CABI_TRY
+    Algorithm *a = (id >= 0 && id < 3) ? get_alg(id) : nullptr;
+    if (!a || !a->res) throw ZkError("algorithm not initialised / nothing uploaded");
+    a->resident_download((ProofPoints *)proofs, errs);
+    return 0;
+    CABI_CATCH
+}
+int zkp_debug_fetch(int id, uint8_t *wires, uint8_t *h) {
+    CABI_TRY
+    Algorithm *a = (id >= 0 && id < 3) ? get_alg(id) : nullptr;
+    if (!a || !a->res) throw ZkError("algorithm not initialised / nothing uploaded");
+    a->debug_fetch(wires, h);
+    return 0;
+    CABI_CATCH
+}
+int zkp_request_witness(GoSlice params, uint32_t *inputs, long inputs_cap, uint8_t *output, long output_cap, long *n_inputs, long *n_output) {
+    try {
+        Json j;
+        std::string err;
+        if (!json_parse((const char *)params.data, (size_t)params.len, j, err)) panic_err();
+        Request rq = decode_request(j);
+        std::vector<uint32_t> w;
+        std::vector<uint8_t> o;
+        build_witness(rq, w, o);
+        if ((long)w.size() > inputs_cap || (long)o.size() > output_cap) return -2;
+        memcpy(inputs, w.data(), w.size() * 4);
+        memcpy(output, o.data(), o.size());
+        *n_inputs = (long)w.size();
+        *n_output = (long)o.size();
+        return rq.alg;
+    } catch (const Panic &p) {
+        g_err = p.json;
+        return -1;
+    }
+}
+const char *zkp_last_panic(void) { return g_err.c_str(); }
+long zkp_proof_serialize(const uint8_t *proof384, int has_commitment, uint8_t *out, long cap) {
+    ProofPoints p;
+    memcpy(&p, proof384, sizeof(p));
+    auto v = proof_serialize(p, has_commitment != 0);
+    if ((long)v.size() > cap) return -1;
+    memcpy(out, v.data(), v.size());
+    return (long)v.size();
+}
+int zkp_r1cs_stats(GoSlice r1cs, uint64_t *st) {
+    CABI_TRY
+    R1cs cs;
+    r1cs_parse((const uint8_t *)r1cs.data, (size_t)r1cs.len, cs);
+    st[0] = cs.nb_constraints; st[1] = cs.nb_public; st[2] = cs.nb_secret; st[3] = cs.nb_internal;
+    st[4] = cs.nb_instructions(); st[5] = cs.calldata.size(); st[6] = cs.levels.size(); st[7] = cs.coeffs.size();
+    return 0;
+    CABI_CATCH
+}
+
+}  // extern "C"

@@ -1,0 +1,53 @@
+// Host-side helpers of the request path: SHA-256, base64, a small JSON reader, the two ciphers, and the
+// handful of 256-bit integer operations the host needs (everything heavy runs on the GPU).
+#pragma once
+#include <stdint.h>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace zk {
+
+void sha256(const uint8_t *msg, size_t len, uint8_t out[32]);
+std::string hex_encode(const uint8_t *p, size_t n);
+
+std::string base64_encode(const uint8_t *p, size_t n);
+bool base64_decode(const std::string &s, std::vector<uint8_t> &out);   // std encoding, padding required as Go's
+
+// ---- JSON (RFC 8259 subset sufficient for Go's encoding/json request shapes) ----
+struct Json {
+    enum T { NUL, BOOL, NUM, STR, ARR, OBJ } t = NUL;
+    bool b = false;
+    double num = 0;
+    std::string raw_num;   // textual number, for exact integer checks
+    std::string s;
+    std::vector<Json> a;
+    std::vector<std::pair<std::string, Json>> o;
+    // Go's json.Unmarshal matches keys case-insensitively, preferring an exact match
+    const Json *get(const char *key) const;
+};
+// returns false and fills err on malformed input
+bool json_parse(const char *p, size_t n, Json &out, std::string &err);
+std::string json_quote(const std::string &s);   // Go json.Marshal string escaping (HTML-safe form)
+
+// ---- ciphers (the reference computes the ciphertext itself: provers.go:139-150, 227-238) ----
+void chacha20_block(const uint8_t key[32], uint32_t counter, const uint8_t nonce[12], uint8_t out[64]);
+// key_len 16 or 32
+void aes_encrypt_block(const uint8_t *key, size_t key_len, const uint8_t in[16], uint8_t out[16]);
+
+// ---- 256-bit helpers: little-endian 8 x u32 limbs ----
+struct U256 {
+    uint32_t l[8];
+};
+extern const U256 FR_MODULUS, FP_MODULUS, FP_HALF;   // r, p, (p-1)/2
+int u256_cmp(const U256 &a, const U256 &b);
+// big-endian bytes (any length) reduced mod m (m < 2^255)
+U256 u256_from_be_mod(const uint8_t *p, size_t n, const U256 &m);
+void u256_to_be(const U256 &v, uint8_t out[32]);
+// uniformly random element of [0, r) from the OS entropy source (fr.Element.SetRandom)
+U256 fr_random();
+// RFC 9380 expand_message_xmd(SHA-256) -> one Fr element (gnark-crypto fr.Hash(msg, dst, 1)), canonical
+U256 hash_to_fr(const uint8_t *msg, size_t len, const char *dst);
+
+}  // namespace zk

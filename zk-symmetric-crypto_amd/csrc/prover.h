@@ -1,0 +1,71 @@
+// Groth16 batch prover for one circuit ("algorithm"): device-resident proving key, solver program,
+// NTT domain and the batch pipeline  solve -> [commit] -> computeH -> 5 (+2) MSMs -> finalize.
+//
+// Replaces groth16.Prove(r1cs, pk, witness) of gnark v0.14 (call sites
+// gnark/libraries/prover/impl/provers.go:179,269) and ProvingKey.ReadFrom (impl/library.go:104-109).
+#pragma once
+#include <memory>
+#include <mutex>
+#include "hostutil.h"
+#include "solver.h"
+
+namespace zk {
+
+struct ProvingKeyDev {
+    uint64_t domain = 0;
+    size_t n_wires = 0;
+    DevBuf<G1Affine> g1_misc;   // alpha, beta, delta
+    DevBuf<G2Affine> g2_misc;   // beta, delta
+    MsmBasesG1 A, B1, K, Z, ped, ped_sigma;
+    MsmBasesG2 B2;
+    size_t n_ped = 0;
+};
+
+// canonical little-endian affine coordinates; (0,0) = infinity
+struct ProofPoints {
+    U256 ar[2], bs[4] /* x.a0 x.a1 y.a0 y.a1 */, krs[2], commitment[2], pok[2];
+};
+
+struct PhaseTimes {   // milliseconds, device time measured with HIP events on the prover's stream
+    float solve = 0, commit = 0, ntt = 0, msm_g1 = 0, msm_g2 = 0, finalize = 0, total = 0;
+};
+
+class Algorithm {
+   public:
+    R1cs cs;
+    SolverProgram prog;
+    ProvingKeyDev pk;
+    NttDomain dom;
+    bool has_commit = false;
+    size_t commit_level = 0;
+
+    // throws ZkError
+    void load(const uint8_t *pk_bytes, size_t pk_len, const uint8_t *r1cs_bytes, size_t r1cs_len);
+
+    // Batch prove.  inputs: [batch][n_inputs] small integers (witness assignment: public without the
+    // constant one, then secret).  r, s, randomize: [batch] canonical Fr (randomize may be null when
+    // the circuit has no Randomize hint).  Results in out[batch]; errs[batch] = solver error words
+    // (0 = ok).  Work is processed in chunks of at most `chunk` instances.
+    void prove_batch(size_t batch, const uint32_t *inputs, const U256 *r, const U256 *s, const U256 *randomize, ProofPoints *out,
+                     uint32_t *errs, PhaseTimes *times = nullptr);
+
+    // device-resident variant for the benchmark: inputs already in HBM as [n_inputs][B] (see bench.py)
+    struct Resident;
+    std::unique_ptr<Resident> res;
+    void resident_reserve(size_t B);
+    void resident_upload(size_t B, const uint32_t *inputs_rowmajor_instance, const U256 *r, const U256 *s, const U256 *randomize);
+    void resident_prove(PhaseTimes *times);                  // timed region of bench.py
+    void resident_download(ProofPoints *out, uint32_t *errs);
+    void debug_fetch(uint8_t *wires_out, uint8_t *h_out);   // parity tests
+
+    size_t n_inputs() const { return prog.n_inputs; }
+    size_t max_chunk = 1024;
+    std::mutex mu;            // one batch at a time per algorithm (device buffers are shared)
+    ~Algorithm();
+    Algorithm();
+};
+
+// gnark groth16 Proof.WriteTo (compressed points): Ar | Bs | Krs | u32 nCommit | commitments | PoK
+std::vector<uint8_t> proof_serialize(const ProofPoints &p, bool has_commit);
+
+}  // namespace zk

@@ -1,0 +1,430 @@
+// Groth16 batch pipeline on one MI355X (see prover.h).
+#include "prover.h"
+#include <string.h>
+#include <algorithm>
+
+namespace zk {
+
+static constexpr int C_WIRE = 13;   // window bits for the wire-scalar MSMs (few wide scalars)
+static constexpr int C_H = 16;      // window bits for the quotient MSM (all scalars full width)
+
+// ------------------------------------------------------------------------------- pk parsing
+namespace {
+struct PkCursor {
+    const uint8_t *p;
+    size_t len, pos = 0;
+    void need(size_t n) const { if (pos + n > len) throw ZkError("proving key: truncated"); }
+    uint32_t u32be() { need(4); uint32_t v = ((uint32_t)p[pos] << 24) | ((uint32_t)p[pos + 1] << 16) | ((uint32_t)p[pos + 2] << 8) | p[pos + 3]; pos += 4; return v; }
+    uint64_t u64be() { uint64_t hi = u32be(); return (hi << 32) | u32be(); }
+};
+struct Slice { size_t off = 0, n = 0; bool raw = false; };
+
+// one point: size from the flag bits of its first byte (gnark-crypto marshal.go)
+static Slice take_points(PkCursor &c, size_t n, size_t comp_size) {
+    Slice s; s.off = c.pos; s.n = n;
+    if (n == 0) return s;
+    c.need(1);
+    s.raw = (c.p[c.pos] & 0xC0) == 0;
+    const size_t sz = s.raw ? 2 * comp_size : comp_size;
+    c.need(n * sz);
+    for (size_t i = 0; i < n; i++) {
+        const bool raw_i = (c.p[c.pos + i * sz] & 0xC0) == 0;
+        if (raw_i != s.raw) throw ZkError("proving key: mixed point encodings in one slice");
+    }
+    c.pos += n * sz;
+    return s;
+}
+static Slice take_slice(PkCursor &c, size_t comp_size) { uint32_t n = c.u32be(); return take_points(c, n, comp_size); }
+
+static void upload_g1(const uint8_t *base, const Slice &s, DevBuf<G1Affine> &out, hipStream_t st) {
+    out.alloc(s.n ? s.n : 1);
+    if (!s.n) return;
+    const size_t bytes = s.n * (s.raw ? 64 : 32);
+    DevBuf<uint8_t> raw(bytes);
+    ZK_HIP(hipMemcpyAsync(raw.p, base + s.off, bytes, hipMemcpyHostToDevice, st));
+    if (s.raw) g1_from_be_bytes(out.p, raw.p, s.n, st);
+    else {
+        DevBuf<uint32_t> bad(1); bad.zero(st);
+        g1_decompress(out.p, raw.p, s.n, bad.p, st);
+        uint32_t nb = 0; bad.download(&nb, 1, st);
+        ZK_HIP(hipStreamSynchronize(st));
+        if (nb) throw ZkError("proving key: invalid compressed G1 point");
+    }
+    ZK_HIP(hipStreamSynchronize(st));
+}
+static void upload_g2(const uint8_t *base, const Slice &s, DevBuf<G2Affine> &out, hipStream_t st) {
+    out.alloc(s.n ? s.n : 1);
+    if (!s.n) return;
+    const size_t bytes = s.n * (s.raw ? 128 : 64);
+    DevBuf<uint8_t> raw(bytes);
+    ZK_HIP(hipMemcpyAsync(raw.p, base + s.off, bytes, hipMemcpyHostToDevice, st));
+    if (s.raw) g2_from_be_bytes(out.p, raw.p, s.n, st);
+    else {
+        DevBuf<uint32_t> bad(1); bad.zero(st);
+        g2_decompress(out.p, raw.p, s.n, bad.p, st);
+        uint32_t nb = 0; bad.download(&nb, 1, st);
+        ZK_HIP(hipStreamSynchronize(st));
+        if (nb) throw ZkError("proving key: invalid compressed G2 point");
+    }
+    ZK_HIP(hipStreamSynchronize(st));
+}
+static std::vector<uint8_t> take_bools(PkCursor &c) {
+    // gnark-crypto encoder []bool: u32 length, bits packed LSB-first  [gnark-mem, unpinned: SURVEY App. C]
+    uint32_t n = c.u32be();
+    size_t nbytes = (n + 7) / 8;
+    c.need(nbytes);
+    std::vector<uint8_t> out(n);
+    for (uint32_t i = 0; i < n; i++) out[i] = (c.p[c.pos + i / 8] >> (i % 8)) & 1;
+    c.pos += nbytes;
+    return out;
+}
+static uint32_t bitrev32(uint32_t v, int bits) {
+    uint32_t r = 0;
+    for (int i = 0; i < bits; i++) if (v & (1u << i)) r |= 1u << (bits - 1 - i);
+    return r;
+}
+}  // namespace
+
+// ---------------------------------------------------------------------------- device state
+struct Algorithm::Resident {
+    size_t B = 0, cap = 0;
+    SolverBuffers sb;
+    MsmScratch ms;
+    DevBuf<G1XYZZ> m_ar, m_bs1, m_k, m_z, m_com, m_pok;
+    DevBuf<G2XYZZ> m_bs2;
+    DevBuf<U256> r, s, rnd, chal;
+    DevBuf<G1Affine> com_aff, pok_aff;
+    DevBuf<ProofPoints> out;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8] = {};
+    std::vector<G1Affine> h_com;
+    std::vector<U256> h_chal;
+};
+
+Algorithm::Algorithm() {}
+Algorithm::~Algorithm() {
+    if (res) {
+        for (auto &e : res->ev) if (e) (void)hipEventDestroy(e);
+        if (res->stream) (void)hipStreamDestroy(res->stream);
+    }
+}
+
+void Algorithm::load(const uint8_t *pkb, size_t pk_len, const uint8_t *r1cs_bytes, size_t r1cs_len) {
+    r1cs_parse(r1cs_bytes, r1cs_len, cs);
+    hipStream_t st = 0;
+    prog.build(cs, st);
+    has_commit = prog.has_commit;
+    commit_level = 0;
+    for (size_t l = 0; l < prog.levels.size(); l++) if (prog.levels[l].has_commit) commit_level = l;
+    const int logn = cs.log_domain();
+    dom.init(logn, st);
+    const size_t N = (size_t)1 << logn, nw = cs.nb_wires();
+
+    PkCursor c{pkb, pk_len};
+    pk.domain = c.u64be();
+    if (pk.domain != N) throw ZkError("proving key: domain size does not match the constraint system");
+    c.need(5 * 32 + 1);
+    c.pos += 5 * 32 + 1;                                  // CardinalityInv, Generator, GeneratorInv, FrMultiplicativeGen(+Inv), withPrecompute
+    Slice misc1 = take_points(c, 3, 32);                  // alpha, beta, delta
+    Slice sA = take_slice(c, 32), sB = take_slice(c, 32), sZ = take_slice(c, 32), sK = take_slice(c, 32);
+    Slice misc2 = take_points(c, 2, 64);                  // beta2, delta2
+    Slice sB2 = take_slice(c, 64);
+    uint64_t nwires = c.u64be(), ninfA = c.u64be(), ninfB = c.u64be();
+    std::vector<uint8_t> infA = take_bools(c), infB = take_bools(c);
+    uint32_t nkeys = c.u32be();
+    Slice sPed, sPedS;
+    if (nkeys > 1) throw ZkError("proving key: more than one commitment key");
+    if (nkeys == 1) { sPed = take_slice(c, 32); sPedS = take_slice(c, 32); }
+    if (c.pos != pk_len) throw ZkError("proving key: trailing bytes");
+    if (nwires != nw || infA.size() != nw || infB.size() != nw) throw ZkError("proving key: wire count does not match the constraint system");
+    if ((nkeys == 1) != has_commit) throw ZkError("proving key: commitment keys do not match the constraint system");
+    pk.n_wires = nw;
+
+    // scalar rows
+    std::vector<uint32_t> rowsA, rowsB, rowsK, rowsZ, rowsPed;
+    std::vector<uint8_t> skip(nw, 0);
+    for (uint32_t w : prog.private_committed) skip[w] = 1;
+    if (has_commit) skip[prog.commit_wire] = 1;
+    for (size_t w = 0; w < nw; w++) {
+        if (!infA[w]) rowsA.push_back((uint32_t)w);
+        if (!infB[w]) rowsB.push_back((uint32_t)w);
+        if (w >= cs.nb_public && !skip[w]) rowsK.push_back((uint32_t)w);
+    }
+    if (rowsA.size() != sA.n || rowsB.size() != sB.n || rowsB.size() != sB2.n || rowsK.size() != sK.n || ninfA != nw - sA.n || ninfB != nw - sB.n)
+        throw ZkError("proving key: point counts do not match the constraint system");
+    if (sZ.n + 1 < N) throw ZkError("proving key: too few Z points");
+    for (size_t k = 0; k + 1 < N; k++) rowsZ.push_back(bitrev32((uint32_t)k, logn));   // H is produced in bit-reversed order
+    sZ.n = N - 1;
+    if (has_commit) {
+        if (sPed.n != prog.private_committed.size() || sPedS.n != sPed.n) throw ZkError("proving key: pedersen basis size mismatch");
+        rowsPed = prog.private_committed;
+    }
+    DevBuf<G1Affine> pts;
+    upload_g1(pkb, misc1, pk.g1_misc, st);
+    upload_g2(pkb, misc2, pk.g2_misc, st);
+    upload_g1(pkb, sA, pts, st); msm_bases_build(pk.A, pts.p, sA.n, rowsA.data(), C_WIRE, st);
+    upload_g1(pkb, sB, pts, st); msm_bases_build(pk.B1, pts.p, sB.n, rowsB.data(), C_WIRE, st);
+    upload_g1(pkb, sK, pts, st); msm_bases_build(pk.K, pts.p, sK.n, rowsK.data(), C_WIRE, st);
+    upload_g1(pkb, sZ, pts, st); msm_bases_build(pk.Z, pts.p, sZ.n, rowsZ.data(), C_H, st);
+    pk.n_ped = 0;
+    if (has_commit) {
+        upload_g1(pkb, sPed, pts, st); msm_bases_build(pk.ped, pts.p, sPed.n, rowsPed.data(), C_WIRE, st);
+        upload_g1(pkb, sPedS, pts, st); msm_bases_build(pk.ped_sigma, pts.p, sPedS.n, rowsPed.data(), C_WIRE, st);
+        pk.n_ped = sPed.n;
+    }
+    DevBuf<G2Affine> pts2;
+    upload_g2(pkb, sB2, pts2, st); msm_bases_build(pk.B2, pts2.p, sB2.n, rowsB.data(), C_WIRE, st);
+    ZK_HIP(hipDeviceSynchronize());
+}
+
+// ------------------------------------------------------------------------------ finalize
+__global__ __launch_bounds__(64) void k_u256_to_mont(const U256 *in, Fr *out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr v;
+#pragma unroll
+    for (int k = 0; k < 8; k++) v.l[k] = in[i].l[k];
+    out[i] = v.to_mont();
+}
+__device__ __forceinline__ void store_fp(U256 &dst, const Fp &v) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) dst.l[k] = v.l[k];
+}
+// Ar = A + alpha + r*delta ; Bs1 = B + beta + s*delta ; Krs = K + Z + (-rs)*delta + s*Ar + r*Bs1
+__global__ __launch_bounds__(64) void k_finalize_g1(const G1XYZZ *__restrict__ m_ar, const G1XYZZ *__restrict__ m_bs1, const G1XYZZ *__restrict__ m_k,
+                                                    const G1XYZZ *__restrict__ m_z, const G1Affine *__restrict__ misc, const U256 *__restrict__ r,
+                                                    const U256 *__restrict__ s, ProofPoints *__restrict__ out, size_t B) {
+    size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const G1Affine alpha = misc[0], beta = misc[1], delta = misc[2];
+    Fr rm, sm;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { rm.l[k] = r[b].l[k]; sm.l[k] = s[b].l[k]; }
+    const Fr kr = (rm.to_mont() * sm.to_mont()).neg().from_mont();
+    G1XYZZ ar = m_ar[b];
+    ar.madd(alpha);
+    ar.add(scalar_mul(delta, rm.l));
+    G1XYZZ bs1 = m_bs1[b];
+    bs1.madd(beta);
+    bs1.add(scalar_mul(delta, sm.l));
+    const G1Affine ar_a = ar.to_affine(), bs1_a = bs1.to_affine();
+    G1XYZZ krs = m_k[b];
+    krs.add(m_z[b]);
+    krs.add(scalar_mul(delta, kr.l));
+    krs.add(scalar_mul(ar_a, sm.l));
+    krs.add(scalar_mul(bs1_a, rm.l));
+    const G1Affine krs_a = krs.to_affine();
+    store_fp(out[b].ar[0], ar_a.x.from_mont()); store_fp(out[b].ar[1], ar_a.y.from_mont());
+    store_fp(out[b].krs[0], krs_a.x.from_mont()); store_fp(out[b].krs[1], krs_a.y.from_mont());
+}
+// Bs = B2 + beta2 + s*delta2
+__global__ __launch_bounds__(64) void k_finalize_g2(const G2XYZZ *__restrict__ m_bs2, const G2Affine *__restrict__ misc, const U256 *__restrict__ s,
+                                                    ProofPoints *__restrict__ out, size_t B) {
+    size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    uint32_t sl[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) sl[k] = s[b].l[k];
+    G2XYZZ bs = m_bs2[b];
+    bs.madd(misc[0]);
+    bs.add(scalar_mul(misc[1], sl));
+    const G2Affine a = bs.to_affine();
+    store_fp(out[b].bs[0], a.x.a0.from_mont()); store_fp(out[b].bs[1], a.x.a1.from_mont());
+    store_fp(out[b].bs[2], a.y.a0.from_mont()); store_fp(out[b].bs[3], a.y.a1.from_mont());
+}
+__global__ void k_store_commit(const G1Affine *com, const G1Affine *pok, ProofPoints *out, size_t B, int has) {
+    size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    if (has) {
+        store_fp(out[b].commitment[0], com[b].x); store_fp(out[b].commitment[1], com[b].y);
+        store_fp(out[b].pok[0], pok[b].x); store_fp(out[b].pok[1], pok[b].y);
+    } else {
+        for (int k = 0; k < 8; k++) { out[b].commitment[0].l[k] = 0; out[b].commitment[1].l[k] = 0; out[b].pok[0].l[k] = 0; out[b].pok[1].l[k] = 0; }
+    }
+}
+
+// ------------------------------------------------------------------------------- pipeline
+void Algorithm::resident_reserve(size_t B) {
+    if (!res) {
+        res.reset(new Resident());
+        ZK_HIP(hipStreamCreate(&res->stream));
+        for (auto &e : res->ev) ZK_HIP(hipEventCreate(&e));
+    }
+    Resident &R = *res;
+    R.B = B;
+    if (B <= R.cap) { R.sb.B = B; R.ms.B = B; return; }
+    R.cap = B;
+    R.sb.reserve(prog, B);
+    size_t max_entries = 0, max_nb = 0, max_part = 0;
+    auto acc = [&](size_t n, int c, int W) {
+        max_entries = std::max(max_entries, n * (size_t)W);
+        max_nb = std::max(max_nb, (size_t)1 << (c - 1));
+        max_part = std::max(max_part, msm_part_stride(n, c));
+    };
+    acc(pk.A.n, pk.A.c, pk.A.W); acc(pk.B1.n, pk.B1.c, pk.B1.W); acc(pk.K.n, pk.K.c, pk.K.W); acc(pk.Z.n, pk.Z.c, pk.Z.W);
+    acc(pk.B2.n, pk.B2.c, pk.B2.W);
+    if (has_commit) acc(pk.ped.n, pk.ped.c, pk.ped.W);
+    R.ms.reserve(B, max_entries, max_nb, max_part);
+    R.m_ar.alloc(B); R.m_bs1.alloc(B); R.m_k.alloc(B); R.m_z.alloc(B); R.m_com.alloc(B); R.m_pok.alloc(B); R.m_bs2.alloc(B);
+    R.r.alloc(B); R.s.alloc(B); R.rnd.alloc(B); R.chal.alloc(B);
+    R.com_aff.alloc(B); R.pok_aff.alloc(B); R.out.alloc(B);
+    R.h_com.resize(B); R.h_chal.resize(B);
+}
+
+void Algorithm::resident_upload(size_t B, const uint32_t *inputs, const U256 *r, const U256 *s, const U256 *randomize) {
+    resident_reserve(B);
+    Resident &R = *res;
+    const size_t ni = prog.n_inputs;
+    std::vector<uint32_t> tr(ni * B);
+    for (size_t b = 0; b < B; b++)
+        for (size_t i = 0; i < ni; i++) tr[i * B + b] = inputs[b * ni + i];
+    ZK_HIP(hipMemcpyAsync(R.sb.inputs.p, tr.data(), tr.size() * 4, hipMemcpyHostToDevice, R.stream));
+    ZK_HIP(hipMemcpyAsync(R.r.p, r, B * sizeof(U256), hipMemcpyHostToDevice, R.stream));
+    ZK_HIP(hipMemcpyAsync(R.s.p, s, B * sizeof(U256), hipMemcpyHostToDevice, R.stream));
+    if (randomize) ZK_HIP(hipMemcpyAsync(R.rnd.p, randomize, B * sizeof(U256), hipMemcpyHostToDevice, R.stream));
+    else ZK_HIP(hipMemsetAsync(R.rnd.p, 0, B * sizeof(U256), R.stream));
+    ZK_HIP(hipStreamSynchronize(R.stream));
+}
+
+void Algorithm::resident_prove(PhaseTimes *times) {
+    Resident &R = *res;
+    const size_t B = R.B;
+    hipStream_t st = R.stream;
+    ZK_HIP(hipEventRecord(R.ev[0], st));
+    hipLaunchKernelGGL(k_u256_to_mont, dim3(ceil_div(B, 64)), dim3(64), 0, st, R.rnd.p, R.sb.randomize.p, B);
+    solver_begin(prog, R.sb, st);
+    if (has_commit) {
+        solver_run_levels(prog, R.sb, 0, commit_level, st);
+        ZK_HIP(hipEventRecord(R.ev[1], st));
+        // BSB22 commitment: C = sum v_i * Basis_i ; challenge = H2F(C.Marshal(), "bsb22-commitment") ; PoK = sum v_i * BasisExpSigma_i
+        msm_batch(pk.ped, R.sb.wires.p, B, R.ms, R.m_com.p, st);
+        msm_batch(pk.ped_sigma, R.sb.wires.p, B, R.ms, R.m_pok.p, st);
+        g1_to_affine_canonical(R.m_com.p, R.com_aff.p, B, st);
+        g1_to_affine_canonical(R.m_pok.p, R.pok_aff.p, B, st);
+        ZK_HIP(hipMemcpyAsync(R.h_com.data(), R.com_aff.p, B * sizeof(G1Affine), hipMemcpyDeviceToHost, st));
+        ZK_HIP(hipStreamSynchronize(st));
+        for (size_t b = 0; b < B; b++) {
+            uint8_t ser[64];
+            U256 x, y;
+            memcpy(x.l, R.h_com[b].x.l, 32); memcpy(y.l, R.h_com[b].y.l, 32);
+            u256_to_be(x, ser); u256_to_be(y, ser + 32);
+            R.h_chal[b] = hash_to_fr(ser, 64, "bsb22-commitment");
+        }
+        ZK_HIP(hipMemcpyAsync(R.chal.p, R.h_chal.data(), B * sizeof(U256), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_u256_to_mont, dim3(ceil_div(B, 64)), dim3(64), 0, st, R.chal.p, R.sb.challenge.p, B);
+        ZK_HIP(hipEventRecord(R.ev[2], st));
+        solver_run_levels(prog, R.sb, commit_level, prog.levels.size(), st);
+    } else {
+        ZK_HIP(hipEventRecord(R.ev[1], st));
+        ZK_HIP(hipEventRecord(R.ev[2], st));
+        solver_run_levels(prog, R.sb, 0, prog.levels.size(), st);
+    }
+    ZK_HIP(hipEventRecord(R.ev[3], st));
+    dom.compute_h(R.sb.a.p, R.sb.b.p, R.sb.c.p, B, st);
+    ZK_HIP(hipEventRecord(R.ev[4], st));
+    msm_batch(pk.A, R.sb.wires.p, B, R.ms, R.m_ar.p, st);
+    msm_batch(pk.B1, R.sb.wires.p, B, R.ms, R.m_bs1.p, st);
+    msm_batch(pk.K, R.sb.wires.p, B, R.ms, R.m_k.p, st);
+    msm_batch(pk.Z, R.sb.a.p, B, R.ms, R.m_z.p, st);
+    ZK_HIP(hipEventRecord(R.ev[5], st));
+    msm_batch(pk.B2, R.sb.wires.p, B, R.ms, R.m_bs2.p, st);
+    ZK_HIP(hipEventRecord(R.ev[6], st));
+    hipLaunchKernelGGL(k_finalize_g1, dim3(ceil_div(B, 64)), dim3(64), 0, st, R.m_ar.p, R.m_bs1.p, R.m_k.p, R.m_z.p, pk.g1_misc.p, R.r.p, R.s.p, R.out.p, B);
+    hipLaunchKernelGGL(k_finalize_g2, dim3(ceil_div(B, 64)), dim3(64), 0, st, R.m_bs2.p, pk.g2_misc.p, R.s.p, R.out.p, B);
+    hipLaunchKernelGGL(k_store_commit, dim3(ceil_div(B, 64)), dim3(64), 0, st, R.com_aff.p, R.pok_aff.p, R.out.p, B, has_commit ? 1 : 0);
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipEventRecord(R.ev[7], st));
+    ZK_HIP(hipStreamSynchronize(st));
+    if (times) {
+        float t01, t12, t23, t34, t45, t56, t67, t07;
+        ZK_HIP(hipEventElapsedTime(&t01, R.ev[0], R.ev[1])); ZK_HIP(hipEventElapsedTime(&t12, R.ev[1], R.ev[2]));
+        ZK_HIP(hipEventElapsedTime(&t23, R.ev[2], R.ev[3])); ZK_HIP(hipEventElapsedTime(&t34, R.ev[3], R.ev[4]));
+        ZK_HIP(hipEventElapsedTime(&t45, R.ev[4], R.ev[5])); ZK_HIP(hipEventElapsedTime(&t56, R.ev[5], R.ev[6]));
+        ZK_HIP(hipEventElapsedTime(&t67, R.ev[6], R.ev[7])); ZK_HIP(hipEventElapsedTime(&t07, R.ev[0], R.ev[7]));
+        times->solve = t01 + t23; times->commit = t12; times->ntt = t34; times->msm_g1 = t45; times->msm_g2 = t56; times->finalize = t67; times->total = t07;
+    }
+}
+
+void Algorithm::resident_download(ProofPoints *out, uint32_t *errs) {
+    Resident &R = *res;
+    ZK_HIP(hipMemcpy(out, R.out.p, R.B * sizeof(ProofPoints), hipMemcpyDeviceToHost));
+    if (errs) ZK_HIP(hipMemcpy(errs, R.sb.err.p, R.B * sizeof(uint32_t), hipMemcpyDeviceToHost));
+}
+
+void Algorithm::prove_batch(size_t batch, const uint32_t *inputs, const U256 *r, const U256 *s, const U256 *randomize, ProofPoints *out,
+                            uint32_t *errs, PhaseTimes *times) {
+    std::lock_guard<std::mutex> lk(mu);
+    PhaseTimes tot;
+    for (size_t off = 0; off < batch; off += max_chunk) {
+        const size_t B = std::min(max_chunk, batch - off);
+        resident_upload(B, inputs + off * prog.n_inputs, r + off, s + off, randomize ? randomize + off : nullptr);
+        PhaseTimes t;
+        resident_prove(&t);
+        resident_download(out + off, errs ? errs + off : nullptr);
+        tot.solve += t.solve; tot.commit += t.commit; tot.ntt += t.ntt; tot.msm_g1 += t.msm_g1; tot.msm_g2 += t.msm_g2; tot.finalize += t.finalize; tot.total += t.total;
+    }
+    if (times) *times = tot;
+}
+
+// parity-test hook: solved wires and quotient coefficients of the last resident batch, canonical form
+void Algorithm::debug_fetch(uint8_t *wires_out, uint8_t *h_out) {
+    Resident &R = *res;
+    const size_t B = R.B, nw = prog.n_wires, N = (size_t)1 << prog.log_domain;
+    const int logn = prog.log_domain;
+    std::vector<Fr> tmp;
+    auto fetch = [&](const Fr *src, size_t rows) {
+        DevBuf<Fr> d(rows * B);
+        ZK_HIP(hipMemcpy(d.p, src, rows * B * sizeof(Fr), hipMemcpyDeviceToDevice));
+        fr_from_mont(d.p, rows * B, 0);
+        tmp.resize(rows * B);
+        ZK_HIP(hipMemcpy(tmp.data(), d.p, rows * B * sizeof(Fr), hipMemcpyDeviceToHost));
+    };
+    if (wires_out) {
+        fetch(R.sb.wires.p, nw);
+        for (size_t b = 0; b < B; b++)
+            for (size_t w = 0; w < nw; w++) memcpy(wires_out + (b * nw + w) * 32, &tmp[w * B + b], 32);
+    }
+    if (h_out) {
+        fetch(R.sb.a.p, N);
+        for (size_t b = 0; b < B; b++)
+            for (size_t k = 0; k < N; k++) memcpy(h_out + (b * N + k) * 32, &tmp[(size_t)bitrev32((uint32_t)k, logn) * B + b], 32);
+    }
+}
+
+// -------------------------------------------------------------------------- serialisation
+static void put_g1(std::vector<uint8_t> &o, const U256 &x, const U256 &y) {
+    uint8_t b[32];
+    static const U256 Z = {{0}};
+    if (u256_cmp(x, Z) == 0 && u256_cmp(y, Z) == 0) {
+        memset(b, 0, 32); b[0] = 0x40;
+    } else {
+        u256_to_be(x, b);
+        b[0] |= u256_cmp(y, FP_HALF) > 0 ? 0xC0 : 0x80;
+    }
+    o.insert(o.end(), b, b + 32);
+}
+std::vector<uint8_t> proof_serialize(const ProofPoints &p, bool has_commit) {
+    std::vector<uint8_t> o;
+    put_g1(o, p.ar[0], p.ar[1]);
+    {   // G2: X.A1 | X.A0, flag from y (A1 first unless zero)
+        uint8_t b[64];
+        static const U256 Z = {{0}};
+        bool inf = true;
+        for (int k = 0; k < 4; k++) if (u256_cmp(p.bs[k], Z)) inf = false;
+        if (inf) { memset(b, 0, 64); b[0] = 0x40; }
+        else {
+            u256_to_be(p.bs[1], b); u256_to_be(p.bs[0], b + 32);
+            const bool largest = u256_cmp(p.bs[3], Z) == 0 ? u256_cmp(p.bs[2], FP_HALF) > 0 : u256_cmp(p.bs[3], FP_HALF) > 0;
+            b[0] |= largest ? 0xC0 : 0x80;
+        }
+        o.insert(o.end(), b, b + 64);
+    }
+    put_g1(o, p.krs[0], p.krs[1]);
+    const uint32_t n = has_commit ? 1 : 0;
+    o.push_back(0); o.push_back(0); o.push_back(0); o.push_back((uint8_t)n);
+    if (has_commit) put_g1(o, p.commitment[0], p.commitment[1]);
+    put_g1(o, p.pok[0], p.pok[1]);
+    return o;
+}
+
+}  // namespace zk

@@ -1,0 +1,54 @@
+// Batched R1CS witness solver for gfx950: one lane = one proof instance, one launch per dependency
+// level of the gnark instruction graph.
+//
+// Replaces gnark v0.14 constraint/bn254 (*system).Solve -> solver.run / solveR1C / solveWithHint and
+// the blueprints (generic R1C, generic hint, logderivlookup) -- SURVEY.md section 8 a6 -- executed inside
+// groth16.Prove (gnark/libraries/prover/impl/provers.go:179,269).
+#pragma once
+#include "kernels.h"
+#include "r1cs_reader.h"
+
+namespace zk {
+
+enum SolverOp : uint32_t { OP_R1C = 1, OP_NBITS = 2, OP_COUNT = 3, OP_RANDOMIZE = 4, OP_BSB22 = 5, OP_LOOKUP = 6 };
+
+// error codes reported per instance (first error wins)
+enum SolverErr : uint32_t { SERR_NONE = 0, SERR_UNSATISFIED = 1, SERR_LOOKUP_RANGE = 2, SERR_COUNT_QUERY = 3 };
+
+struct SolverLevel {
+    uint32_t first = 0, count = 0;   // range in level_instr
+    bool has_commit = false;         // a BSB22 hint sits in this level: commitment must be ready before launch
+};
+
+struct SolverProgram {
+    size_t n_wires = 0, n_inputs = 0, n_constraints = 0, n_public = 0;
+    int log_domain = 0;
+    std::vector<SolverLevel> levels;
+    DevBuf<uint32_t> prog, instr_off, level_instr;
+    DevBuf<Fr> coeffs, coeff_inv, lookup_tables;   // lookup_tables: [table][256]
+    size_t n_count_rows = 0, n_count_slots = 0;     // countHint scratch sizing: [slot][row][B]
+    bool has_commit = false;
+    uint32_t commit_wire = 0;
+    std::vector<uint32_t> private_committed;
+
+    void build(const R1cs &cs, hipStream_t s);
+};
+
+struct SolverBuffers {
+    size_t B = 0;
+    DevBuf<Fr> wires;          // [n_wires][B]
+    DevBuf<Fr> a, b, c;        // [N][B]
+    DevBuf<uint32_t> inputs;   // [n_inputs][B] small integers
+    DevBuf<Fr> randomize;      // [B] Montgomery
+    DevBuf<Fr> challenge;      // [B] Montgomery (commitment challenge)
+    DevBuf<uint32_t> err;      // [B] (code | constraint<<8)
+    DevBuf<uint32_t> count_scratch;
+    void reserve(const SolverProgram &p, size_t B);
+};
+
+// inputs -> wires rows 0..n_inputs ; zero a,b,c ; clear errors
+void solver_begin(const SolverProgram &p, SolverBuffers &buf, hipStream_t s);
+// run levels [first_level, last_level)
+void solver_run_levels(const SolverProgram &p, SolverBuffers &buf, size_t first_level, size_t last_level, hipStream_t s);
+
+}  // namespace zk

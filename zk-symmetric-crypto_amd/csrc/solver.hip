@@ -1,0 +1,389 @@
+// Batched R1CS witness solver kernels (see solver.h).
+//
+// Program encoding (u32 words, one record per gnark instruction, built once per circuit):
+//   OP_R1C      : op, constraint, nL, nR, nO, loc(0 none | 1 L | 2 R | 3 O), solve_wire, solve_coeff, terms (cid,wid)...
+//                 -- the single unknown term is removed from the term lists at build time: which wire
+//                 an instruction defines is a property of the circuit, not of the witness, so all lanes
+//                 (instances) follow the same control flow.
+//   OP_NBITS    : op, nout, out_start, linexp
+//   OP_COUNT    : op, ntab, ncol, nq, out_start, scratch_slot, linexp x (ntab*ncol), linexp x (nq*ncol)
+//   OP_RANDOMIZE: op, out_wire
+//   OP_BSB22    : op, out_wire
+//   OP_LOOKUP   : op, table, nq, first_out_wire, nentries, linexp x nq
+//   linexp      : nterms, (cid, wid) x nterms        wid == 0xFFFFFFFF => constant coeffs[cid]
+// Data layout: wires[w * B + b], a/b/c[constraint * B + b]  (Fr, Montgomery).
+#include "solver.h"
+#include <string.h>
+#include <string>
+
+namespace zk {
+
+// ------------------------------------------------------------------------------------- build
+namespace {
+void push_linexp(std::vector<uint32_t> &out, const uint32_t *&p) {
+    uint32_t n = *p++;
+    out.push_back(n);
+    for (uint32_t k = 0; k < 2 * n; k++) out.push_back(*p++);
+}
+__global__ void k_coeff_inv(const Fr *c, Fr *ci, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ci[i] = c[i].inv();
+}
+}  // namespace
+
+void SolverProgram::build(const R1cs &cs, hipStream_t s) {
+    n_wires = cs.nb_wires();
+    n_inputs = cs.nb_public - 1 + cs.nb_secret;
+    n_constraints = cs.nb_constraints;
+    n_public = cs.nb_public;
+    log_domain = cs.log_domain();
+    const size_t ni = cs.nb_instructions();
+    std::vector<uint8_t> solved(n_wires, 0);
+    for (size_t i = 0; i < cs.nb_public + cs.nb_secret; i++) solved[i] = 1;
+    // lookup tables
+    std::vector<int> table_of_bp(cs.bp_kind.size(), -1);
+    std::vector<Fr> tables;
+    size_t nent_max = 0;
+    int ntables = 0;
+    for (size_t bp = 0; bp < cs.bp_kind.size(); bp++) {
+        if (cs.bp_kind[bp] != BP_LOOKUP) continue;
+        const auto &e = cs.lookup_entries[bp];
+        std::vector<Fr> vals;
+        for (size_t p = 0; p < e.size();) {
+            uint32_t nt = e[p++];
+            if (nt != 1 || p + 2 > e.size() || e[p + 1] != WIRE_CONST || e[p] >= cs.coeffs.size())
+                throw ZkError("lookup blueprint with non-constant entries is not supported");
+            Fr v;
+            memcpy(v.l, cs.coeffs[e[p]].data(), 32);
+            vals.push_back(v);
+            p += 2;
+        }
+        if (nent_max && vals.size() != nent_max) throw ZkError("lookup tables of differing sizes");
+        nent_max = vals.size();
+        table_of_bp[bp] = ntables++;
+        tables.insert(tables.end(), vals.begin(), vals.end());
+    }
+    has_commit = !cs.commitments.empty();
+    if (cs.commitments.size() > 1) throw ZkError("more than one commitment is not supported");
+    if (has_commit) {
+        const auto &ci = cs.commitments[0];
+        if (ci.nb_public_committed || !ci.public_and_commitment_committed.empty()) throw ZkError("public committed wires are not supported");
+        commit_wire = ci.commitment_wire;
+        private_committed = ci.private_committed;
+    }
+    std::vector<uint32_t> prg, off(ni);
+    std::vector<uint8_t> is_commit_instr(ni, 0);
+    n_count_rows = 0;
+    n_count_slots = 0;
+    for (size_t i = 0; i < ni; i++) {
+        off[i] = (uint32_t)prg.size();
+        const uint32_t *cd = cs.calldata.data() + cs.start_calldata[i];
+        const uint32_t size = cd[0];
+        const int kind = cs.bp_kind[cs.blueprint_id[i]];
+        auto chk_wire = [&](uint32_t w) { if (w != WIRE_CONST && w >= n_wires) throw ZkError("wire id out of range"); };
+        if (kind == BP_R1C) {
+            const uint32_t n[3] = {cd[1], cd[2], cd[3]};
+            if (4 + 2 * (uint64_t)(n[0] + n[1] + n[2]) != size) throw ZkError("r1c calldata size mismatch");
+            size_t hdr = prg.size();
+            prg.insert(prg.end(), {OP_R1C, cs.constraint_offset[i], 0u, 0u, 0u, 0u, 0u, 0u});
+            const uint32_t *p = cd + 4;
+            uint32_t loc = 0;
+            for (int which = 0; which < 3; which++) {
+                uint32_t kept = 0;
+                for (uint32_t k = 0; k < n[which]; k++, p += 2) {
+                    chk_wire(p[1]);
+                    if (p[0] >= cs.coeffs.size()) throw ZkError("coefficient id out of range");
+                    if (p[1] != WIRE_CONST && !solved[p[1]]) {
+                        if (loc) throw ZkError("instruction with more than one unknown wire");
+                        loc = which + 1;
+                        prg[hdr + 6] = p[1]; prg[hdr + 7] = p[0];
+                        solved[p[1]] = 1;
+                        continue;
+                    }
+                    prg.push_back(p[0]); prg.push_back(p[1]);
+                    kept++;
+                }
+                prg[hdr + 2 + which] = kept;
+            }
+            prg[hdr + 5] = loc;
+            if (cs.constraint_offset[i] >= n_constraints) throw ZkError("constraint index out of range");
+        } else if (kind == BP_HINT) {
+            const uint32_t hid = cd[1], nin = cd[2];
+            const uint32_t out_start = cd[size - 2], out_end = cd[size - 1];
+            if (out_end < out_start || out_end > n_wires) throw ZkError("hint outputs out of range");
+            const uint32_t *p = cd + 3;
+            if (hid == HINT_NBITS) {
+                if (nin != 1) throw ZkError("nBits hint with != 1 input");
+                prg.insert(prg.end(), {OP_NBITS, out_end - out_start, out_start});
+                push_linexp(prg, p);
+            } else if (hid == HINT_COUNT) {
+                // inputs: [nTable, nCol, table rows..., query rows...]; first two are constants
+                std::vector<uint32_t> tmp;
+                const uint32_t *q = p;
+                auto const_val = [&](const uint32_t *&pp) -> uint64_t {
+                    uint32_t nt = *pp++;
+                    if (nt != 1 || pp[1] != WIRE_CONST) throw ZkError("countHint header is not constant");
+                    // canonical value of the Montgomery coefficient is needed: small constants only
+                    uint32_t cid = pp[0];
+                    pp += 2;
+                    // coefficient ids 0,1,2 are the literals 0,1,2; others: decode via from_mont on host is avoided
+                    // by scanning small integers
+                    if (cid <= 2) return cid;
+                    return 0x100000000ull | cid;   // resolved below
+                };
+                uint64_t ntab_c = const_val(q), ncol_c = const_val(q);
+                // resolve coefficient ids to small integers by brute force compare with i*R mod r computed incrementally on host
+                auto resolve = [&](uint64_t v) -> uint32_t {
+                    if (!(v >> 32)) return (uint32_t)v;
+                    uint32_t cid = (uint32_t)v;
+                    // host Montgomery "one" = coeffs[1]; add repeatedly
+                    const uint32_t *one = cs.coeffs[1].data();
+                    uint32_t acc[8] = {0};
+                    static const uint32_t M[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+                    for (uint32_t k = 1; k <= 65536; k++) {
+                        uint64_t c = 0;
+                        for (int j = 0; j < 8; j++) { uint64_t x = (uint64_t)acc[j] + one[j] + c; acc[j] = (uint32_t)x; c = x >> 32; }
+                        bool ge = true;
+                        for (int j = 7; j >= 0; j--) { if (acc[j] > M[j]) break; if (acc[j] < M[j]) { ge = false; break; } }
+                        if (ge) { uint64_t br = 0; for (int j = 0; j < 8; j++) { uint64_t x = (uint64_t)acc[j] - M[j] - br; acc[j] = (uint32_t)x; br = (x >> 63) & 1; } }
+                        if (memcmp(acc, cs.coeffs[cid].data(), 32) == 0) return k;
+                    }
+                    throw ZkError("countHint header constant too large");
+                };
+                const uint32_t ntab = resolve(ntab_c), ncol = resolve(ncol_c);
+                if (ncol == 0 || nin < 2 + ntab * ncol || (nin - 2 - ntab * ncol) % ncol) throw ZkError("countHint input shape");
+                const uint32_t nq = (nin - 2 - ntab * ncol) / ncol;
+                if (out_end - out_start != ntab) throw ZkError("countHint output count");
+                prg.insert(prg.end(), {OP_COUNT, ntab, ncol, nq, out_start, (uint32_t)n_count_slots});
+                n_count_slots++;
+                for (uint32_t k = 0; k < (ntab + nq) * ncol; k++) push_linexp(prg, q);
+                if (ntab > n_count_rows) n_count_rows = ntab;
+            } else if (hid == HINT_RANDOMIZE) {
+                if (out_end - out_start != 1) throw ZkError("Randomize hint with != 1 output");
+                prg.insert(prg.end(), {OP_RANDOMIZE, out_start});
+            } else if (hid == HINT_BSB22) {
+                if (!has_commit || out_start != commit_wire) throw ZkError("bsb22 hint does not match commitment info");
+                // inputs: [commitment index, committed wires...] must be the PrivateCommitted list, coefficient one
+                if (nin != private_committed.size() + 1) throw ZkError("bsb22 hint input count");
+                const uint32_t *q = p;
+                q += 1 + 2 * q[0];
+                for (size_t k = 0; k < private_committed.size(); k++) {
+                    if (q[0] != 1 || q[1] != 1 || q[2] != private_committed[k]) throw ZkError("bsb22 hint inputs differ from PrivateCommitted");
+                    q += 3;
+                }
+                prg.insert(prg.end(), {OP_BSB22, out_start});
+                is_commit_instr[i] = 1;
+            } else {
+                throw ZkError("unsupported hint id " + std::to_string(hid));
+            }
+            for (uint32_t w = out_start; w < out_end; w++) solved[w] = 1;
+        } else {   // lookup
+            const uint32_t nent = cd[1], nq = cd[2];
+            int tb = table_of_bp[cs.blueprint_id[i]];
+            if (tb < 0 || nent != nent_max) throw ZkError("lookup instruction without table");
+            if ((size_t)cs.wire_offset[i] + nq > n_wires) throw ZkError("lookup outputs out of range");
+            prg.insert(prg.end(), {OP_LOOKUP, (uint32_t)tb, nq, cs.wire_offset[i], nent});
+            const uint32_t *p = cd + 3;
+            for (uint32_t q = 0; q < nq; q++) push_linexp(prg, p);
+            for (uint32_t q = 0; q < nq; q++) solved[cs.wire_offset[i] + q] = 1;
+        }
+    }
+    for (size_t w = 0; w < n_wires; w++)
+        if (!solved[w]) throw ZkError("circuit leaves wire " + std::to_string(w) + " undefined");
+    // levels
+    std::vector<uint32_t> li;
+    levels.clear();
+    for (auto &l : cs.levels) {
+        SolverLevel lv;
+        lv.first = (uint32_t)li.size();
+        lv.count = (uint32_t)l.size();
+        for (uint32_t i : l) { li.push_back(i); if (is_commit_instr[i]) lv.has_commit = true; }
+        levels.push_back(lv);
+    }
+    prog.upload(prg.data(), prg.size(), s);
+    instr_off.upload(off.data(), off.size(), s);
+    level_instr.upload(li.data(), li.size(), s);
+    coeffs.alloc(cs.coeffs.size());
+    ZK_HIP(hipMemcpyAsync(coeffs.p, cs.coeffs.data(), cs.coeffs.size() * 32, hipMemcpyHostToDevice, s));
+    coeff_inv.alloc(cs.coeffs.size());
+    hipLaunchKernelGGL(k_coeff_inv, dim3(ceil_div(cs.coeffs.size(), 64)), dim3(64), 0, s, coeffs.p, coeff_inv.p, cs.coeffs.size());
+    lookup_tables.alloc(tables.size() ? tables.size() : 1);
+    if (!tables.empty()) ZK_HIP(hipMemcpyAsync(lookup_tables.p, tables.data(), tables.size() * sizeof(Fr), hipMemcpyHostToDevice, s));
+    ZK_HIP(hipStreamSynchronize(s));
+}
+
+void SolverBuffers::reserve(const SolverProgram &p, size_t B_) {
+    B = B_;
+    const size_t N = (size_t)1 << p.log_domain;
+    wires.ensure(p.n_wires * B);
+    a.ensure(N * B); b.ensure(N * B); c.ensure(N * B);
+    inputs.ensure(p.n_inputs * B);
+    randomize.ensure(B); challenge.ensure(B); err.ensure(B);
+    count_scratch.ensure((p.n_count_rows ? p.n_count_rows : 1) * (p.n_count_slots ? p.n_count_slots : 1) * B);
+}
+
+// ----------------------------------------------------------------------------------- kernels
+struct SolveCtx {
+    const uint32_t *prog;
+    const Fr *coeffs, *coeff_inv, *tables;
+    Fr *wires, *a, *b, *c;
+    const Fr *randomize, *challenge;
+    uint32_t *err, *count_scratch;
+    size_t B, count_rows;
+};
+
+__device__ __forceinline__ Fr term_val(const SolveCtx &cx, uint32_t cid, uint32_t wid, size_t b) {
+    if (wid == WIRE_CONST) return cx.coeffs[cid];
+    const Fr w = cx.wires[(size_t)wid * cx.B + b];
+    switch (cid) {
+        case 0: return Fr::zero();
+        case 1: return w;
+        case 2: return w.dbl();
+        case 3: return w.neg();
+        case 4: return w.dbl().neg();
+        default: return cx.coeffs[cid] * w;
+    }
+}
+__device__ __forceinline__ Fr eval_terms(const SolveCtx &cx, const uint32_t *&p, uint32_t n, size_t b) {
+    Fr acc = Fr::zero();
+    for (uint32_t k = 0; k < n; k++, p += 2) acc = acc + term_val(cx, p[0], p[1], b);
+    return acc;
+}
+__device__ __forceinline__ Fr eval_linexp(const SolveCtx &cx, const uint32_t *&p, size_t b) {
+    uint32_t n = *p++;
+    return eval_terms(cx, p, n, b);
+}
+__device__ __forceinline__ void report(const SolveCtx &cx, size_t b, uint32_t code, uint32_t detail) {
+    atomicCAS(&cx.err[b], 0u, code | (detail << 8));
+}
+__device__ __forceinline__ bool small_index(const Fr &v_mont, uint32_t bound, uint32_t &idx) {
+    Fr c = v_mont.from_mont();
+    uint32_t hi = 0;
+#pragma unroll
+    for (int i = 1; i < 8; i++) hi |= c.l[i];
+    idx = c.l[0];
+    return hi == 0 && idx < bound;
+}
+
+__global__ __launch_bounds__(256) void k_solve_level(SolveCtx cx, const uint32_t *__restrict__ instr_off, const uint32_t *__restrict__ level_instr,
+                                                     uint32_t count) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t B = cx.B;
+    if (t >= (size_t)count * B) return;
+    const size_t b = t % B;
+    const uint32_t instr = level_instr[t / B];
+    const uint32_t *p = cx.prog + instr_off[instr];
+    const uint32_t op = p[0];
+    if (op == OP_R1C) {
+        const uint32_t cons = p[1], nL = p[2], nR = p[3], nO = p[4], loc = p[5], sw = p[6], sc = p[7];
+        p += 8;
+        Fr vL = eval_terms(cx, p, nL, b);
+        Fr vR = eval_terms(cx, p, nR, b);
+        Fr vO = eval_terms(cx, p, nO, b);
+        if (loc == 0) {
+            if (vL * vR != vO) report(cx, b, SERR_UNSATISFIED, cons);
+        } else {
+            Fr x = Fr::zero();
+            if (loc == 3) {
+                x = vL * vR - vO;
+                vO = vO + x;
+            } else if (loc == 1) {
+                if (!vR.is_zero()) { x = vO * vR.inv() - vL; vL = vL + x; }
+                else if (!vO.is_zero()) report(cx, b, SERR_UNSATISFIED, cons);
+            } else {
+                if (!vL.is_zero()) { x = vO * vL.inv() - vR; vR = vR + x; }
+                else if (!vO.is_zero()) report(cx, b, SERR_UNSATISFIED, cons);
+            }
+            if (sc == 3) x = x.neg();
+            else if (sc != 1) x = x * cx.coeff_inv[sc];
+            cx.wires[(size_t)sw * B + b] = x;
+        }
+        cx.a[(size_t)cons * B + b] = vL;
+        cx.b[(size_t)cons * B + b] = vR;
+        cx.c[(size_t)cons * B + b] = vO;
+    } else if (op == OP_NBITS) {
+        const uint32_t nout = p[1], out0 = p[2];
+        p += 3;
+        Fr v = eval_linexp(cx, p, b).from_mont();
+        const Fr one = Fr::one(), zero = Fr::zero();
+        for (uint32_t k = 0; k < nout; k++) {
+            const bool bit = k < 256 && ((v.l[k >> 5] >> (k & 31)) & 1);
+            cx.wires[(size_t)(out0 + k) * B + b] = bit ? one : zero;
+        }
+    } else if (op == OP_LOOKUP) {
+        const uint32_t tb = p[1], nq = p[2], w0 = p[3], nent = p[4];
+        p += 5;
+        for (uint32_t q = 0; q < nq; q++) {
+            Fr v = eval_linexp(cx, p, b);
+            uint32_t idx;
+            if (!small_index(v, nent, idx)) { report(cx, b, SERR_LOOKUP_RANGE, instr); idx = 0; }
+            cx.wires[(size_t)(w0 + q) * B + b] = cx.tables[(size_t)tb * nent + idx];
+        }
+    } else if (op == OP_COUNT) {
+        const uint32_t ntab = p[1], ncol = p[2], nq = p[3], out0 = p[4], slot = p[5];
+        p += 6;
+        uint32_t *cnt = cx.count_scratch + (size_t)slot * cx.count_rows * B;
+        for (uint32_t r = 0; r < ntab; r++) cnt[(size_t)r * B + b] = 0;
+        const uint32_t *tab0 = p;
+        // skip table rows (constants): remember where each row starts by re-walking on demand
+        const uint32_t *q = p;
+        for (uint32_t k = 0; k < ntab * ncol; k++) q += 1 + 2 * q[0];
+        for (uint32_t j = 0; j < nq; j++) {
+            const uint32_t *qq = q;
+            Fr key = eval_linexp(cx, qq, b);
+            uint32_t row;
+            bool ok = small_index(key, ntab, row);
+            if (ok) {
+                // compare the full query row with table row `row` (first column of row i is i in logderivlookup tables)
+                const uint32_t *tp = tab0;
+                for (uint32_t k = 0; k < row * ncol; k++) tp += 1 + 2 * tp[0];
+                const uint32_t *qc = q;
+                for (uint32_t col = 0; col < ncol; col++) {
+                    Fr tv = eval_linexp(cx, tp, b), qv = eval_linexp(cx, qc, b);
+                    if (tv != qv) ok = false;
+                }
+            }
+            if (ok) cnt[(size_t)row * B + b] += 1;
+            else report(cx, b, SERR_COUNT_QUERY, instr);
+            for (uint32_t col = 0; col < ncol; col++) q += 1 + 2 * q[0];
+        }
+        for (uint32_t r = 0; r < ntab; r++) cx.wires[(size_t)(out0 + r) * B + b] = Fr::from_u32(cnt[(size_t)r * B + b]);
+    } else if (op == OP_RANDOMIZE) {
+        cx.wires[(size_t)p[1] * B + b] = cx.randomize[b];
+    } else if (op == OP_BSB22) {
+        cx.wires[(size_t)p[1] * B + b] = cx.challenge[b];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_assign_inputs(const uint32_t *__restrict__ in, Fr *__restrict__ wires, size_t n_inputs, size_t B) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (n_inputs + 1) * B) return;
+    const size_t row = t / B;
+    if (row == 0) { wires[t] = Fr::one(); return; }
+    const uint32_t v = in[t - B];
+    wires[t] = v == 0 ? Fr::zero() : (v == 1 ? Fr::one() : Fr::from_u32(v));
+}
+
+void solver_begin(const SolverProgram &p, SolverBuffers &buf, hipStream_t s) {
+    const size_t B = buf.B, N = (size_t)1 << p.log_domain;
+    ZK_HIP(hipMemsetAsync(buf.a.p, 0, N * B * sizeof(Fr), s));
+    ZK_HIP(hipMemsetAsync(buf.b.p, 0, N * B * sizeof(Fr), s));
+    ZK_HIP(hipMemsetAsync(buf.c.p, 0, N * B * sizeof(Fr), s));
+    ZK_HIP(hipMemsetAsync(buf.err.p, 0, B * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(k_assign_inputs, dim3(ceil_div((p.n_inputs + 1) * B, 256)), dim3(256), 0, s, buf.inputs.p, buf.wires.p, p.n_inputs, B);
+    ZK_HIP(hipGetLastError());
+}
+
+void solver_run_levels(const SolverProgram &p, SolverBuffers &buf, size_t first_level, size_t last_level, hipStream_t s) {
+    SolveCtx cx{p.prog.p, p.coeffs.p, p.coeff_inv.p, p.lookup_tables.p, buf.wires.p, buf.a.p, buf.b.p, buf.c.p,
+                buf.randomize.p, buf.challenge.p, buf.err.p, buf.count_scratch.p, buf.B, p.n_count_rows};
+    for (size_t l = first_level; l < last_level && l < p.levels.size(); l++) {
+        const SolverLevel &lv = p.levels[l];
+        if (!lv.count) continue;
+        const size_t threads = (size_t)lv.count * buf.B;
+        hipLaunchKernelGGL(k_solve_level, dim3(ceil_div(threads, 256)), dim3(256), 0, s, cx, p.instr_off.p, p.level_instr.p + lv.first, lv.count);
+    }
+    ZK_HIP(hipGetLastError());
+}
+
+}  // namespace zk
