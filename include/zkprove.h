@@ -59,7 +59,8 @@ ProveReturn ZkpProveDeterministic(GoSlice params, const uint8_t *r32, const uint
 /* Device-resident batch benchmark (bench.py).  inputs: [batch][n_inputs] u32 witness assignment
  * (public inputs without the constant one, then secret), r/s/randomize: [batch][32] canonical LE.
  * zkp_bench_step = one pass of the whole proving path over the resident batch; times7 (ms, HIP events):
- * solve, commit, ntt, msm_g1, msm_g2, finalize, total.  proofs: [batch][384] canonical LE affine
+ * solve, commit, ntt, msm_g1, msm_g2, finalize, total, z_segments (times7 has room for 8 floats;
+ * z_segments = the dominant kernel k_msm_segments<Fp> of the quotient MSM alone).  proofs: [batch][384] canonical LE affine
  * coordinates Ar(64) Bs(128: x.a0 x.a1 y.a0 y.a1) Krs(64) commitment(64) pok(64). */
 long zkp_n_inputs(int algorithmID);
 int zkp_bench_upload(int algorithmID, long batch, const uint32_t *inputs, const uint8_t *r, const uint8_t *s, const uint8_t *randomize);

@@ -163,10 +163,10 @@ class ResidentBatch:
             raise RuntimeError("zkp_bench_upload failed")
 
     def step(self):
-        t = _np.zeros(7, _np.float32)
+        t = _np.zeros(8, _np.float32)
         if lib.zkp_bench_step(self.alg, t.ctypes.data) != 0:
             raise RuntimeError("zkp_bench_step failed")
-        return dict(zip(("solve", "commit", "ntt", "msm_g1", "msm_g2", "finalize", "total"), [float(x) for x in t]))
+        return dict(zip(("solve", "commit", "ntt", "msm_g1", "msm_g2", "finalize", "total", "z_segments"), [float(x) for x in t]))
 
     def fetch(self):
         proofs = _np.zeros((self.batch, 384), _np.uint8)

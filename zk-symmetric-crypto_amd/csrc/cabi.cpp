@@ -392,7 +392,7 @@ int zkp_bench_step(int id, float *times7) {
     if (!a || !a->res) throw ZkError("algorithm not initialised / nothing uploaded");
     PhaseTimes t;
     a->resident_prove(&t);
-    if (times7) { times7[0] = t.solve; times7[1] = t.commit; times7[2] = t.ntt; times7[3] = t.msm_g1; times7[4] = t.msm_g2; times7[5] = t.finalize; times7[6] = t.total; }
+    if (times7) { times7[0] = t.solve; times7[1] = t.commit; times7[2] = t.ntt; times7[3] = t.msm_g1; times7[4] = t.msm_g2; times7[5] = t.finalize; times7[6] = t.total; times7[7] = t.z_segments; }
     return 0;
     CABI_CATCH
 }

@@ -52,7 +52,8 @@ struct MsmScratch {
 
 // out[b] (+)= sum_j scalars[row_j][b] * P_j for b in [0,B).  scalars: [rows][B] Fr Montgomery.
 // If accumulate is false out[b] is overwritten.
-void msm_batch(const MsmBasesG1 &mb, const Fr *scalars, size_t B, MsmScratch &sc, G1XYZZ *out, hipStream_t s);
+// seg_events (optional): two events recorded around the bucket kernel (k_msm_segments) for the roofline line
+void msm_batch(const MsmBasesG1 &mb, const Fr *scalars, size_t B, MsmScratch &sc, G1XYZZ *out, hipStream_t s, hipEvent_t *seg_events = nullptr);
 void msm_batch(const MsmBasesG2 &mb, const Fr *scalars, size_t B, MsmScratch &sc, G2XYZZ *out, hipStream_t s);
 
 // number of XYZZ partial slots per instance that msm_batch needs in MsmScratch::part*

@@ -242,7 +242,7 @@ template <>
 struct PartSel<Fp2> { static G2XYZZ *get(MsmScratch &s) { return s.part2.p; } static size_t cap(MsmScratch &s) { return s.part2.n; } };
 
 template <class F>
-static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, MsmScratch &sc, XYZZ<F> *out, hipStream_t s) {
+static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, MsmScratch &sc, XYZZ<F> *out, hipStream_t s, hipEvent_t *seg_events) {
     const size_t n = mb.n;
     const int c = mb.c, W = mb.W;
     const uint32_t nb = 1u << (c - 1);
@@ -271,14 +271,16 @@ static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, M
                        sc.entries.p, max_entries);
     hipLaunchKernelGGL(k_msm_ones<F>, dim3(ceil_div(nchunks * B, 256)), dim3(256), 0, s, mb.table.p, W, scalars, B, mb.scalar_row.p, n, part,
                        stride, (size_t)0);
+    if (seg_events) ZK_HIP(hipEventRecord(seg_events[0], s));
     hipLaunchKernelGGL(k_msm_segments<F>, dim3(ceil_div(nseg * B, 64)), dim3(64), 0, s, mb.table.p, sc.bucket_start.p, sc.entries.p, max_entries,
                        c, B, part, stride, nchunks);
+    if (seg_events) ZK_HIP(hipEventRecord(seg_events[1], s));
     hipLaunchKernelGGL(k_sum_groups<F>, dim3(ceil_div(nlvl1 * B, 64)), dim3(64), 0, s, part, stride, npart, GROUP, part + npart, stride, B);
     hipLaunchKernelGGL(k_sum_groups<F>, dim3(ceil_div(B, 64)), dim3(64), 0, s, part + npart, stride, nlvl1, nlvl1, out, (size_t)1, B);
     ZK_HIP(hipGetLastError());
 }
-void msm_batch(const MsmBasesG1 &mb, const Fr *sc, size_t B, MsmScratch &scr, G1XYZZ *out, hipStream_t s) { msm_batch_impl<Fp>(mb, sc, B, scr, out, s); }
-void msm_batch(const MsmBasesG2 &mb, const Fr *sc, size_t B, MsmScratch &scr, G2XYZZ *out, hipStream_t s) { msm_batch_impl<Fp2>(mb, sc, B, scr, out, s); }
+void msm_batch(const MsmBasesG1 &mb, const Fr *sc, size_t B, MsmScratch &scr, G1XYZZ *out, hipStream_t s, hipEvent_t *ev) { msm_batch_impl<Fp>(mb, sc, B, scr, out, s, ev); }
+void msm_batch(const MsmBasesG2 &mb, const Fr *sc, size_t B, MsmScratch &scr, G2XYZZ *out, hipStream_t s) { msm_batch_impl<Fp2>(mb, sc, B, scr, out, s, nullptr); }
 
 size_t msm_part_stride(size_t n, int c) {
     const uint32_t nb = 1u << (c - 1);

@@ -96,7 +96,7 @@ struct Algorithm::Resident {
     DevBuf<G1Affine> com_aff, pok_aff;
     DevBuf<ProofPoints> out;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[8] = {};
+    hipEvent_t ev[10] = {};
     std::vector<G1Affine> h_com;
     std::vector<U256> h_chal;
 };
@@ -325,7 +325,7 @@ void Algorithm::resident_prove(PhaseTimes *times) {
     msm_batch(pk.A, R.sb.wires.p, B, R.ms, R.m_ar.p, st);
     msm_batch(pk.B1, R.sb.wires.p, B, R.ms, R.m_bs1.p, st);
     msm_batch(pk.K, R.sb.wires.p, B, R.ms, R.m_k.p, st);
-    msm_batch(pk.Z, R.sb.a.p, B, R.ms, R.m_z.p, st);
+    msm_batch(pk.Z, R.sb.a.p, B, R.ms, R.m_z.p, st, &R.ev[8]);
     ZK_HIP(hipEventRecord(R.ev[5], st));
     msm_batch(pk.B2, R.sb.wires.p, B, R.ms, R.m_bs2.p, st);
     ZK_HIP(hipEventRecord(R.ev[6], st));
@@ -341,6 +341,7 @@ void Algorithm::resident_prove(PhaseTimes *times) {
         ZK_HIP(hipEventElapsedTime(&t23, R.ev[2], R.ev[3])); ZK_HIP(hipEventElapsedTime(&t34, R.ev[3], R.ev[4]));
         ZK_HIP(hipEventElapsedTime(&t45, R.ev[4], R.ev[5])); ZK_HIP(hipEventElapsedTime(&t56, R.ev[5], R.ev[6]));
         ZK_HIP(hipEventElapsedTime(&t67, R.ev[6], R.ev[7])); ZK_HIP(hipEventElapsedTime(&t07, R.ev[0], R.ev[7]));
+        ZK_HIP(hipEventElapsedTime(&times->z_segments, R.ev[8], R.ev[9]));
         times->solve = t01 + t23; times->commit = t12; times->ntt = t34; times->msm_g1 = t45; times->msm_g2 = t56; times->finalize = t67; times->total = t07;
     }
 }
@@ -361,7 +362,7 @@ void Algorithm::prove_batch(size_t batch, const uint32_t *inputs, const U256 *r,
         PhaseTimes t;
         resident_prove(&t);
         resident_download(out + off, errs ? errs + off : nullptr);
-        tot.solve += t.solve; tot.commit += t.commit; tot.ntt += t.ntt; tot.msm_g1 += t.msm_g1; tot.msm_g2 += t.msm_g2; tot.finalize += t.finalize; tot.total += t.total;
+        tot.solve += t.solve; tot.commit += t.commit; tot.ntt += t.ntt; tot.msm_g1 += t.msm_g1; tot.msm_g2 += t.msm_g2; tot.finalize += t.finalize; tot.total += t.total; tot.z_segments += t.z_segments;
     }
     if (times) *times = tot;
 }
