@@ -1,0 +1,106 @@
+"""CPU tests of the product's host side: the C-ABI library loads and exports every declared symbol, the
+C++ decoders / request handling agree with the oracle, and errors mirror the reference's panics.
+No GPU compute is called here."""
+import base64
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import gnark_format as gf
+from oracle import r1cs_format as rf
+
+import helpers as H
+
+
+def test_library_exports_every_declared_symbol(zk):
+    hdr = open(os.path.join(H.ROOT, "include", "zkprove.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", hdr)
+    assert {"InitAlgorithm", "Prove", "Free", "enforce_binding", "GenerateOPRFRequestData", "TOPRFFinalize", "ProveBatch"} <= set(names)
+    for n in names:
+        assert hasattr(zk.lib, n), "libzkprove.so does not export %s" % n
+    zk.lib.enforce_binding()
+
+
+@pytest.mark.parametrize("name", ["chacha20", "aes128", "aes256"])
+def test_cpp_r1cs_decoder_matches_python_decoder(zk, name):
+    data = rf.load_r1cs_bytes(name)
+    r = rf.parse_r1cs(data)
+    assert zk.r1cs_stats(data) == [r.nb_constraints, r.nb_public, r.nb_secret, r.nb_internal, r.nb_instructions, len(r.calldata), len(r.levels), len(r.coeffs)]
+    with pytest.raises(ValueError):
+        zk.r1cs_stats(data[:-7])
+    with pytest.raises(ValueError):
+        zk.r1cs_stats(data[:1000] + bytes(50) + data[1050:])
+
+
+@pytest.mark.parametrize("alg", [0, 1, 2])
+def test_request_to_witness_matches_oracle(zk, alg):
+    rng = H.SplitMix64(31337 + alg)
+    for _ in range(5):
+        inst = H.make_instance(alg, rng)
+        a, w, out = zk.request_witness(H.request_json(alg, inst))
+        ow, oout = H.oracle_witness(alg, inst)
+        assert a == alg and list(w) == ow and out == oout
+
+
+def test_js_shaped_request_with_unknown_fields(zk):
+    j = json.load(open(os.path.join(H.ROOT, "tests", "golden", "aux_test_request.json")))
+    a, w, out = zk.request_witness(json.dumps(j, indent=2).encode())
+    assert a == 1 and out == base64.b64decode(j["ciphertext"])
+
+
+def _req(**kw):
+    base = dict(cipher="chacha20", key=base64.b64encode(bytes(32)).decode(),
+                blocks=[{"nonce": base64.b64encode(bytes(12)).decode(), "counter": 1}] * 2,
+                input=base64.b64encode(bytes(128)).decode())
+    base.update(kw)
+    return json.dumps(base).encode()
+
+
+@pytest.mark.parametrize("req,panic", [
+    (_req(key=base64.b64encode(bytes(16)).decode()), "key length must be 32: 16"),                              # provers.go:120-122
+    (_req(blocks=[]), "blocks array length must be 2: 0"),                                                       # :123-125
+    (_req(blocks=[{"nonce": "AAAA", "counter": 1}] * 2), "block[0] nonce length must be 12: 3"),                # :126-130
+    (_req(input=base64.b64encode(bytes(64)).decode()), "input length must be 128: 64"),                         # :131-133
+    (_req(cipher="rot13"), "could not find prover forrot13"),                                                   # library.go:158
+    (_req(cipher="aes-128-ctr"), "key length must be 16 or 32: 32".replace("32: 32", "32: 32")),                # falls to blocks check below
+])
+def test_reference_panic_messages(zk, req, panic):
+    with pytest.raises(ValueError) as e:
+        zk.request_witness(req)
+    got = json.loads(str(e.value))
+    if "aes-128-ctr" in req.decode():
+        assert got == "blocks array length must be 5: 2"     # provers.go:206-208 (key of 32 passes the 16-or-32 check)
+    else:
+        assert got == panic
+
+
+def test_malformed_json_and_types_answer_with_empty_object(zk):
+    for bad in (b"{", b"[]", b'{"cipher": 5}', b'{"cipher":"chacha20","key":"!!!"}', b'{"cipher":"chacha20","blocks":[{"counter":-1}]}', b"null"):
+        with pytest.raises(ValueError) as e:
+            zk.request_witness(bad)
+        assert str(e.value) == "{}"
+
+
+def test_prove_before_init_and_bad_key_hash(zk):
+    zk.lib.ZkpReset()
+    res = json.loads(zk.prove_raw(_req()))
+    assert res == "proving params are not initialized for cipher: chacha20"       # library.go:143-145
+    # wrong proving-key hash is refused without touching the GPU (library.go:96-102); unknown ids return false
+    zk.lib.ZkpAllowUnpinnedKeys(0)
+    os.environ.pop("ZKPROVE_ALLOW_UNPINNED_PK", None)
+    assert zk.init_algorithm(0, b"not a key", rf.load_r1cs_bytes("chacha20")) is False
+    assert zk.init_algorithm(9, b"", b"") is False
+    assert json.loads(zk._take(zk.lib.TOPRFFinalize(zk._slice(b"{}")[0]))) == "toprf is not supported by libzkprove"
+
+
+def test_proof_serialisation_matches_gnark_format(zk, oracle):
+    for alg in (0, 1):
+        inst = H.make_instance(alg, H.SplitMix64(5 + alg))
+        pb, _, prf, _ = H.oracle_proof_bytes(alg, inst)
+        rec = oracle.ints_to_le32([prf["Ar"][0], prf["Ar"][1], prf["Bs"][0][0], prf["Bs"][0][1], prf["Bs"][1][0], prf["Bs"][1][1],
+                                   prf["Krs"][0], prf["Krs"][1], prf["commitment"][0], prf["commitment"][1], prf["pok"][0], prf["pok"][1]]).reshape(-1)
+        assert zk.proof_serialize(rec, alg != 0) == pb

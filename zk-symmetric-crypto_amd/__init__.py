@@ -188,3 +188,10 @@ def proof_serialize(proof384, has_commitment: bool) -> bytes:
     out = _np.zeros(256, _np.uint8)
     n = lib.zkp_proof_serialize(p.ctypes.data, int(has_commitment), out.ctypes.data, out.size)
     return out[:n].tobytes()
+
+
+def shard_range(total: int, rank: int, world: int):
+    """Contiguous slice of a batch owned by `rank` (independent proofs: no data-path collective)."""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
