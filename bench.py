@@ -21,7 +21,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 # algorithmic HBM bytes per proof, SURVEY.md section 8d / BASELINE.md section 2
 BYTES_PER_PROOF = {0: 56378656, 1: 113334016, 2: 128283328}
-# dominant kernel = quotient MSM bucket kernel (k_msm_segments<Fp> on G1.Z): one 32 B scalar + one 64 B base per term
+# dominant kernel = quotient MSM bucket kernel (k_msm_accumulate<Fp> on G1.Z): one 32 B scalar + one 64 B base per term
 Z_TERMS = {0: 65535, 1: 131071, 2: 131071}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 
@@ -111,7 +111,7 @@ def main():
                        "algorithm_id": alg, "batch_per_gpu": B, "parallelism": "dp%d (independent proofs, no collective)" % world,
                        "blocks_per_s": value * (2 if alg == 0 else 5)},
             "phases_ms": mean, "verified_ok": ok, "init_s": t_init,
-            "roofline": {"bound": "hbm", "kernel": "k_msm_segments<Fp> (quotient MSM over G1.Z)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate<Fp> (bucket accumulation of the quotient MSM over G1.Z)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "launch_ms": zdur_ms, "algorithmic_bytes_per_launch": zbytes,
                          "whole_path_GBps": value / world * BYTES_PER_PROOF[alg] / 1e9,

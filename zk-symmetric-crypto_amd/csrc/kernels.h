@@ -46,8 +46,11 @@ struct MsmScratch {
     DevBuf<uint32_t> bucket_start;   // [B][nb + 1]
     DevBuf<G1XYZZ> part1;            // partial sums G1
     DevBuf<G2XYZZ> part2;            // partial sums G2
+    DevBuf<G1XYZZ> sums1;            // [B][nb] bucket sums G1
+    DevBuf<G2XYZZ> sums2;            // [B][nb] bucket sums G2
     size_t B = 0;
     void reserve(size_t B, size_t max_entries_per_inst, size_t max_nb, size_t max_part);
+    void reserve_sums(size_t B, size_t nb_g1, size_t nb_g2);
 };
 
 // out[b] (+)= sum_j scalars[row_j][b] * P_j for b in [0,B).  scalars: [rows][B] Fr Montgomery.

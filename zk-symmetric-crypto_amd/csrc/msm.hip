@@ -15,8 +15,9 @@
 //     base point).
 //   * k_msm_sort: one workgroup per instance builds the bucket histogram in LDS (up to 128 KiB of
 //     the 160 KiB), scans it and scatters (table index | sign) entries into bucket order.
-//   * k_msm_segments: one thread per run of L consecutive buckets walks its (contiguous) entries
-//     from the top bucket down, fusing accumulation with the running-sum reduction.
+//   * k_msm_accumulate: the sorted entry list of an instance is cut into equal pieces (boundaries
+//     rounded to bucket boundaries); one thread per piece, perfectly balanced lanes, bucket sums to HBM.
+//   * k_msm_bucket_reduce: one thread per 64 buckets, running-sum reduction (sum_k (k+1) B_k).
 //   * k_sum_groups folds the per-chunk / per-segment partial sums.
 // Results are group elements; any correct schedule yields the same affine point, which is what the
 // parity tests compare bit-for-bit with the oracle.
@@ -69,6 +70,10 @@ static void bases_build(MsmBases<F> &mb, const Affine<F> *d_points, size_t n, co
 void msm_bases_build(MsmBasesG1 &mb, const G1Affine *p, size_t n, const uint32_t *rows, int c, hipStream_t s) { bases_build<Fp>(mb, p, n, rows, c, s); }
 void msm_bases_build(MsmBasesG2 &mb, const G2Affine *p, size_t n, const uint32_t *rows, int c, hipStream_t s) { bases_build<Fp2>(mb, p, n, rows, c, s); }
 
+void MsmScratch::reserve_sums(size_t B_, size_t nb_g1, size_t nb_g2) {
+    sums1.ensure(B_ * nb_g1 + 1);
+    sums2.ensure(B_ * nb_g2 + 1);
+}
 void MsmScratch::reserve(size_t B_, size_t max_entries, size_t max_nb, size_t max_part) {
     B = B_;
     entries.ensure(B * max_entries + 1);
@@ -160,11 +165,69 @@ __global__ __launch_bounds__(SORT_THREADS) void k_msm_sort(const Fr *__restrict_
     }
 }
 
-// thread (b, seg): buckets [seg*L, seg*L + L) of instance b; lanes = consecutive segments
+// Bucket accumulation, balanced: instance b's sorted entry list is cut into `nlanes` pieces of (almost)
+// equal length whose boundaries are rounded up to the next bucket boundary; one thread walks one piece
+// linearly.  A bucket change only costs a predicated 128-byte store, so all lanes of a wavefront run the
+// same number of mixed additions (+-1 bucket) -- the earlier "one thread per 64 buckets" form lost ~30 %
+// to the spread of Poisson(32) bucket sizes across the 64 lanes.
+// sums[b * nb + k] receives the sum of bucket k when it is non-empty (empty buckets are never written;
+// the reduce kernel reads emptiness from bucket_start).
 template <class F>
-__global__ __launch_bounds__(64) void k_msm_segments(const Affine<F> *__restrict__ table, const uint32_t *__restrict__ bucket_start,
-                                                     const uint32_t *__restrict__ entries, size_t max_entries, int c, size_t B,
-                                                     XYZZ<F> *__restrict__ part, size_t part_stride, size_t part_off) {
+__global__ __launch_bounds__(64) void k_msm_accumulate(const Affine<F> *__restrict__ table, const uint32_t *__restrict__ bucket_start,
+                                                       const uint32_t *__restrict__ entries, size_t max_entries, int c, size_t B,
+                                                       uint32_t nlanes, XYZZ<F> *__restrict__ sums) {
+    const uint32_t nb = 1u << (c - 1);
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)nlanes * B) return;
+    const size_t b = t / nlanes;
+    const uint32_t lane = (uint32_t)(t % nlanes);
+    const uint32_t *bs = bucket_start + b * (nb + 1);
+    const uint32_t *ent = entries + b * max_entries;
+    XYZZ<F> *out = sums + b * nb;
+    const uint32_t total = bs[nb];
+    // first bucket k with bs[k] >= target
+    auto first_bucket = [&](uint32_t target) -> uint32_t {
+        uint32_t lo = 0, hi = nb;          // answer in [0, nb]
+        while (lo < hi) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (bs[mid] >= target) hi = mid; else lo = mid + 1;
+        }
+        return lo;
+    };
+    const uint32_t k0 = first_bucket((uint32_t)(((uint64_t)total * lane + nlanes - 1) / nlanes));
+    const uint32_t k1 = lane + 1 == nlanes ? nb : first_bucket((uint32_t)(((uint64_t)total * (lane + 1) + nlanes - 1) / nlanes));
+    if (k0 >= k1) return;
+    uint32_t e = bs[k0];
+    const uint32_t e_end = bs[k1];
+    if (e >= e_end) return;
+    uint32_t cur = k0, cur_start = e, next_b = bs[k0 + 1];
+    XYZZ<F> acc = XYZZ<F>::inf();
+    uint32_t v = ent[e];
+    Affine<F> p = table[v & 0x7fffffffu];
+    while (true) {
+        while (e >= next_b) {              // leave bucket `cur` (also skips empty buckets)
+            if (next_b > cur_start) { out[cur] = acc; acc = XYZZ<F>::inf(); }   // every non-empty bucket is written, even if its sum is infinity
+            cur++;
+            cur_start = next_b;
+            next_b = bs[cur + 1];
+        }
+        // prefetch the next entry's base point before the long dependent chain of the mixed addition
+        const uint32_t e_next = e + 1;
+        uint32_t v_next = 0;
+        Affine<F> p_next = p;
+        if (e_next < e_end) { v_next = ent[e_next]; p_next = table[v_next & 0x7fffffffu]; }
+        if (v >> 31) p.y = p.y.neg();
+        acc.madd(p);
+        if (e_next >= e_end) break;
+        e = e_next; v = v_next; p = p_next;
+    }
+    out[cur] = acc;
+}
+
+// thread (b, seg): running-sum reduction of buckets [seg*L, seg*L + L) of instance b
+template <class F>
+__global__ __launch_bounds__(64) void k_msm_bucket_reduce(const XYZZ<F> *__restrict__ sums, const uint32_t *__restrict__ bucket_start, int c, size_t B,
+                                                          XYZZ<F> *__restrict__ part, size_t part_stride, size_t part_off) {
     const uint32_t nb = 1u << (c - 1);
     const uint32_t L = nb < (1u << SEG_LOG) ? nb : (1u << SEG_LOG);
     const uint32_t nseg = nb / L;
@@ -173,21 +236,14 @@ __global__ __launch_bounds__(64) void k_msm_segments(const Affine<F> *__restrict
     const size_t b = t / nseg;
     const uint32_t seg = (uint32_t)(t % nseg);
     const uint32_t *bs = bucket_start + b * (nb + 1);
-    const uint32_t *ent = entries + b * max_entries;
+    const XYZZ<F> *in = sums + b * nb;
     XYZZ<F> run = XYZZ<F>::inf(), tot = XYZZ<F>::inf();
     const uint32_t s0 = seg * L;
     uint32_t hi = bs[s0 + L];
     for (int k = (int)L - 1; k >= 0; k--) {
         const uint32_t lo = bs[s0 + k];
-        XYZZ<F> acc = XYZZ<F>::inf();
-        for (uint32_t e = lo; e < hi; e++) {
-            const uint32_t v = ent[e];
-            Affine<F> p = table[v & 0x7fffffffu];
-            if (v >> 31) p.y = p.y.neg();
-            acc.madd(p);
-        }
+        if (hi > lo) run.add(in[s0 + k]);
         hi = lo;
-        run.add(acc);
         tot.add(run);
     }
     // contribution = tot + s0 * run   (bucket index i carries weight i+1)
@@ -249,6 +305,13 @@ template <>
 struct PartSel<Fp2> { static G2XYZZ *get(MsmScratch &s) { return s.part2.p; } static size_t cap(MsmScratch &s) { return s.part2.n; } };
 
 template <class F>
+struct SumsSel;
+template <>
+struct SumsSel<Fp> { static G1XYZZ *get(MsmScratch &s) { return s.sums1.p; } static size_t cap(MsmScratch &s) { return s.sums1.n; } };
+template <>
+struct SumsSel<Fp2> { static G2XYZZ *get(MsmScratch &s) { return s.sums2.p; } static size_t cap(MsmScratch &s) { return s.sums2.n; } };
+
+template <class F>
 static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, MsmScratch &sc, XYZZ<F> *out, hipStream_t s, hipEvent_t *seg_events) {
     const size_t n = mb.n;
     const int c = mb.c, W = mb.W;
@@ -278,10 +341,16 @@ static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, M
                        sc.entries.p, max_entries);
     hipLaunchKernelGGL(k_msm_ones<F>, dim3(ceil_div(nchunks * B, 256)), dim3(256), 0, s, mb.table.p, W, scalars, B, mb.scalar_row.p, n, part,
                        stride, (size_t)0);
+    // lanes per instance for the accumulate kernel: ~2048 entries per lane at the worst case (all scalars wide)
+    uint32_t nlanes = (uint32_t)((max_entries + 2047) / 2048);
+    if (nlanes < 1) nlanes = 1;
+    XYZZ<F> *sums = SumsSel<F>::get(sc);
+    if (SumsSel<F>::cap(sc) < B * (size_t)nb) throw ZkError("msm bucket-sum scratch too small");
     if (seg_events) ZK_HIP(hipEventRecord(seg_events[0], s));
-    hipLaunchKernelGGL(k_msm_segments<F>, dim3(ceil_div(nseg * B, 64)), dim3(64), 0, s, mb.table.p, sc.bucket_start.p, sc.entries.p, max_entries,
-                       c, B, part, stride, nchunks);
+    hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(ceil_div((size_t)nlanes * B, 64)), dim3(64), 0, s, mb.table.p, sc.bucket_start.p, sc.entries.p,
+                       max_entries, c, B, nlanes, sums);
     if (seg_events) ZK_HIP(hipEventRecord(seg_events[1], s));
+    hipLaunchKernelGGL(k_msm_bucket_reduce<F>, dim3(ceil_div(nseg * B, 64)), dim3(64), 0, s, sums, sc.bucket_start.p, c, B, part, stride, nchunks);
     hipLaunchKernelGGL(k_sum_groups<F>, dim3(ceil_div(nlvl1 * B, 64)), dim3(64), 0, s, part, stride, npart, GROUP, part + npart, stride, B);
     hipLaunchKernelGGL(k_sum_groups<F>, dim3(ceil_div(B, 64)), dim3(64), 0, s, part + npart, stride, nlvl1, nlvl1, out, (size_t)1, B);
     ZK_HIP(hipGetLastError());

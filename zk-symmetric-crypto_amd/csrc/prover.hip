@@ -265,6 +265,10 @@ void Algorithm::resident_reserve(size_t B) {
     acc(pk.B2.n, pk.B2.c, pk.B2.W);
     if (has_commit) acc(pk.ped.n, pk.ped.c, pk.ped.W);
     R.ms.reserve(B, max_entries, max_nb, max_part);
+    {
+        size_t nb1 = (size_t)1 << (std::max({pk.A.c, pk.B1.c, pk.K.c, pk.Z.c, has_commit ? pk.ped.c : 1}) - 1);
+        R.ms.reserve_sums(B, nb1, (size_t)1 << (pk.B2.c - 1));
+    }
     R.m_ar.alloc(B); R.m_bs1.alloc(B); R.m_k.alloc(B); R.m_z.alloc(B); R.m_com.alloc(B); R.m_pok.alloc(B); R.m_bs2.alloc(B);
     R.r.alloc(B); R.s.alloc(B); R.rnd.alloc(B); R.chal.alloc(B);
     R.com_aff.alloc(B); R.pok_aff.alloc(B); R.out.alloc(B);
