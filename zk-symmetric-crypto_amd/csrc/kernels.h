@@ -32,11 +32,14 @@ struct MsmBases {
     int W = 0;             // windows
     DevBuf<Affine<F>> table;
     DevBuf<uint32_t> scalar_row;   // row index of the scalar of point j in the [row][B] scalar matrix
+    bool dense = false;            // quotient MSM: all scalars wide, read from an instance-major copy [B][dense_stride]
+    size_t dense_stride = 0;
 };
 using MsmBasesG1 = MsmBases<Fp>;
 using MsmBasesG2 = MsmBases<Fp2>;
 
-// points: n affine points in Montgomery form on the device (infinity = (0,0) allowed)
+// points: n affine points in Montgomery form on the device (infinity = (0,0) allowed).
+// h_scalar_rows == nullptr selects the dense mode (set mb.dense_stride afterwards).
 void msm_bases_build(MsmBasesG1 &mb, const G1Affine *d_points, size_t n, const uint32_t *h_scalar_rows, int c, hipStream_t s);
 void msm_bases_build(MsmBasesG2 &mb, const G2Affine *d_points, size_t n, const uint32_t *h_scalar_rows, int c, hipStream_t s);
 
@@ -51,6 +54,9 @@ struct MsmScratch {
     size_t B = 0;
     void reserve(size_t B, size_t max_entries_per_inst, size_t max_nb, size_t max_part);
     void reserve_sums(size_t B, size_t nb_g1, size_t nb_g2);
+    DevBuf<uint32_t> gen_count, gen_idx;   // compact per-instance lists of the scalars that are neither 0 nor +-1
+    DevBuf<Fr> gen_val;
+    void reserve_compact(size_t B, size_t max_sparse_n);
 };
 
 // out[b] (+)= sum_j scalars[row_j][b] * P_j for b in [0,B).  scalars: [rows][B] Fr Montgomery.
@@ -58,6 +64,9 @@ struct MsmScratch {
 // seg_events (optional): two events recorded around the bucket kernel (k_msm_segments) for the roofline line
 void msm_batch(const MsmBasesG1 &mb, const Fr *scalars, size_t B, MsmScratch &sc, G1XYZZ *out, hipStream_t s, hipEvent_t *seg_events = nullptr);
 void msm_batch(const MsmBasesG2 &mb, const Fr *scalars, size_t B, MsmScratch &sc, G2XYZZ *out, hipStream_t s);
+
+// instance-major copy: out[b * stride + i] = in[i * B + b]
+void fr_transpose(const Fr *in, Fr *out, size_t rows, size_t B, size_t stride, hipStream_t s);
 
 // number of XYZZ partial slots per instance that msm_batch needs in MsmScratch::part*
 size_t msm_part_stride(size_t n, int c);

@@ -51,8 +51,9 @@ __global__ __launch_bounds__(256) void k_xyzz_to_affine(const XYZZ<F> *__restric
 template <class F>
 static void bases_build(MsmBases<F> &mb, const Affine<F> *d_points, size_t n, const uint32_t *h_rows, int c, hipStream_t s) {
     mb.n = n; mb.c = c; mb.W = (254 + c - 1) / c;
+    mb.dense = (h_rows == nullptr);
     mb.scalar_row.alloc(n ? n : 1);
-    if (n) ZK_HIP(hipMemcpyAsync(mb.scalar_row.p, h_rows, n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    if (n && h_rows) ZK_HIP(hipMemcpyAsync(mb.scalar_row.p, h_rows, n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
     size_t tot = n * mb.W;
     mb.table.alloc(tot ? tot : 1);
     if (!n) return;
@@ -70,6 +71,11 @@ static void bases_build(MsmBases<F> &mb, const Affine<F> *d_points, size_t n, co
 void msm_bases_build(MsmBasesG1 &mb, const G1Affine *p, size_t n, const uint32_t *rows, int c, hipStream_t s) { bases_build<Fp>(mb, p, n, rows, c, s); }
 void msm_bases_build(MsmBasesG2 &mb, const G2Affine *p, size_t n, const uint32_t *rows, int c, hipStream_t s) { bases_build<Fp2>(mb, p, n, rows, c, s); }
 
+void MsmScratch::reserve_compact(size_t B_, size_t max_sparse_n) {
+    gen_count.ensure(B_ + 1);
+    gen_idx.ensure(B_ * max_sparse_n + 1);
+    gen_val.ensure(B_ * max_sparse_n + 1);
+}
 void MsmScratch::reserve_sums(size_t B_, size_t nb_g1, size_t nb_g2) {
     sums1.ensure(B_ * nb_g1 + 1);
     sums2.ensure(B_ * nb_g2 + 1);
@@ -103,9 +109,15 @@ __device__ __forceinline__ int signed_digit(const uint32_t *l, int w, int c, int
     return raw;
 }
 
-// one workgroup per instance.  dyn LDS: nb counters + SORT_THREADS scan slots
-__global__ __launch_bounds__(SORT_THREADS) void k_msm_sort(const Fr *__restrict__ scalars, size_t B, const uint32_t *__restrict__ rows, size_t n,
-                                                           int c, int W, uint32_t *__restrict__ bucket_start, uint32_t *__restrict__ entries,
+// One workgroup per instance.  dyn LDS: nb counters + SORT_THREADS scan slots.
+// DENSE  : every scalar is wide (quotient MSM); scalars are read from the instance-major copy
+//          dense[b * dense_stride + j] (Montgomery), fully coalesced.
+// !DENSE : only the scalars that k_msm_ones found to be neither 0 nor +-1 are processed: compact per-instance
+//          list gen_idx / gen_val (canonical) of length gen_count[b].
+template <bool DENSE>
+__global__ __launch_bounds__(SORT_THREADS) void k_msm_sort(const Fr *__restrict__ dense, size_t dense_stride, const uint32_t *__restrict__ gen_count,
+                                                           const uint32_t *__restrict__ gen_idx, const Fr *__restrict__ gen_val, size_t n, int c,
+                                                           int W, uint32_t *__restrict__ bucket_start, uint32_t *__restrict__ entries,
                                                            size_t max_entries) {
     extern __shared__ uint32_t lds[];
     const uint32_t nb = 1u << (c - 1);
@@ -113,12 +125,22 @@ __global__ __launch_bounds__(SORT_THREADS) void k_msm_sort(const Fr *__restrict_
     uint32_t *scan = lds + nb;
     const size_t b = blockIdx.x;
     const int tid = threadIdx.x;
+    const size_t cnt = DENSE ? n : (size_t)gen_count[b];
+    uint32_t *bs = bucket_start + b * (nb + 1);
+    if (cnt == 0) {     // nothing for the bucket pipeline: publish an empty histogram and leave
+        for (uint32_t i = tid; i <= nb; i += SORT_THREADS) bs[i] = 0;
+        return;
+    }
     for (uint32_t i = tid; i < nb; i += SORT_THREADS) hist[i] = 0;
     __syncthreads();
-    for (size_t j = tid; j < n; j += SORT_THREADS) {
-        Fr s = scalars[(size_t)rows[j] * B + b];
-        if (classify(s) != 2) continue;
-        Fr cs = s.from_mont();
+    auto load = [&](size_t k, uint32_t &j) -> Fr {
+        if (DENSE) { j = (uint32_t)k; return dense[b * dense_stride + k].from_mont(); }
+        j = gen_idx[b * n + k];
+        return gen_val[b * n + k];
+    };
+    for (size_t k = tid; k < cnt; k += SORT_THREADS) {
+        uint32_t j;
+        Fr cs = load(k, j);
         int carry = 0;
         for (int w = 0; w < W; w++) {
             int d = signed_digit(cs.l, w, c, carry);
@@ -126,7 +148,6 @@ __global__ __launch_bounds__(SORT_THREADS) void k_msm_sort(const Fr *__restrict_
         }
     }
     __syncthreads();
-    // exclusive scan of hist (nb is a multiple of SORT_THREADS or smaller)
     const uint32_t per = (nb + SORT_THREADS - 1) / SORT_THREADS;
     const uint32_t lo = tid * per;
     uint32_t sum = 0;
@@ -140,27 +161,25 @@ __global__ __launch_bounds__(SORT_THREADS) void k_msm_sort(const Fr *__restrict_
         __syncthreads();
     }
     uint32_t run = scan[tid] - sum;   // exclusive prefix of this thread's chunk
-    uint32_t *bs = bucket_start + b * (nb + 1);
     for (uint32_t i = lo; i < lo + per && i < nb; i++) {
-        uint32_t cnt = hist[i];
+        uint32_t cntb = hist[i];
         hist[i] = run;                // becomes the scatter cursor
         bs[i] = run;
-        run += cnt;
+        run += cntb;
     }
     if (tid == SORT_THREADS - 1) bs[nb] = scan[tid];
     __syncthreads();
     uint32_t *ent = entries + b * max_entries;
-    for (size_t j = tid; j < n; j += SORT_THREADS) {
-        Fr s = scalars[(size_t)rows[j] * B + b];
-        if (classify(s) != 2) continue;
-        Fr cs = s.from_mont();
+    for (size_t k = tid; k < cnt; k += SORT_THREADS) {
+        uint32_t j;
+        Fr cs = load(k, j);
         int carry = 0;
         for (int w = 0; w < W; w++) {
             int d = signed_digit(cs.l, w, c, carry);
             if (!d) continue;
             uint32_t neg = d < 0;
             uint32_t pos = atomicAdd(&hist[(neg ? -d : d) - 1], 1u);
-            ent[pos] = (uint32_t)(j * W + w) | (neg << 31);
+            ent[pos] = (uint32_t)((size_t)j * W + w) | (neg << 31);
         }
     }
 }
@@ -258,11 +277,13 @@ __global__ __launch_bounds__(64) void k_msm_bucket_reduce(const XYZZ<F> *__restr
     part[b * part_stride + part_off + seg] = tot;
 }
 
-// thread (chunk, b): lanes = consecutive instances
+// thread (chunk, b): lanes = consecutive instances.  Scalars +-1 are summed here; scalars that are neither 0 nor
+// +-1 are appended (index + canonical value) to the instance's compact list for the bucket pipeline.
 template <class F>
 __global__ __launch_bounds__(256) void k_msm_ones(const Affine<F> *__restrict__ table, int W, const Fr *__restrict__ scalars, size_t B,
                                                   const uint32_t *__restrict__ rows, size_t n, XYZZ<F> *__restrict__ part,
-                                                  size_t part_stride, size_t part_off) {
+                                                  size_t part_stride, size_t part_off, uint32_t *__restrict__ gen_count,
+                                                  uint32_t *__restrict__ gen_idx, Fr *__restrict__ gen_val) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t nchunks = (n + ONES_CHUNK - 1) / ONES_CHUNK;
     if (t >= nchunks * B) return;
@@ -273,14 +294,40 @@ __global__ __launch_bounds__(256) void k_msm_ones(const Affine<F> *__restrict__ 
     const Fr one = Fr::one(), mone = fr_minus_one();
     for (size_t j = j0; j < j1; j++) {
         const Fr s = scalars[(size_t)rows[j] * B + b];
+        if (s.is_zero()) continue;
         const bool pos = s == one, neg = s == mone;
         if (pos || neg) {
             Affine<F> p = table[j * W];
             if (neg) p.y = p.y.neg();
             acc.madd(p);
+        } else {
+            const uint32_t k = atomicAdd(&gen_count[b], 1u);
+            gen_idx[b * n + k] = (uint32_t)j;
+            gen_val[b * n + k] = s.from_mont();
         }
     }
     part[b * part_stride + part_off + chunk] = acc;
+}
+
+// instance-major copy of a [rows][B] matrix: out[b * stride + i] = in[i * B + b]  (tiled through LDS)
+__global__ __launch_bounds__(256) void k_transpose_fr(const Fr *__restrict__ in, Fr *__restrict__ out, size_t rows, size_t B, size_t stride) {
+    __shared__ uint4 tile[2][32][33];
+    const size_t i0 = (size_t)blockIdx.x * 32, b0 = (size_t)blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+    const uint4 *src = (const uint4 *)in;
+    uint4 *dst = (uint4 *)out;
+    for (int r = ty; r < 32; r += 8) {
+        const size_t i = i0 + r, b = b0 + tx;
+        if (i < rows && b < B) { tile[0][r][tx] = src[(i * B + b) * 2]; tile[1][r][tx] = src[(i * B + b) * 2 + 1]; }
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const size_t b = b0 + r, i = i0 + tx;
+        if (i < rows && b < B) { dst[(b * stride + i) * 2] = tile[0][tx][r]; dst[(b * stride + i) * 2 + 1] = tile[1][tx][r]; }
+    }
+}
+void fr_transpose(const Fr *in, Fr *out, size_t rows, size_t B, size_t stride, hipStream_t s) {
+    hipLaunchKernelGGL(k_transpose_fr, dim3(ceil_div(rows, 32), ceil_div(B, 32)), dim3(256), 0, s, in, out, rows, B, stride);
 }
 
 // out[b*out_stride + g] = sum_{i < group} in[b*in_stride + g*group + i]   (i bounded by count)
@@ -334,13 +381,23 @@ static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, M
     size_t lds = (size_t)(nb + SORT_THREADS) * sizeof(uint32_t);
     static bool attr_set = false;
     if (!attr_set) {
-        ZK_HIP(hipFuncSetAttribute((const void *)k_msm_sort, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+        ZK_HIP(hipFuncSetAttribute((const void *)k_msm_sort<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+        ZK_HIP(hipFuncSetAttribute((const void *)k_msm_sort<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_msm_sort, dim3((unsigned)B), dim3(SORT_THREADS), lds, s, scalars, B, mb.scalar_row.p, n, c, W, sc.bucket_start.p,
-                       sc.entries.p, max_entries);
-    hipLaunchKernelGGL(k_msm_ones<F>, dim3(ceil_div(nchunks * B, 256)), dim3(256), 0, s, mb.table.p, W, scalars, B, mb.scalar_row.p, n, part,
-                       stride, (size_t)0);
+    if (mb.dense) {
+        // scalars = instance-major [B][dense_stride] copy; no +-1 fast path (every quotient coefficient is wide)
+        ZK_HIP(hipMemsetAsync(part, 0, B * stride * sizeof(XYZZ<F>), s));
+        hipLaunchKernelGGL(k_msm_sort<true>, dim3((unsigned)B), dim3(SORT_THREADS), lds, s, scalars, mb.dense_stride, (const uint32_t *)nullptr,
+                           (const uint32_t *)nullptr, (const Fr *)nullptr, n, c, W, sc.bucket_start.p, sc.entries.p, max_entries);
+    } else {
+        if (sc.gen_count.n < B || sc.gen_idx.n < B * n || sc.gen_val.n < B * n) throw ZkError("msm compact-list scratch too small");
+        ZK_HIP(hipMemsetAsync(sc.gen_count.p, 0, B * sizeof(uint32_t), s));
+        hipLaunchKernelGGL(k_msm_ones<F>, dim3(ceil_div(nchunks * B, 256)), dim3(256), 0, s, mb.table.p, W, scalars, B, mb.scalar_row.p, n, part,
+                           stride, (size_t)0, sc.gen_count.p, sc.gen_idx.p, sc.gen_val.p);
+        hipLaunchKernelGGL(k_msm_sort<false>, dim3((unsigned)B), dim3(SORT_THREADS), lds, s, (const Fr *)nullptr, (size_t)0, sc.gen_count.p, sc.gen_idx.p,
+                           sc.gen_val.p, n, c, W, sc.bucket_start.p, sc.entries.p, max_entries);
+    }
     // lanes per instance for the accumulate kernel: ~2048 entries per lane at the worst case (all scalars wide)
     uint32_t nlanes = (uint32_t)((max_entries + 2047) / 2048);
     if (nlanes < 1) nlanes = 1;

@@ -170,7 +170,7 @@ static void launch_dit(Fr *data, size_t B, int logn, int logS, const Fr *tw, con
     hipLaunchKernelGGL(k_ntt_dit<K>, dim3(ceil_div(threads, 256)), dim3(256), 0, s, data, B, logn, logS, tw, premul);
 }
 
-static constexpr int KMAX = 3;
+static constexpr int KMAX = 3;     // radix-8 (radix-16 needs 256 VGPRs -> 1 wave/SIMD or spills: measured worse)
 
 void NttDomain::dif(Fr *data, size_t B, bool inverse, const Fr *postmul, hipStream_t s) const {
     const Fr *tw = inverse ? tw_inv.p : tw_fwd.p;
@@ -181,7 +181,8 @@ void NttDomain::dif(Fr *data, size_t B, bool inverse, const Fr *postmul, hipStre
         switch (k) {
             case 1: launch_dif<1>(data, B, logn, loglen, tw, pm, s); break;
             case 2: launch_dif<2>(data, B, logn, loglen, tw, pm, s); break;
-            default: launch_dif<3>(data, B, logn, loglen, tw, pm, s); break;
+            case 3: launch_dif<3>(data, B, logn, loglen, tw, pm, s); break;
+            default: launch_dif<4>(data, B, logn, loglen, tw, pm, s); break;
         }
         loglen -= k;
     }
@@ -196,7 +197,8 @@ void NttDomain::dit(Fr *data, size_t B, bool inverse, const Fr *premul, hipStrea
         switch (k) {
             case 1: launch_dit<1>(data, B, logn, logS, tw, pm, s); break;
             case 2: launch_dit<2>(data, B, logn, logS, tw, pm, s); break;
-            default: launch_dit<3>(data, B, logn, logS, tw, pm, s); break;
+            case 3: launch_dit<3>(data, B, logn, logS, tw, pm, s); break;
+            default: launch_dit<4>(data, B, logn, logS, tw, pm, s); break;
         }
         logS += k;
     }

@@ -16,6 +16,8 @@ struct ProvingKeyDev {
     size_t n_wires = 0;
     DevBuf<G1Affine> g1_misc;   // alpha, beta, delta
     DevBuf<G2Affine> g2_misc;   // beta, delta
+    DevBuf<G1Affine> delta_tab; // fixed-base table of delta (8-bit windows)
+    DevBuf<G2Affine> delta2_tab;
     MsmBasesG1 A, B1, K, Z, ped, ped_sigma;
     MsmBasesG2 B2;
     size_t n_ped = 0;

@@ -85,6 +85,17 @@ static uint32_t bitrev32(uint32_t v, int bits) {
 }
 }  // namespace
 
+// Fixed-base table for delta (the only base of r*delta, s*delta, -rs*delta): tab[w*255 + d-1] = d * 2^(8w) * base
+template <class F>
+__global__ __launch_bounds__(64) void k_fixed_table(const Affine<F> *__restrict__ base, Affine<F> *__restrict__ tab) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 32 * 255) return;
+    const uint32_t w = t / 255, d = t % 255 + 1;
+    uint32_t k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    k[w >> 2] = d << ((w & 3) * 8);
+    tab[t] = scalar_mul(*base, k, 256).to_affine();
+}
+
 // ---------------------------------------------------------------------------- device state
 struct Algorithm::Resident {
     size_t B = 0, cap = 0;
@@ -93,7 +104,8 @@ struct Algorithm::Resident {
     DevBuf<G1XYZZ> m_ar, m_bs1, m_k, m_z, m_com, m_pok;
     DevBuf<G2XYZZ> m_bs2;
     DevBuf<U256> r, s, rnd, chal;
-    DevBuf<G1Affine> com_aff, pok_aff;
+    DevBuf<G1Affine> com_aff, pok_aff, ar_aff, bs1_aff;
+    DevBuf<G1XYZZ> f_t, f_u, f_v;
     DevBuf<ProofPoints> out;
     hipStream_t stream = nullptr;
     hipEvent_t ev[10] = {};
@@ -153,7 +165,6 @@ void Algorithm::load(const uint8_t *pkb, size_t pk_len, const uint8_t *r1cs_byte
     if (rowsA.size() != sA.n || rowsB.size() != sB.n || rowsB.size() != sB2.n || rowsK.size() != sK.n || ninfA != nw - sA.n || ninfB != nw - sB.n)
         throw ZkError("proving key: point counts do not match the constraint system");
     if (sZ.n + 1 < N) throw ZkError("proving key: too few Z points");
-    for (size_t k = 0; k + 1 < N; k++) rowsZ.push_back(bitrev32((uint32_t)k, logn));   // H is produced in bit-reversed order
     sZ.n = N - 1;
     if (has_commit) {
         if (sPed.n != prog.private_committed.size() || sPedS.n != sPed.n) throw ZkError("proving key: pedersen basis size mismatch");
@@ -162,10 +173,22 @@ void Algorithm::load(const uint8_t *pkb, size_t pk_len, const uint8_t *r1cs_byte
     DevBuf<G1Affine> pts;
     upload_g1(pkb, misc1, pk.g1_misc, st);
     upload_g2(pkb, misc2, pk.g2_misc, st);
+    pk.delta_tab.alloc(32 * 255); pk.delta2_tab.alloc(32 * 255);
+    hipLaunchKernelGGL(k_fixed_table<Fp>, dim3(ceil_div(32 * 255, 64)), dim3(64), 0, st, pk.g1_misc.p + 2, pk.delta_tab.p);
+    hipLaunchKernelGGL(k_fixed_table<Fp2>, dim3(ceil_div(32 * 255, 64)), dim3(64), 0, st, pk.g2_misc.p + 1, pk.delta2_tab.p);
     upload_g1(pkb, sA, pts, st); msm_bases_build(pk.A, pts.p, sA.n, rowsA.data(), C_WIRE, st);
     upload_g1(pkb, sB, pts, st); msm_bases_build(pk.B1, pts.p, sB.n, rowsB.data(), C_WIRE, st);
     upload_g1(pkb, sK, pts, st); msm_bases_build(pk.K, pts.p, sK.n, rowsK.data(), C_WIRE, st);
-    upload_g1(pkb, sZ, pts, st); msm_bases_build(pk.Z, pts.p, sZ.n, rowsZ.data(), C_H, st);
+    {   // H comes out of computeH in bit-reversed coefficient order: store the Z bases in that order so that the
+        // (dense, instance-major) scalar vector is consumed linearly.  bitrev(N-1) = N-1, so positions 0..N-2 cover Z_0..Z_{N-2}.
+        upload_g1(pkb, sZ, pts, st);
+        std::vector<G1Affine> hz(sZ.n), hp(sZ.n);
+        ZK_HIP(hipMemcpy(hz.data(), pts.p, sZ.n * sizeof(G1Affine), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i + 1 < N; i++) hp[i] = hz[bitrev32((uint32_t)i, logn)];
+        ZK_HIP(hipMemcpy(pts.p, hp.data(), sZ.n * sizeof(G1Affine), hipMemcpyHostToDevice));
+        msm_bases_build(pk.Z, pts.p, sZ.n, nullptr, C_H, st);
+        pk.Z.dense_stride = N;
+    }
     pk.n_ped = 0;
     if (has_commit) {
         upload_g1(pkb, sPed, pts, st); msm_bases_build(pk.ped, pts.p, sPed.n, rowsPed.data(), C_WIRE, st);
@@ -190,36 +213,74 @@ __device__ __forceinline__ void store_fp(U256 &dst, const Fp &v) {
 #pragma unroll
     for (int k = 0; k < 8; k++) dst.l[k] = v.l[k];
 }
-// Ar = A + alpha + r*delta ; Bs1 = B + beta + s*delta ; Krs = K + Z + (-rs)*delta + s*Ar + r*Bs1
-__global__ __launch_bounds__(64) void k_finalize_g1(const G1XYZZ *__restrict__ m_ar, const G1XYZZ *__restrict__ m_bs1, const G1XYZZ *__restrict__ m_k,
-                                                    const G1XYZZ *__restrict__ m_z, const G1Affine *__restrict__ misc, const U256 *__restrict__ r,
-                                                    const U256 *__restrict__ s, ProofPoints *__restrict__ out, size_t B) {
-    size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+template <class F>
+__device__ __forceinline__ XYZZ<F> fixed_mul(const Affine<F> *__restrict__ tab, const uint32_t *k) {
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (int w = 0; w < 32; w++) {
+        const uint32_t d = (k[w >> 2] >> ((w & 3) * 8)) & 0xff;
+        if (d) acc.madd(tab[w * 255 + d - 1]);
+    }
+    return acc;
+}
+// Stage 1 (blockIdx.y = task, lanes = instances): 0: Ar = A + alpha + r*delta   1: Bs1 = B + beta + s*delta   2: T = (-rs)*delta
+__global__ __launch_bounds__(64) void k_finalize_stage1(const G1XYZZ *__restrict__ m_ar, const G1XYZZ *__restrict__ m_bs1, const G1Affine *__restrict__ misc,
+                                                        const G1Affine *__restrict__ dtab, const U256 *__restrict__ r, const U256 *__restrict__ s,
+                                                        G1Affine *__restrict__ ar_aff, G1Affine *__restrict__ bs1_aff, G1XYZZ *__restrict__ t_out, size_t B) {
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    const G1Affine alpha = misc[0], beta = misc[1], delta = misc[2];
+    const int task = blockIdx.y;
     Fr rm, sm;
 #pragma unroll
     for (int k = 0; k < 8; k++) { rm.l[k] = r[b].l[k]; sm.l[k] = s[b].l[k]; }
-    const Fr kr = (rm.to_mont() * sm.to_mont()).neg().from_mont();
-    G1XYZZ ar = m_ar[b];
-    ar.madd(alpha);
-    ar.add(scalar_mul(delta, rm.l));
-    G1XYZZ bs1 = m_bs1[b];
-    bs1.madd(beta);
-    bs1.add(scalar_mul(delta, sm.l));
-    const G1Affine ar_a = ar.to_affine(), bs1_a = bs1.to_affine();
+    if (task == 0) {
+        G1XYZZ ar = m_ar[b];
+        ar.madd(misc[0]);
+        ar.add(fixed_mul(dtab, rm.l));
+        ar_aff[b] = ar.to_affine();
+    } else if (task == 1) {
+        G1XYZZ bs1 = m_bs1[b];
+        bs1.madd(misc[1]);
+        bs1.add(fixed_mul(dtab, sm.l));
+        bs1_aff[b] = bs1.to_affine();
+    } else {
+        const Fr kr = (rm.to_mont() * sm.to_mont()).neg().from_mont();
+        t_out[b] = fixed_mul(dtab, kr.l);
+    }
+}
+// Stage 2 (blockIdx.y = task): 0: U = s*Ar   1: V = r*Bs1   (variable base)
+__global__ __launch_bounds__(64) void k_finalize_stage2(const G1Affine *__restrict__ ar_aff, const G1Affine *__restrict__ bs1_aff, const U256 *__restrict__ r,
+                                                        const U256 *__restrict__ s, G1XYZZ *__restrict__ u_out, G1XYZZ *__restrict__ v_out, size_t B) {
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    uint32_t k[8];
+    if (blockIdx.y == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) k[i] = s[b].l[i];
+        u_out[b] = scalar_mul(ar_aff[b], k);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) k[i] = r[b].l[i];
+        v_out[b] = scalar_mul(bs1_aff[b], k);
+    }
+}
+// Stage 3: Krs = K + Z + T + U + V ; canonical outputs
+__global__ __launch_bounds__(64) void k_finalize_stage3(const G1XYZZ *__restrict__ m_k, const G1XYZZ *__restrict__ m_z, const G1XYZZ *__restrict__ t_in,
+                                                        const G1XYZZ *__restrict__ u_in, const G1XYZZ *__restrict__ v_in, const G1Affine *__restrict__ ar_aff,
+                                                        ProofPoints *__restrict__ out, size_t B) {
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
     G1XYZZ krs = m_k[b];
     krs.add(m_z[b]);
-    krs.add(scalar_mul(delta, kr.l));
-    krs.add(scalar_mul(ar_a, sm.l));
-    krs.add(scalar_mul(bs1_a, rm.l));
-    const G1Affine krs_a = krs.to_affine();
+    krs.add(t_in[b]);
+    krs.add(u_in[b]);
+    krs.add(v_in[b]);
+    const G1Affine krs_a = krs.to_affine(), ar_a = ar_aff[b];
     store_fp(out[b].ar[0], ar_a.x.from_mont()); store_fp(out[b].ar[1], ar_a.y.from_mont());
     store_fp(out[b].krs[0], krs_a.x.from_mont()); store_fp(out[b].krs[1], krs_a.y.from_mont());
 }
 // Bs = B2 + beta2 + s*delta2
-__global__ __launch_bounds__(64) void k_finalize_g2(const G2XYZZ *__restrict__ m_bs2, const G2Affine *__restrict__ misc, const U256 *__restrict__ s,
-                                                    ProofPoints *__restrict__ out, size_t B) {
+__global__ __launch_bounds__(64) void k_finalize_g2(const G2XYZZ *__restrict__ m_bs2, const G2Affine *__restrict__ misc, const G2Affine *__restrict__ dtab,
+                                                    const U256 *__restrict__ s, ProofPoints *__restrict__ out, size_t B) {
     size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     uint32_t sl[8];
@@ -227,7 +288,7 @@ __global__ __launch_bounds__(64) void k_finalize_g2(const G2XYZZ *__restrict__ m
     for (int k = 0; k < 8; k++) sl[k] = s[b].l[k];
     G2XYZZ bs = m_bs2[b];
     bs.madd(misc[0]);
-    bs.add(scalar_mul(misc[1], sl));
+    bs.add(fixed_mul(dtab, sl));
     const G2Affine a = bs.to_affine();
     store_fp(out[b].bs[0], a.x.a0.from_mont()); store_fp(out[b].bs[1], a.x.a1.from_mont());
     store_fp(out[b].bs[2], a.y.a0.from_mont()); store_fp(out[b].bs[3], a.y.a1.from_mont());
@@ -265,6 +326,7 @@ void Algorithm::resident_reserve(size_t B) {
     acc(pk.B2.n, pk.B2.c, pk.B2.W);
     if (has_commit) acc(pk.ped.n, pk.ped.c, pk.ped.W);
     R.ms.reserve(B, max_entries, max_nb, max_part);
+    R.ms.reserve_compact(B, std::max({pk.A.n, pk.B1.n, pk.K.n, pk.B2.n, has_commit ? pk.ped.n : (size_t)1}));
     {
         size_t nb1 = (size_t)1 << (std::max({pk.A.c, pk.B1.c, pk.K.c, pk.Z.c, has_commit ? pk.ped.c : 1}) - 1);
         R.ms.reserve_sums(B, nb1, (size_t)1 << (pk.B2.c - 1));
@@ -272,6 +334,7 @@ void Algorithm::resident_reserve(size_t B) {
     R.m_ar.alloc(B); R.m_bs1.alloc(B); R.m_k.alloc(B); R.m_z.alloc(B); R.m_com.alloc(B); R.m_pok.alloc(B); R.m_bs2.alloc(B);
     R.r.alloc(B); R.s.alloc(B); R.rnd.alloc(B); R.chal.alloc(B);
     R.com_aff.alloc(B); R.pok_aff.alloc(B); R.out.alloc(B);
+    R.ar_aff.alloc(B); R.bs1_aff.alloc(B); R.f_t.alloc(B); R.f_u.alloc(B); R.f_v.alloc(B);
     R.h_com.resize(B); R.h_chal.resize(B);
 }
 
@@ -329,12 +392,16 @@ void Algorithm::resident_prove(PhaseTimes *times) {
     msm_batch(pk.A, R.sb.wires.p, B, R.ms, R.m_ar.p, st);
     msm_batch(pk.B1, R.sb.wires.p, B, R.ms, R.m_bs1.p, st);
     msm_batch(pk.K, R.sb.wires.p, B, R.ms, R.m_k.p, st);
-    msm_batch(pk.Z, R.sb.a.p, B, R.ms, R.m_z.p, st, &R.ev[8]);
+    fr_transpose(R.sb.a.p, R.sb.b.p, (size_t)1 << prog.log_domain, B, (size_t)1 << prog.log_domain, st);   // b is free after computeH
+    msm_batch(pk.Z, R.sb.b.p, B, R.ms, R.m_z.p, st, &R.ev[8]);
     ZK_HIP(hipEventRecord(R.ev[5], st));
     msm_batch(pk.B2, R.sb.wires.p, B, R.ms, R.m_bs2.p, st);
     ZK_HIP(hipEventRecord(R.ev[6], st));
-    hipLaunchKernelGGL(k_finalize_g1, dim3(ceil_div(B, 64)), dim3(64), 0, st, R.m_ar.p, R.m_bs1.p, R.m_k.p, R.m_z.p, pk.g1_misc.p, R.r.p, R.s.p, R.out.p, B);
-    hipLaunchKernelGGL(k_finalize_g2, dim3(ceil_div(B, 64)), dim3(64), 0, st, R.m_bs2.p, pk.g2_misc.p, R.s.p, R.out.p, B);
+    hipLaunchKernelGGL(k_finalize_stage1, dim3(ceil_div(B, 64), 3), dim3(64), 0, st, R.m_ar.p, R.m_bs1.p, pk.g1_misc.p, pk.delta_tab.p, R.r.p, R.s.p,
+                       R.ar_aff.p, R.bs1_aff.p, R.f_t.p, B);
+    hipLaunchKernelGGL(k_finalize_g2, dim3(ceil_div(B, 64)), dim3(64), 0, st, R.m_bs2.p, pk.g2_misc.p, pk.delta2_tab.p, R.s.p, R.out.p, B);
+    hipLaunchKernelGGL(k_finalize_stage2, dim3(ceil_div(B, 64), 2), dim3(64), 0, st, R.ar_aff.p, R.bs1_aff.p, R.r.p, R.s.p, R.f_u.p, R.f_v.p, B);
+    hipLaunchKernelGGL(k_finalize_stage3, dim3(ceil_div(B, 64)), dim3(64), 0, st, R.m_k.p, R.m_z.p, R.f_t.p, R.f_u.p, R.f_v.p, R.ar_aff.p, R.out.p, B);
     hipLaunchKernelGGL(k_store_commit, dim3(ceil_div(B, 64)), dim3(64), 0, st, R.com_aff.p, R.pok_aff.p, R.out.p, B, has_commit ? 1 : 0);
     ZK_HIP(hipGetLastError());
     ZK_HIP(hipEventRecord(R.ev[7], st));

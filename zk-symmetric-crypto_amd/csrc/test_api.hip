@@ -122,6 +122,7 @@ static int msm_test(long n_, long batch, const uint8_t *points, const uint8_t *s
     fr_to_mont(ds.p, n * B, 0);
     MsmScratch sc;
     sc.reserve(B, n * mb.W, (size_t)1 << (c - 1), msm_part_stride(n, c));
+    sc.reserve_compact(B, n);
     sc.reserve_sums(B, sizeof(F) == 32 ? (size_t)1 << (c - 1) : 1, sizeof(F) == 32 ? 1 : (size_t)1 << (c - 1));
     DevBuf<XYZZ<F>> res(B);
     DevBuf<Affine<F>> aff(B);
