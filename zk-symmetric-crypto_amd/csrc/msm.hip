@@ -56,7 +56,9 @@ static void bases_build(MsmBases<F> &mb, const Affine<F> *d_points, size_t n, co
     if (n && h_rows) ZK_HIP(hipMemcpyAsync(mb.scalar_row.p, h_rows, n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
     size_t tot = n * mb.W;
     mb.table.alloc(tot ? tot : 1);
+    mb.base.alloc(n ? n : 1);
     if (!n) return;
+    ZK_HIP(hipMemcpyAsync(mb.base.p, d_points, n * sizeof(Affine<F>), hipMemcpyDeviceToDevice, s));
     // chunked to bound the XYZZ temp
     const size_t CH = 1 << 16;
     DevBuf<XYZZ<F>> tmp(CH * mb.W);
@@ -279,31 +281,45 @@ __global__ __launch_bounds__(64) void k_msm_bucket_reduce(const XYZZ<F> *__restr
 
 // thread (chunk, b): lanes = consecutive instances.  Scalars +-1 are summed here; scalars that are neither 0 nor
 // +-1 are appended (index + canonical value) to the instance's compact list for the bucket pipeline.
+// Two phases per thread: (1) classify the chunk's 128 scalars into +1 / -1 bit masks (coalesced row reads),
+// (2) walk the set bits only -- a wavefront then runs max-over-lanes(popcount) ~ 77 mixed additions instead of
+// 128 predicated ones (49 % of the ChaCha wire scalars are +-1).
 template <class F>
-__global__ __launch_bounds__(256) void k_msm_ones(const Affine<F> *__restrict__ table, int W, const Fr *__restrict__ scalars, size_t B,
+__global__ __launch_bounds__(256) void k_msm_ones(const Affine<F> *__restrict__ base, const Fr *__restrict__ scalars, size_t B,
                                                   const uint32_t *__restrict__ rows, size_t n, XYZZ<F> *__restrict__ part,
                                                   size_t part_stride, size_t part_off, uint32_t *__restrict__ gen_count,
                                                   uint32_t *__restrict__ gen_idx, Fr *__restrict__ gen_val) {
+    static_assert(ONES_CHUNK == 128, "mask layout");
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t nchunks = (n + ONES_CHUNK - 1) / ONES_CHUNK;
     if (t >= nchunks * B) return;
     const size_t b = t % B, chunk = t / B;
     const size_t j0 = chunk * ONES_CHUNK;
     const size_t j1 = j0 + ONES_CHUNK < n ? j0 + ONES_CHUNK : n;
-    XYZZ<F> acc = XYZZ<F>::inf();
     const Fr one = Fr::one(), mone = fr_minus_one();
+    uint32_t pos[4] = {0, 0, 0, 0}, neg[4] = {0, 0, 0, 0};
     for (size_t j = j0; j < j1; j++) {
         const Fr s = scalars[(size_t)rows[j] * B + b];
         if (s.is_zero()) continue;
-        const bool pos = s == one, neg = s == mone;
-        if (pos || neg) {
-            Affine<F> p = table[j * W];
-            if (neg) p.y = p.y.neg();
+        const uint32_t k = (uint32_t)(j - j0);
+        if (s == one) pos[k >> 5] |= 1u << (k & 31);
+        else if (s == mone) neg[k >> 5] |= 1u << (k & 31);
+        else {
+            const uint32_t q = atomicAdd(&gen_count[b], 1u);
+            gen_idx[b * n + q] = (uint32_t)j;
+            gen_val[b * n + q] = s.from_mont();
+        }
+    }
+    XYZZ<F> acc = XYZZ<F>::inf();
+#pragma unroll
+    for (int wd = 0; wd < 4; wd++) {
+        uint32_t m = pos[wd] | neg[wd];
+        while (m) {
+            const int bit = __ffs((int)m) - 1;
+            m &= m - 1;
+            Affine<F> p = base[j0 + wd * 32 + bit];
+            if ((neg[wd] >> bit) & 1) p.y = p.y.neg();
             acc.madd(p);
-        } else {
-            const uint32_t k = atomicAdd(&gen_count[b], 1u);
-            gen_idx[b * n + k] = (uint32_t)j;
-            gen_val[b * n + k] = s.from_mont();
         }
     }
     part[b * part_stride + part_off + chunk] = acc;
@@ -393,7 +409,7 @@ static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, M
     } else {
         if (sc.gen_count.n < B || sc.gen_idx.n < B * n || sc.gen_val.n < B * n) throw ZkError("msm compact-list scratch too small");
         ZK_HIP(hipMemsetAsync(sc.gen_count.p, 0, B * sizeof(uint32_t), s));
-        hipLaunchKernelGGL(k_msm_ones<F>, dim3(ceil_div(nchunks * B, 256)), dim3(256), 0, s, mb.table.p, W, scalars, B, mb.scalar_row.p, n, part,
+        hipLaunchKernelGGL(k_msm_ones<F>, dim3(ceil_div(nchunks * B, 256)), dim3(256), 0, s, mb.base.p, scalars, B, mb.scalar_row.p, n, part,
                            stride, (size_t)0, sc.gen_count.p, sc.gen_idx.p, sc.gen_val.p);
         hipLaunchKernelGGL(k_msm_sort<false>, dim3((unsigned)B), dim3(SORT_THREADS), lds, s, (const Fr *)nullptr, (size_t)0, sc.gen_count.p, sc.gen_idx.p,
                            sc.gen_val.p, n, c, W, sc.bucket_start.p, sc.entries.p, max_entries);

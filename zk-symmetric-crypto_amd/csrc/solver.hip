@@ -232,6 +232,19 @@ struct SolveCtx {
     size_t B, count_rows;
 };
 
+// Almost every wire of these circuits is a bit, so coefficient * wire and <L,w> * <R,w> are mostly products with
+// 0 or 1: test for that before paying a 254-bit Montgomery multiplication (all lanes agree in practice, the
+// add32 / FromBinary constraints with ~100 power-of-two terms otherwise cost ~100 sequential multiplications).
+__device__ __forceinline__ Fr mul_fast(const Fr &a, const Fr &b) {
+    if (a.is_zero() || b.is_zero()) return Fr::zero();
+    const Fr one = Fr::one();
+    if (a == one) return b;
+    if (b == one) return a;
+    const Fr mone = one.neg();          // -1 is the third common wire value (a - b of two bits, XOR intermediates)
+    if (a == mone) return b.neg();
+    if (b == mone) return a.neg();
+    return a * b;
+}
 __device__ __forceinline__ Fr term_val(const SolveCtx &cx, uint32_t cid, uint32_t wid, size_t b) {
     if (wid == WIRE_CONST) return cx.coeffs[cid];
     const Fr w = cx.wires[(size_t)wid * cx.B + b];
@@ -241,12 +254,46 @@ __device__ __forceinline__ Fr term_val(const SolveCtx &cx, uint32_t cid, uint32_
         case 2: return w.dbl();
         case 3: return w.neg();
         case 4: return w.dbl().neg();
-        default: return cx.coeffs[cid] * w;
+        default: return mul_fast(w, cx.coeffs[cid]);
+    }
+}
+// p is wave-uniform (one instruction per workgroup row): the (cid, wid) words come from scalar loads, and the
+// wire loads of four terms are issued together so that a 100-term linear expression costs ~25 memory round
+// trips instead of 100 (the long add32 constraints used to set every level's latency).
+__device__ __forceinline__ Fr term_apply(const SolveCtx &cx, uint32_t cid, uint32_t wid, const Fr &w) {
+    if (wid == WIRE_CONST) return cx.coeffs[cid];
+    switch (cid) {
+        case 0: return Fr::zero();
+        case 1: return w;
+        case 2: return w.dbl();
+        case 3: return w.neg();
+        case 4: return w.dbl().neg();
+        default: return mul_fast(w, cx.coeffs[cid]);
     }
 }
 __device__ __forceinline__ Fr eval_terms(const SolveCtx &cx, const uint32_t *&p, uint32_t n, size_t b) {
     Fr acc = Fr::zero();
-    for (uint32_t k = 0; k < n; k++, p += 2) acc = acc + term_val(cx, p[0], p[1], b);
+    uint32_t k = 0;
+    for (; k + 8 <= n; k += 8, p += 16) {
+        // unconditional loads (constants read wire 0, a valid address): a conditional load would be branched around
+        // and waited for one by one
+        Fr v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const uint32_t w = p[2 * q + 1];
+            v[q] = cx.wires[(size_t)(w == WIRE_CONST ? 0u : w) * cx.B + b];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) acc = acc + term_apply(cx, p[2 * q], p[2 * q + 1], v[q]);
+    }
+    for (; k + 2 <= n; k += 2, p += 4) {
+        const uint32_t w0 = p[1], w1 = p[3];
+        const Fr v0 = cx.wires[(size_t)(w0 == WIRE_CONST ? 0u : w0) * cx.B + b];
+        const Fr v1 = cx.wires[(size_t)(w1 == WIRE_CONST ? 0u : w1) * cx.B + b];
+        acc = acc + term_apply(cx, p[0], w0, v0);
+        acc = acc + term_apply(cx, p[2], w1, v1);
+    }
+    for (; k < n; k++, p += 2) acc = acc + term_val(cx, p[0], p[1], b);
     return acc;
 }
 __device__ __forceinline__ Fr eval_linexp(const SolveCtx &cx, const uint32_t *&p, size_t b) {
@@ -267,11 +314,12 @@ __device__ __forceinline__ bool small_index(const Fr &v_mont, uint32_t bound, ui
 
 __global__ __launch_bounds__(256) void k_solve_level(SolveCtx cx, const uint32_t *__restrict__ instr_off, const uint32_t *__restrict__ level_instr,
                                                      uint32_t count) {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // grid = (ceil(B / 256), instructions of the level): the instruction is uniform per workgroup, so the program
+    // words are scalar loads and all control flow on them is wave-uniform
     const size_t B = cx.B;
-    if (t >= (size_t)count * B) return;
-    const size_t b = t % B;
-    const uint32_t instr = level_instr[t / B];
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B || blockIdx.y >= count) return;
+    const uint32_t instr = level_instr[blockIdx.y];
     const uint32_t *p = cx.prog + instr_off[instr];
     const uint32_t op = p[0];
     if (op == OP_R1C) {
@@ -281,11 +329,11 @@ __global__ __launch_bounds__(256) void k_solve_level(SolveCtx cx, const uint32_t
         Fr vR = eval_terms(cx, p, nR, b);
         Fr vO = eval_terms(cx, p, nO, b);
         if (loc == 0) {
-            if (vL * vR != vO) report(cx, b, SERR_UNSATISFIED, cons);
+            if (mul_fast(vL, vR) != vO) report(cx, b, SERR_UNSATISFIED, cons);
         } else {
             Fr x = Fr::zero();
             if (loc == 3) {
-                x = vL * vR - vO;
+                x = mul_fast(vL, vR) - vO;
                 vO = vO + x;
             } else if (loc == 1) {
                 if (!vR.is_zero()) { x = vO * vR.inv() - vL; vL = vL + x; }
@@ -380,8 +428,10 @@ void solver_run_levels(const SolverProgram &p, SolverBuffers &buf, size_t first_
     for (size_t l = first_level; l < last_level && l < p.levels.size(); l++) {
         const SolverLevel &lv = p.levels[l];
         if (!lv.count) continue;
-        const size_t threads = (size_t)lv.count * buf.B;
-        hipLaunchKernelGGL(k_solve_level, dim3(ceil_div(threads, 256)), dim3(256), 0, s, cx, p.instr_off.p, p.level_instr.p + lv.first, lv.count);
+        for (uint32_t off = 0; off < lv.count; off += 65535) {       // grid.y limit
+            const uint32_t cnt = lv.count - off < 65535 ? lv.count - off : 65535;
+            hipLaunchKernelGGL(k_solve_level, dim3(ceil_div(buf.B, 256), cnt), dim3(256), 0, s, cx, p.instr_off.p, p.level_instr.p + lv.first + off, cnt);
+        }
     }
     ZK_HIP(hipGetLastError());
 }
