@@ -88,9 +88,10 @@ def pk_file_bytes(alg: int, seed: int = 1, raw: bool = True) -> bytes:
     if os.path.exists(path):
         return open(path, "rb").read()
     data = gf.pk_bytes(oracle_pk(alg, seed), raw=raw)
-    with open(path + ".tmp", "wb") as f:
+    tmp = "%s.tmp.%d" % (path, os.getpid())      # ranks of a multi-GPU run may build the fixture concurrently
+    with open(tmp, "wb") as f:
         f.write(data)
-    os.replace(path + ".tmp", path)
+    os.replace(tmp, path)
     return data
 
 

@@ -159,6 +159,191 @@ __global__ __launch_bounds__(256) void k_ntt_dit(Fr *__restrict__ data, size_t B
     for (int m = 0; m < R; m++) data[(base + ((size_t)m << logS)) * B + b] = x[m];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Two-level passes through LDS: a workgroup of 256 threads owns a tile of 2^(K1+K2) elements x TI instances
+// (TI * 2^(K1+K2) * 32 B = 64 KiB of LDS), does K1 butterfly stages in registers, exchanges through LDS and does
+// K2 more -- K1+K2 = 5..6 stages per HBM round trip instead of 3 (N = 2^16: 3 passes instead of 6).
+// Global accesses stay instance-contiguous (TI * 32 B segments).
+template <int K1, int K2>
+struct LdsTile {
+    static constexpr int K = K1 + K2;
+    static constexpr int E = 1 << K;               // elements per tile
+    static constexpr int TI = 2048 / E;            // instances per tile (E * TI = 2048 field elements = 64 KiB)
+    static constexpr int THREADS = 256;
+    static_assert(E * TI == 2048 && TI >= 1, "tile shape");
+};
+
+// DIF: stages loglen .. loglen-K+1 (block lengths len, len/2, ...).  Element e of the tile sits at
+// pos = blk*len + p + e*S with S = len >> K.
+template <int K1, int K2>
+__global__ __launch_bounds__(256) void k_ntt_dif_lds(Fr *__restrict__ data, size_t B, int logn, int loglen, const Fr *__restrict__ tw,
+                                                     const Fr *__restrict__ postmul) {
+    using T = LdsTile<K1, K2>;
+    constexpr int K = T::K, E = T::E, TI = T::TI, R1 = 1 << K1, R2 = 1 << K2;
+    extern __shared__ uint4 lds_raw[];
+    Fr *lds = (Fr *)lds_raw;                       // [E][TI]
+    const int tid = threadIdx.x;
+    const int bl = tid % TI;                       // instance within the tile
+    const size_t b = (size_t)blockIdx.y * TI + bl;
+    const int logS = loglen - K;
+    const size_t S = (size_t)1 << logS;
+    const size_t g = blockIdx.x;                   // tile index in [0, n >> K)
+    const size_t blk = g >> logS, p = g & (S - 1);
+    const size_t base = (blk << loglen) + p;
+    const bool active = b < B;
+    // ---- stage group A: thread holds e = q + R2' * m (R2' = E / R1), distances E/2 .. R2'
+    {
+        constexpr int STR = E / R1;                // element stride inside the thread's set
+        for (int q = tid / TI; q < STR; q += 256 / TI) {
+            Fr x[R1];
+#pragma unroll
+            for (int m = 0; m < R1; m++) {
+                const size_t e = (size_t)q + (size_t)STR * m;
+                x[m] = active ? data[(base + (e << logS)) * B + b] : Fr::zero();
+            }
+#pragma unroll
+            for (int st = 0; st < K1; st++) {
+                const int half = 1 << (K1 - 1 - st);
+                const int twshift = logn - (loglen - st);
+#pragma unroll
+                for (int m = 0; m < R1; m++) {
+                    if ((m / half) & 1) continue;
+                    const size_t j = p + (((size_t)q + (size_t)STR * (m % half)) << logS);
+                    Fr u = x[m], v = x[m + half];
+                    x[m] = u + v;
+                    Fr d = u - v;
+                    x[m + half] = (j == 0) ? d : d * tw[j << twshift];
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < R1; m++) lds[((size_t)q + (size_t)STR * m) * TI + bl] = x[m];
+        }
+    }
+    __syncthreads();
+    // ---- stage group B: thread holds e = q2 * R2 + m, distances R2/2 .. 1
+    {
+        for (int q2 = tid / TI; q2 < E / R2; q2 += 256 / TI) {
+            Fr x[R2];
+#pragma unroll
+            for (int m = 0; m < R2; m++) x[m] = lds[((size_t)q2 * R2 + m) * TI + bl];
+#pragma unroll
+            for (int st = 0; st < K2; st++) {
+                const int half = 1 << (K2 - 1 - st);
+                const int twshift = logn - (loglen - K1 - st);
+#pragma unroll
+                for (int m = 0; m < R2; m++) {
+                    if ((m / half) & 1) continue;
+                    const size_t j = p + ((size_t)(m % half) << logS);
+                    Fr u = x[m], v = x[m + half];
+                    x[m] = u + v;
+                    Fr d = u - v;
+                    x[m + half] = (j == 0) ? d : d * tw[j << twshift];
+                }
+            }
+            if (active) {
+#pragma unroll
+                for (int m = 0; m < R2; m++) {
+                    const size_t idx = base + (((size_t)q2 * R2 + m) << logS);
+                    Fr v = x[m];
+                    if (postmul) v = v * postmul[idx];
+                    data[idx * B + b] = v;
+                }
+            }
+        }
+    }
+}
+
+// DIT: stages with half-distances S, 2S, ... (S = 2^logS), tile element e at pos = blk*(S<<K) + p + e*S.
+template <int K1, int K2>
+__global__ __launch_bounds__(256) void k_ntt_dit_lds(Fr *__restrict__ data, size_t B, int logn, int logS, const Fr *__restrict__ tw,
+                                                     const Fr *__restrict__ premul) {
+    using T = LdsTile<K1, K2>;
+    constexpr int K = T::K, E = T::E, TI = T::TI, R1 = 1 << K1, R2 = 1 << K2;
+    extern __shared__ uint4 lds_raw[];
+    Fr *lds = (Fr *)lds_raw;
+    const int tid = threadIdx.x;
+    const int bl = tid % TI;
+    const size_t b = (size_t)blockIdx.y * TI + bl;
+    const size_t S = (size_t)1 << logS;
+    const size_t g = blockIdx.x;
+    const size_t blk = g >> logS, p = g & (S - 1);
+    const size_t base = (blk << (logS + K)) + p;
+    const bool active = b < B;
+    // ---- group A: consecutive elements e = q * R1 + m, distances 1 .. R1/2
+    {
+        for (int q = tid / TI; q < E / R1; q += 256 / TI) {
+            Fr x[R1];
+#pragma unroll
+            for (int m = 0; m < R1; m++) {
+                const size_t idx = base + (((size_t)q * R1 + m) << logS);
+                Fr v = active ? data[idx * B + b] : Fr::zero();
+                if (premul) v = v * premul[idx];
+                x[m] = v;
+            }
+#pragma unroll
+            for (int st = 0; st < K1; st++) {
+                const int h = 1 << st;
+                const int twshift = logn - (logS + st + 1);
+#pragma unroll
+                for (int m = 0; m < R1; m++) {
+                    if ((m >> st) & 1) continue;
+                    const size_t j = p + ((size_t)(m & (h - 1)) << logS);
+                    Fr u = x[m];
+                    Fr v = (j == 0) ? x[m + h] : x[m + h] * tw[j << twshift];
+                    x[m] = u + v;
+                    x[m + h] = u - v;
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < R1; m++) lds[((size_t)q * R1 + m) * TI + bl] = x[m];
+        }
+    }
+    __syncthreads();
+    // ---- group B: strided elements e = q2 + R1 * m, distances R1 .. E/2
+    {
+        for (int q2 = tid / TI; q2 < R1; q2 += 256 / TI) {
+            Fr x[R2];
+#pragma unroll
+            for (int m = 0; m < R2; m++) x[m] = lds[((size_t)q2 + (size_t)R1 * m) * TI + bl];
+#pragma unroll
+            for (int st = 0; st < K2; st++) {
+                const int h = 1 << st;                          // in units of R1 elements
+                const int twshift = logn - (logS + K1 + st + 1);
+#pragma unroll
+                for (int m = 0; m < R2; m++) {
+                    if ((m >> st) & 1) continue;
+                    const size_t j = p + (((size_t)q2 + (size_t)R1 * (m & (h - 1))) << logS);
+                    Fr u = x[m];
+                    Fr v = (j == 0) ? x[m + h] : x[m + h] * tw[j << twshift];
+                    x[m] = u + v;
+                    x[m + h] = u - v;
+                }
+            }
+            if (active) {
+#pragma unroll
+                for (int m = 0; m < R2; m++) data[(base + (((size_t)q2 + (size_t)R1 * m) << logS)) * B + b] = x[m];
+            }
+        }
+    }
+}
+
+template <int K1, int K2>
+static void launch_dif_lds(Fr *data, size_t B, int logn, int loglen, const Fr *tw, const Fr *postmul, hipStream_t s) {
+    using T = LdsTile<K1, K2>;
+    static bool attr = false;
+    if (!attr) { ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_dif_lds<K1, K2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr = true; }
+    dim3 grid((unsigned)(((size_t)1 << logn) >> T::K), ceil_div(B, T::TI));
+    hipLaunchKernelGGL((k_ntt_dif_lds<K1, K2>), grid, dim3(256), 65536, s, data, B, logn, loglen, tw, postmul);
+}
+template <int K1, int K2>
+static void launch_dit_lds(Fr *data, size_t B, int logn, int logS, const Fr *tw, const Fr *premul, hipStream_t s) {
+    using T = LdsTile<K1, K2>;
+    static bool attr = false;
+    if (!attr) { ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_dit_lds<K1, K2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr = true; }
+    dim3 grid((unsigned)(((size_t)1 << logn) >> T::K), ceil_div(B, T::TI));
+    hipLaunchKernelGGL((k_ntt_dit_lds<K1, K2>), grid, dim3(256), 65536, s, data, B, logn, logS, tw, premul);
+}
+
 template <int K>
 static void launch_dif(Fr *data, size_t B, int logn, int loglen, const Fr *tw, const Fr *postmul, hipStream_t s) {
     size_t threads = (((size_t)1 << logn) >> K) * B;
@@ -170,19 +355,25 @@ static void launch_dit(Fr *data, size_t B, int logn, int logS, const Fr *tw, con
     hipLaunchKernelGGL(k_ntt_dit<K>, dim3(ceil_div(threads, 256)), dim3(256), 0, s, data, B, logn, logS, tw, premul);
 }
 
-static constexpr int KMAX = 3;     // radix-8 (radix-16 needs 256 VGPRs -> 1 wave/SIMD or spills: measured worse)
 
+// stage schedule: as many 6-stage LDS passes as possible, then one 5- or 4-stage LDS pass, then register passes
+static int next_pass(int rem) {
+    if (rem >= 6) return 6;
+    return rem;     // 5, 4 -> LDS (3,2)/(2,2); 3, 2, 1 -> register kernels
+}
 void NttDomain::dif(Fr *data, size_t B, bool inverse, const Fr *postmul, hipStream_t s) const {
     const Fr *tw = inverse ? tw_inv.p : tw_fwd.p;
     int loglen = logn;
     while (loglen > 0) {
-        int k = loglen >= KMAX ? KMAX : loglen;
+        const int k = next_pass(loglen);
         const Fr *pm = (loglen - k == 0) ? postmul : nullptr;
         switch (k) {
-            case 1: launch_dif<1>(data, B, logn, loglen, tw, pm, s); break;
-            case 2: launch_dif<2>(data, B, logn, loglen, tw, pm, s); break;
+            case 6: launch_dif_lds<3, 3>(data, B, logn, loglen, tw, pm, s); break;
+            case 5: launch_dif_lds<3, 2>(data, B, logn, loglen, tw, pm, s); break;
+            case 4: launch_dif_lds<2, 2>(data, B, logn, loglen, tw, pm, s); break;
             case 3: launch_dif<3>(data, B, logn, loglen, tw, pm, s); break;
-            default: launch_dif<4>(data, B, logn, loglen, tw, pm, s); break;
+            case 2: launch_dif<2>(data, B, logn, loglen, tw, pm, s); break;
+            default: launch_dif<1>(data, B, logn, loglen, tw, pm, s); break;
         }
         loglen -= k;
     }
@@ -192,13 +383,15 @@ void NttDomain::dit(Fr *data, size_t B, bool inverse, const Fr *premul, hipStrea
     const Fr *tw = inverse ? tw_inv.p : tw_fwd.p;
     int logS = 0;
     while (logS < logn) {
-        int k = (logn - logS) >= KMAX ? KMAX : (logn - logS);
+        const int k = next_pass(logn - logS);
         const Fr *pm = (logS == 0) ? premul : nullptr;
         switch (k) {
-            case 1: launch_dit<1>(data, B, logn, logS, tw, pm, s); break;
-            case 2: launch_dit<2>(data, B, logn, logS, tw, pm, s); break;
+            case 6: launch_dit_lds<3, 3>(data, B, logn, logS, tw, pm, s); break;
+            case 5: launch_dit_lds<3, 2>(data, B, logn, logS, tw, pm, s); break;
+            case 4: launch_dit_lds<2, 2>(data, B, logn, logS, tw, pm, s); break;
             case 3: launch_dit<3>(data, B, logn, logS, tw, pm, s); break;
-            default: launch_dit<4>(data, B, logn, logS, tw, pm, s); break;
+            case 2: launch_dit<2>(data, B, logn, logS, tw, pm, s); break;
+            default: launch_dit<1>(data, B, logn, logS, tw, pm, s); break;
         }
         logS += k;
     }
