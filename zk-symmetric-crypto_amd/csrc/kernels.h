@@ -58,6 +58,8 @@ struct MsmScratch {
     DevBuf<uint32_t> gen_count, gen_idx;   // compact per-instance lists of the scalars that are neither 0 nor +-1
     DevBuf<Fr> gen_val;
     void reserve_compact(size_t B, size_t max_sparse_n);
+    DevBuf<uint32_t> entries2, coarse_base;   // dense two-level sort: partitioned entries, per-instance coarse bin offsets
+    void reserve_dense(size_t B, size_t max_dense_entries);
 };
 
 // out[b] (+)= sum_j scalars[row_j][b] * P_j for b in [0,B).  scalars: [rows][B] Fr Montgomery.

@@ -73,6 +73,10 @@ static void bases_build(MsmBases<F> &mb, const Affine<F> *d_points, size_t n, co
 void msm_bases_build(MsmBasesG1 &mb, const G1Affine *p, size_t n, const uint32_t *rows, int c, hipStream_t s) { bases_build<Fp>(mb, p, n, rows, c, s); }
 void msm_bases_build(MsmBasesG2 &mb, const G2Affine *p, size_t n, const uint32_t *rows, int c, hipStream_t s) { bases_build<Fp2>(mb, p, n, rows, c, s); }
 
+void MsmScratch::reserve_dense(size_t B_, size_t max_dense_entries) {
+    entries2.ensure(B_ * max_dense_entries + 1);
+    coarse_base.ensure(B_ * 257);
+}
 void MsmScratch::reserve_compact(size_t B_, size_t max_sparse_n) {
     gen_count.ensure(B_ + 1);
     gen_idx.ensure(B_ * max_sparse_n + 1);
@@ -183,6 +187,142 @@ __global__ __launch_bounds__(SORT_THREADS) void k_msm_sort(const Fr *__restrict_
             uint32_t pos = atomicAdd(&hist[(neg ? -d : d) - 1], 1u);
             ent[pos] = (uint32_t)((size_t)j * W + w) | (neg << 31);
         }
+    }
+}
+
+// ---- dense two-level sort (quotient MSM) -------------------------------------------------------
+// A single-level scatter writes 4-byte entries to random places of a 4 MiB region per instance: on HBM that is
+// one 64-byte transaction per entry (26 ms per batch).  Two levels keep every global write in >= 128-byte runs:
+//   k_msm_partition: one workgroup per instance; tiles of 512 scalars x W digits are counting-sorted in LDS by
+//                    COARSE bin (top bits of the bucket id) and appended to the bin's region as contiguous runs;
+//   k_msm_binsort  : one workgroup per (coarse bin, instance): counting sort of the bin (~4096 entries) by the
+//                    7 low bucket bits into the final array; all scattered writes stay inside a 16 KiB window (L2).
+// Intermediate entry: idx (21 bits) | fine bucket (7 bits) << 21 | sign << 31.
+static constexpr int FINE_BITS = 7;
+static constexpr int PART_THREADS = 512;
+static constexpr int MAX_COARSE = 256;
+
+__global__ __launch_bounds__(PART_THREADS) void k_msm_partition(const Fr *__restrict__ dense, size_t dense_stride, size_t n, int c, int W,
+                                                                uint32_t *__restrict__ coarse_base, uint32_t *__restrict__ part_entries,
+                                                                size_t max_entries) {
+    extern __shared__ uint32_t lds[];
+    const int cb = c - 1 - FINE_BITS;                 // coarse bits
+    const uint32_t nbin = 1u << cb;
+    const int nwave = PART_THREADS / 64;
+    uint32_t *wave_hist = lds;                        // [nwave][nbin]  (pass 0)
+    uint32_t *bin_base = wave_hist + nwave * MAX_COARSE;   // [nbin + 1]
+    uint32_t *bin_cursor = bin_base + MAX_COARSE + 1; // [nbin]
+    uint32_t *tile_cnt = bin_cursor + MAX_COARSE;     // [nbin]
+    uint32_t *tile_off = tile_cnt + MAX_COARSE;       // [nbin]
+    uint32_t *tile_ent = tile_off + MAX_COARSE;       // [PART_THREADS * W]
+    uint32_t *tile_dst = tile_ent + PART_THREADS * 24;
+    const size_t b = blockIdx.x;
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const Fr *sc = dense + b * dense_stride;
+    // ---- pass 0: coarse histogram (privatised per wavefront)
+    for (uint32_t i = tid; i < (uint32_t)nwave * nbin; i += PART_THREADS) wave_hist[(i / nbin) * MAX_COARSE + (i % nbin)] = 0;
+    if (tid < (int)nbin) { bin_cursor[tid] = 0; tile_cnt[tid] = 0; }
+    __syncthreads();
+    for (size_t j = tid; j < n; j += PART_THREADS) {
+        const Fr cs = sc[j].from_mont();
+        int carry = 0;
+        for (int w = 0; w < W; w++) {
+            const int d = signed_digit(cs.l, w, c, carry);
+            if (d) atomicAdd(&wave_hist[wave * MAX_COARSE + ((uint32_t)((d < 0 ? -d : d) - 1) >> FINE_BITS)], 1u);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (uint32_t k = 0; k < nbin; k++) {
+            uint32_t t = 0;
+            for (int wv = 0; wv < nwave; wv++) t += wave_hist[wv * MAX_COARSE + k];
+            bin_base[k] = run;
+            run += t;
+        }
+        bin_base[nbin] = run;
+    }
+    __syncthreads();
+    for (uint32_t k = tid; k <= nbin; k += PART_THREADS) coarse_base[b * (MAX_COARSE + 1) + k] = bin_base[k];
+    // ---- pass A: tiles of PART_THREADS scalars
+    uint32_t *out = part_entries + b * max_entries;
+    const size_t ntiles = (n + PART_THREADS - 1) / PART_THREADS;
+    for (size_t tile = 0; tile < ntiles; tile++) {
+        const size_t j = tile * PART_THREADS + tid;
+        // statically indexed per-window slots (a runtime-indexed array would live in scratch); 0xffffffff = no entry
+        uint32_t ent[24];
+        uint32_t binrank[24];
+#pragma unroll
+        for (int w = 0; w < 24; w++) binrank[w] = 0xffffffffu;
+        if (j < n) {
+            const Fr cs = sc[j].from_mont();
+            int carry = 0;
+#pragma unroll
+            for (int w = 0; w < 24; w++) {
+                if (w < W) {
+                    const int d = signed_digit(cs.l, w, c, carry);
+                    if (d) {
+                        const uint32_t neg = d < 0, bk = (uint32_t)(neg ? -d : d) - 1;
+                        const uint32_t bin = bk >> FINE_BITS;
+                        const uint32_t r = atomicAdd(&tile_cnt[bin], 1u);
+                        ent[w] = (uint32_t)(j * W + w) | ((bk & ((1u << FINE_BITS) - 1)) << 21) | (neg << 31);
+                        binrank[w] = (bin << 16) | r;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t run = 0;
+            for (uint32_t k = 0; k < nbin; k++) { tile_off[k] = run; run += tile_cnt[k]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < 24; w++) {
+            if (binrank[w] != 0xffffffffu) {
+                const uint32_t bin = binrank[w] >> 16, r = binrank[w] & 0xffff;
+                const uint32_t pos = tile_off[bin] + r;
+                tile_ent[pos] = ent[w];
+                tile_dst[pos] = bin_base[bin] + bin_cursor[bin] + r;
+            }
+        }
+        __syncthreads();
+        uint32_t total = tile_off[nbin - 1] + tile_cnt[nbin - 1];
+        for (uint32_t i = tid; i < total; i += PART_THREADS) out[tile_dst[i]] = tile_ent[i];
+        __syncthreads();
+        if (tid < (int)nbin) { bin_cursor[tid] += tile_cnt[tid]; tile_cnt[tid] = 0; }
+        __syncthreads();
+    }
+}
+
+// grid (nbin, B), 256 threads
+__global__ __launch_bounds__(256) void k_msm_binsort(const uint32_t *__restrict__ coarse_base, const uint32_t *__restrict__ part_entries,
+                                                     uint32_t *__restrict__ entries, size_t max_entries, int c,
+                                                     uint32_t *__restrict__ bucket_start) {
+    __shared__ uint32_t hist[1 << FINE_BITS];
+    __shared__ uint32_t cursor[1 << FINE_BITS];
+    const uint32_t nb = 1u << (c - 1);
+    const uint32_t bin = blockIdx.x;
+    const size_t b = blockIdx.y;
+    const int tid = threadIdx.x;
+    const uint32_t lo = coarse_base[b * (MAX_COARSE + 1) + bin], hi = coarse_base[b * (MAX_COARSE + 1) + bin + 1];
+    const uint32_t *in = part_entries + b * max_entries;
+    uint32_t *out = entries + b * max_entries;
+    uint32_t *bs = bucket_start + b * (nb + 1) + ((size_t)bin << FINE_BITS);
+    if (tid < (1 << FINE_BITS)) hist[tid] = 0;
+    __syncthreads();
+    for (uint32_t i = lo + tid; i < hi; i += 256) atomicAdd(&hist[(in[i] >> 21) & ((1u << FINE_BITS) - 1)], 1u);
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = lo;
+        for (int k = 0; k < (1 << FINE_BITS); k++) { cursor[k] = run; bs[k] = run; run += hist[k]; }
+        if (bin + 1 == gridDim.x) bs[1 << FINE_BITS] = run;          // bucket_start[nb] = total
+    }
+    __syncthreads();
+    for (uint32_t i = lo + tid; i < hi; i += 256) {
+        const uint32_t v = in[i];
+        const uint32_t pos = atomicAdd(&cursor[(v >> 21) & ((1u << FINE_BITS) - 1)], 1u);
+        out[pos] = v & 0x801fffffu;
     }
 }
 
@@ -404,8 +544,19 @@ static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, M
     if (mb.dense) {
         // scalars = instance-major [B][dense_stride] copy; no +-1 fast path (every quotient coefficient is wide)
         ZK_HIP(hipMemsetAsync(part, 0, B * stride * sizeof(XYZZ<F>), s));
-        hipLaunchKernelGGL(k_msm_sort<true>, dim3((unsigned)B), dim3(SORT_THREADS), lds, s, scalars, mb.dense_stride, (const uint32_t *)nullptr,
-                           (const uint32_t *)nullptr, (const Fr *)nullptr, n, c, W, sc.bucket_start.p, sc.entries.p, max_entries);
+        if (c - 1 > FINE_BITS && c - 1 - FINE_BITS <= 8 && W <= 24 && n * (size_t)W < (1u << 21) && sc.entries2.n >= B * max_entries + 1) {
+            static bool attr2 = false;
+            const size_t lds2 = (size_t)(PART_THREADS / 64 * MAX_COARSE + (MAX_COARSE + 1) + 3 * MAX_COARSE + 2 * PART_THREADS * 24) * sizeof(uint32_t);
+            if (!attr2) { ZK_HIP(hipFuncSetAttribute((const void *)k_msm_partition, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)); attr2 = true; }
+            sc.coarse_base.ensure(B * (MAX_COARSE + 1));
+            hipLaunchKernelGGL(k_msm_partition, dim3((unsigned)B), dim3(PART_THREADS), lds2, s, scalars, mb.dense_stride, n, c, W, sc.coarse_base.p,
+                               sc.entries2.p, max_entries);
+            hipLaunchKernelGGL(k_msm_binsort, dim3(1u << (c - 1 - FINE_BITS), (unsigned)B), dim3(256), 0, s, sc.coarse_base.p, sc.entries2.p, sc.entries.p,
+                               max_entries, c, sc.bucket_start.p);
+        } else {
+            hipLaunchKernelGGL(k_msm_sort<true>, dim3((unsigned)B), dim3(SORT_THREADS), lds, s, scalars, mb.dense_stride, (const uint32_t *)nullptr,
+                               (const uint32_t *)nullptr, (const Fr *)nullptr, n, c, W, sc.bucket_start.p, sc.entries.p, max_entries);
+        }
     } else {
         if (sc.gen_count.n < B || sc.gen_idx.n < B * n || sc.gen_val.n < B * n) throw ZkError("msm compact-list scratch too small");
         ZK_HIP(hipMemsetAsync(sc.gen_count.p, 0, B * sizeof(uint32_t), s));

@@ -326,6 +326,7 @@ void Algorithm::resident_reserve(size_t B) {
     acc(pk.B2.n, pk.B2.c, pk.B2.W);
     if (has_commit) acc(pk.ped.n, pk.ped.c, pk.ped.W);
     R.ms.reserve(B, max_entries, max_nb, max_part);
+    R.ms.reserve_dense(B, pk.Z.n * (size_t)pk.Z.W);
     R.ms.reserve_compact(B, std::max({pk.A.n, pk.B1.n, pk.K.n, pk.B2.n, has_commit ? pk.ped.n : (size_t)1}));
     {
         size_t nb1 = (size_t)1 << (std::max({pk.A.c, pk.B1.c, pk.K.c, pk.Z.c, has_commit ? pk.ped.c : 1}) - 1);
