@@ -18,6 +18,7 @@ enum SolverErr : uint32_t { SERR_NONE = 0, SERR_UNSATISFIED = 1, SERR_LOOKUP_RAN
 struct SolverLevel {
     uint32_t first = 0, count = 0;   // range in level_instr
     bool has_commit = false;         // a BSB22 hint sits in this level: commitment must be ready before launch
+    uint32_t div_first = 0, div_count = 0;   // deferred divisions of this level (records in div_list)
 };
 
 struct SolverProgram {
@@ -25,7 +26,8 @@ struct SolverProgram {
     int log_domain = 0;
     std::vector<SolverLevel> levels;
     DevBuf<uint32_t> prog, instr_off, level_instr;
-    DevBuf<Fr> coeffs, coeff_inv, lookup_tables;   // lookup_tables: [table][256]
+    DevBuf<Fr> coeffs, coeff_inv, lookup_tables, count_tables;   // lookup_tables: [table][256]
+    DevBuf<uint32_t> div_list;                      // (constraint, loc, wire, coeff) x deferred divisions, grouped by level
     size_t n_count_rows = 0, n_count_slots = 0;     // countHint scratch sizing: [slot][row][B]
     bool has_commit = false;
     uint32_t commit_wire = 0;

@@ -6,7 +6,7 @@
 //                 an instruction defines is a property of the circuit, not of the witness, so all lanes
 //                 (instances) follow the same control flow.
 //   OP_NBITS    : op, nout, out_start, linexp
-//   OP_COUNT    : op, ntab, ncol, nq, out_start, scratch_slot, linexp x (ntab*ncol), linexp x (nq*ncol)
+//   OP_COUNT    : op, ntab, ncol, nq, out_start, scratch_slot, table_off, linexp x (nq*ncol)   (table rows: constants in count_tables)
 //   OP_RANDOMIZE: op, out_wire
 //   OP_BSB22    : op, out_wire
 //   OP_LOOKUP   : op, table, nq, first_out_wire, nentries, linexp x nq
@@ -72,7 +72,10 @@ void SolverProgram::build(const R1cs &cs, hipStream_t s) {
         private_committed = ci.private_committed;
     }
     std::vector<uint32_t> prg, off(ni);
-    std::vector<uint8_t> is_commit_instr(ni, 0);
+    std::vector<Fr> count_tab;
+    std::vector<uint32_t> defer;           // deferred divisions: (level-local order) cons, loc, wire, coeff
+    std::vector<uint32_t> defer_level(ni, 0);
+    std::vector<uint8_t> is_commit_instr(ni, 0), is_div_instr(ni, 0);
     n_count_rows = 0;
     n_count_slots = 0;
     for (size_t i = 0; i < ni; i++) {
@@ -106,6 +109,7 @@ void SolverProgram::build(const R1cs &cs, hipStream_t s) {
                 prg[hdr + 2 + which] = kept;
             }
             prg[hdr + 5] = loc;
+            if (loc == 1 || loc == 2) is_div_instr[i] = 1;
             if (cs.constraint_offset[i] >= n_constraints) throw ZkError("constraint index out of range");
         } else if (kind == BP_HINT) {
             const uint32_t hid = cd[1], nin = cd[2];
@@ -154,9 +158,18 @@ void SolverProgram::build(const R1cs &cs, hipStream_t s) {
                 if (ncol == 0 || nin < 2 + ntab * ncol || (nin - 2 - ntab * ncol) % ncol) throw ZkError("countHint input shape");
                 const uint32_t nq = (nin - 2 - ntab * ncol) / ncol;
                 if (out_end - out_start != ntab) throw ZkError("countHint output count");
-                prg.insert(prg.end(), {OP_COUNT, ntab, ncol, nq, out_start, (uint32_t)n_count_slots});
+                // table rows are constants: resolve them now so that the kernel compares a query row in O(1)
+                const uint32_t table_off = (uint32_t)count_tab.size();
+                for (uint32_t k = 0; k < ntab * ncol; k++) {
+                    if (q[0] != 1 || q[2] != WIRE_CONST || q[1] >= cs.coeffs.size()) throw ZkError("countHint table rows must be constants");
+                    Fr v;
+                    memcpy(v.l, cs.coeffs[q[1]].data(), 32);
+                    count_tab.push_back(v);
+                    q += 3;
+                }
+                prg.insert(prg.end(), {OP_COUNT, ntab, ncol, nq, out_start, (uint32_t)n_count_slots, table_off});
                 n_count_slots++;
-                for (uint32_t k = 0; k < (ntab + nq) * ncol; k++) push_linexp(prg, q);
+                for (uint32_t k = 0; k < nq * ncol; k++) push_linexp(prg, q);
                 if (ntab > n_count_rows) n_count_rows = ntab;
             } else if (hid == HINT_RANDOMIZE) {
                 if (out_end - out_start != 1) throw ZkError("Randomize hint with != 1 output");
@@ -197,7 +210,16 @@ void SolverProgram::build(const R1cs &cs, hipStream_t s) {
         SolverLevel lv;
         lv.first = (uint32_t)li.size();
         lv.count = (uint32_t)l.size();
-        for (uint32_t i : l) { li.push_back(i); if (is_commit_instr[i]) lv.has_commit = true; }
+        lv.div_first = (uint32_t)(defer.size() / 4);
+        for (uint32_t i : l) {
+            li.push_back(i);
+            if (is_commit_instr[i]) lv.has_commit = true;
+            if (is_div_instr[i]) {
+                const uint32_t *rec = prg.data() + off[i];
+                defer.insert(defer.end(), {rec[1], rec[5], rec[6], rec[7]});
+            }
+        }
+        lv.div_count = (uint32_t)(defer.size() / 4) - lv.div_first;
         levels.push_back(lv);
     }
     prog.upload(prg.data(), prg.size(), s);
@@ -207,6 +229,9 @@ void SolverProgram::build(const R1cs &cs, hipStream_t s) {
     ZK_HIP(hipMemcpyAsync(coeffs.p, cs.coeffs.data(), cs.coeffs.size() * 32, hipMemcpyHostToDevice, s));
     coeff_inv.alloc(cs.coeffs.size());
     hipLaunchKernelGGL(k_coeff_inv, dim3(ceil_div(cs.coeffs.size(), 64)), dim3(64), 0, s, coeffs.p, coeff_inv.p, cs.coeffs.size());
+    count_tables.alloc(count_tab.size() ? count_tab.size() : 1);
+    if (!count_tab.empty()) ZK_HIP(hipMemcpyAsync(count_tables.p, count_tab.data(), count_tab.size() * sizeof(Fr), hipMemcpyHostToDevice, s));
+    div_list.upload(defer.data(), defer.size() ? defer.size() : 0, s);
     lookup_tables.alloc(tables.size() ? tables.size() : 1);
     if (!tables.empty()) ZK_HIP(hipMemcpyAsync(lookup_tables.p, tables.data(), tables.size() * sizeof(Fr), hipMemcpyHostToDevice, s));
     ZK_HIP(hipStreamSynchronize(s));
@@ -225,7 +250,7 @@ void SolverBuffers::reserve(const SolverProgram &p, size_t B_) {
 // ----------------------------------------------------------------------------------- kernels
 struct SolveCtx {
     const uint32_t *prog;
-    const Fr *coeffs, *coeff_inv, *tables;
+    const Fr *coeffs, *coeff_inv, *tables, *count_tables;
     Fr *wires, *a, *b, *c;
     const Fr *randomize, *challenge;
     uint32_t *err, *count_scratch;
@@ -335,12 +360,14 @@ __global__ __launch_bounds__(256) void k_solve_level(SolveCtx cx, const uint32_t
             if (loc == 3) {
                 x = mul_fast(vL, vR) - vO;
                 vO = vO + x;
-            } else if (loc == 1) {
-                if (!vR.is_zero()) { x = vO * vR.inv() - vL; vL = vL + x; }
-                else if (!vO.is_zero()) report(cx, b, SERR_UNSATISFIED, cons);
             } else {
-                if (!vL.is_zero()) { x = vO * vL.inv() - vR; vR = vR + x; }
-                else if (!vO.is_zero()) report(cx, b, SERR_UNSATISFIED, cons);
+                // unknown wire sits in L or R: x = O / R - L needs a field inversion.  Deferred to k_solve_divisions,
+                // which shares ONE inversion between up to 16 such constraints of this level (Montgomery's trick);
+                // a/b/c written below carry the partial sums it needs.
+                cx.a[(size_t)cons * B + b] = vL;
+                cx.b[(size_t)cons * B + b] = vR;
+                cx.c[(size_t)cons * B + b] = vO;
+                return;
             }
             if (sc == 3) x = x.neg();
             else if (sc != 1) x = x * cx.coeff_inv[sc];
@@ -368,38 +395,72 @@ __global__ __launch_bounds__(256) void k_solve_level(SolveCtx cx, const uint32_t
             cx.wires[(size_t)(w0 + q) * B + b] = cx.tables[(size_t)tb * nent + idx];
         }
     } else if (op == OP_COUNT) {
-        const uint32_t ntab = p[1], ncol = p[2], nq = p[3], out0 = p[4], slot = p[5];
-        p += 6;
+        const uint32_t ntab = p[1], ncol = p[2], nq = p[3], out0 = p[4], slot = p[5], toff = p[6];
+        p += 7;
         uint32_t *cnt = cx.count_scratch + (size_t)slot * cx.count_rows * B;
         for (uint32_t r = 0; r < ntab; r++) cnt[(size_t)r * B + b] = 0;
-        const uint32_t *tab0 = p;
-        // skip table rows (constants): remember where each row starts by re-walking on demand
-        const uint32_t *q = p;
-        for (uint32_t k = 0; k < ntab * ncol; k++) q += 1 + 2 * q[0];
+        const Fr *tab = cx.count_tables + toff;
         for (uint32_t j = 0; j < nq; j++) {
-            const uint32_t *qq = q;
-            Fr key = eval_linexp(cx, qq, b);
-            uint32_t row;
-            bool ok = small_index(key, ntab, row);
-            if (ok) {
-                // compare the full query row with table row `row` (first column of row i is i in logderivlookup tables)
-                const uint32_t *tp = tab0;
-                for (uint32_t k = 0; k < row * ncol; k++) tp += 1 + 2 * tp[0];
-                const uint32_t *qc = q;
-                for (uint32_t col = 0; col < ncol; col++) {
-                    Fr tv = eval_linexp(cx, tp, b), qv = eval_linexp(cx, qc, b);
-                    if (tv != qv) ok = false;
-                }
+            // first column of a logderivlookup table row is the row index: O(1) candidate, then full-row compare
+            uint32_t row = 0;
+            bool ok = true;
+            for (uint32_t col = 0; col < ncol; col++) {
+                const Fr qv = eval_linexp(cx, p, b);
+                if (col == 0) ok = small_index(qv, ntab, row);
+                if (ok && tab[(size_t)row * ncol + col] != qv) ok = false;
             }
             if (ok) cnt[(size_t)row * B + b] += 1;
             else report(cx, b, SERR_COUNT_QUERY, instr);
-            for (uint32_t col = 0; col < ncol; col++) q += 1 + 2 * q[0];
         }
         for (uint32_t r = 0; r < ntab; r++) cx.wires[(size_t)(out0 + r) * B + b] = Fr::from_u32(cnt[(size_t)r * B + b]);
     } else if (op == OP_RANDOMIZE) {
         cx.wires[(size_t)p[1] * B + b] = cx.randomize[b];
     } else if (op == OP_BSB22) {
         cx.wires[(size_t)p[1] * B + b] = cx.challenge[b];
+    }
+}
+
+// Deferred divisions of one level: thread = (instance, group of up to DIV_GROUP constraints).
+// rec = (constraint, loc, wire, coeff id).  loc 1: x = c/b - a ; loc 2: x = c/a - b.
+static constexpr int DIV_GROUP = 16;
+__global__ __launch_bounds__(256) void k_solve_divisions(SolveCtx cx, const uint32_t *__restrict__ recs, uint32_t count) {
+    const size_t B = cx.B;
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t g0 = blockIdx.y * DIV_GROUP;
+    const uint32_t g1 = g0 + DIV_GROUP < count ? g0 + DIV_GROUP : count;
+    Fr pref[DIV_GROUP];
+    Fr acc = Fr::one();
+#pragma unroll
+    for (int k = 0; k < DIV_GROUP; k++) {
+        pref[k] = acc;
+        if (g0 + k < g1) {
+            const uint32_t cons = recs[4 * (g0 + k)], loc = recs[4 * (g0 + k) + 1];
+            const Fr den = loc == 1 ? cx.b[(size_t)cons * B + b] : cx.a[(size_t)cons * B + b];
+            if (!den.is_zero()) acc = acc * den;
+        }
+    }
+    Fr inv = acc.inv();
+#pragma unroll
+    for (int k = DIV_GROUP - 1; k >= 0; k--) {
+        if (g0 + k < g1) {
+            const uint32_t cons = recs[4 * (g0 + k)], loc = recs[4 * (g0 + k) + 1], sw = recs[4 * (g0 + k) + 2], sc = recs[4 * (g0 + k) + 3];
+            const size_t o = (size_t)cons * B + b;
+            const Fr va = cx.a[o], vb = cx.b[o], vc = cx.c[o];
+            const Fr den = loc == 1 ? vb : va;
+            Fr x = Fr::zero();
+            if (!den.is_zero()) {
+                const Fr di = inv * pref[k];
+                inv = inv * den;
+                if (loc == 1) { x = vc * di - va; cx.a[o] = va + x; }
+                else { x = vc * di - vb; cx.b[o] = vb + x; }
+            } else if (!vc.is_zero()) {
+                report(cx, b, SERR_UNSATISFIED, cons);
+            }
+            if (sc == 3) x = x.neg();
+            else if (sc != 1) x = x * cx.coeff_inv[sc];
+            cx.wires[(size_t)sw * B + b] = x;
+        }
     }
 }
 
@@ -423,7 +484,7 @@ void solver_begin(const SolverProgram &p, SolverBuffers &buf, hipStream_t s) {
 }
 
 void solver_run_levels(const SolverProgram &p, SolverBuffers &buf, size_t first_level, size_t last_level, hipStream_t s) {
-    SolveCtx cx{p.prog.p, p.coeffs.p, p.coeff_inv.p, p.lookup_tables.p, buf.wires.p, buf.a.p, buf.b.p, buf.c.p,
+    SolveCtx cx{p.prog.p, p.coeffs.p, p.coeff_inv.p, p.lookup_tables.p, p.count_tables.p, buf.wires.p, buf.a.p, buf.b.p, buf.c.p,
                 buf.randomize.p, buf.challenge.p, buf.err.p, buf.count_scratch.p, buf.B, p.n_count_rows};
     for (size_t l = first_level; l < last_level && l < p.levels.size(); l++) {
         const SolverLevel &lv = p.levels[l];
@@ -432,6 +493,9 @@ void solver_run_levels(const SolverProgram &p, SolverBuffers &buf, size_t first_
             const uint32_t cnt = lv.count - off < 65535 ? lv.count - off : 65535;
             hipLaunchKernelGGL(k_solve_level, dim3(ceil_div(buf.B, 256), cnt), dim3(256), 0, s, cx, p.instr_off.p, p.level_instr.p + lv.first + off, cnt);
         }
+        if (lv.div_count)
+            hipLaunchKernelGGL(k_solve_divisions, dim3(ceil_div(buf.B, 256), ceil_div(lv.div_count, DIV_GROUP)), dim3(256), 0, s, cx,
+                               p.div_list.p + 4 * (size_t)lv.div_first, lv.div_count);
     }
     ZK_HIP(hipGetLastError());
 }
