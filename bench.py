@@ -101,6 +101,18 @@ def main():
         zdur_ms = mean.get("z_segments", 0.0) or mean["msm_g1"]
         zbytes = Z_TERMS[alg] * 96 * B
         achieved = zbytes / (zdur_ms * 1e-3) / 1e9
+        # HBM traffic of that kernel from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+        # passes, same command line); only valid for the configuration it was collected on (chacha20, batch 1024)
+        traffic = None
+        try:
+            import glob
+            pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+            if pm and alg == 0 and B == 1024:
+                for k, v in json.load(open(pm[-1]))["kernels"].items():
+                    if "k_msm_accumulate<zk::Field<zk::FpParams>" in k:
+                        traffic = (v["FETCH_SIZE_KB_per_launch_max"] + v["WRITE_SIZE_KB_per_launch_max"]) * 1024.0
+        except Exception:
+            traffic = None
         out = {
             "metric": "Groth16 proofs/sec (ChaCha20 1-block, AES-256-CTR 1-block) at 1/2/4/8 GPU",
             "value": value, "unit": "proofs/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
@@ -112,10 +124,13 @@ def main():
                        "blocks_per_s": value * (2 if alg == 0 else 5)},
             "phases_ms": mean, "verified_ok": ok, "init_s": t_init,
             "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate<Fp> (bucket accumulation of the quotient MSM over G1.Z)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launch_ms": zdur_ms, "algorithmic_bytes_per_launch": zbytes,
                          "whole_path_GBps": value / world * BYTES_PER_PROOF[alg] / 1e9,
-                         "note": "integer-ALU bound (v_mad_u64_u32 chains); MFMA not applicable"},
+                         "mixed_adds_per_s": Z_TERMS[alg] * 16 * B / (zdur_ms * 1e-3), "mixed_add_peak_per_s": 10.8e9,
+                         "note": "integer-ALU bound (v_mad_u64_u32 + v_addc_co_u32 chains): the kernel runs W=16 mixed additions per term and gathers one "
+                                 "64-byte window multiple per addition (traffic = 16 x 64 B per term by design, served mostly from MALL/HBM); "
+                                 "mixed_add_peak = back-to-back G1 mixed additions measured by scripts/gpu_microbench.py; MFMA not applicable"},
         }
         if args.cpu_proofs != 0:
             # CPU baseline: the oracle (C restatement of gnark's prover), one single-threaded proof per host
