@@ -52,11 +52,13 @@ def main():
     zk.lib.ZkpSetDevice(local_rank)
     zk.lib.ZkpAllowUnpinnedKeys(1)
 
-    import helpers as H           # synthetic request generator + proving-key fixture
-    from oracle import r1cs_format as rf   # R1CS fixture loader only (xz golden file)
+    H = zk.synth                  # product-side synthetic workload generator (no oracle in the GPU leg)
     alg, B = args.alg, args.batch
-    r1cs_bytes = rf.load_r1cs_bytes(H.NAMES[alg])
-    pk_bytes = H.pk_file_bytes(alg)
+    r1cs_bytes = H.r1cs_bytes(alg)
+    # the reference's pk.* are not distributable: generate a synthetic proving key on the GPU (ZkpSetup) in gnark's format
+    t0 = time.time()
+    pk_bytes, _vk = zk.setup(r1cs_bytes, H.toxic_from_seed(1), raw=True)
+    t_setup = time.time() - t0
     t0 = time.time()
     if not zk.init_algorithm(alg, pk_bytes, r1cs_bytes):
         raise SystemExit("InitAlgorithm failed")
@@ -122,7 +124,7 @@ def main():
                                    % (H.CIPHER[alg], 2 if alg == 0 else 5, B),
                        "algorithm_id": alg, "batch_per_gpu": B, "parallelism": "dp%d (independent proofs, no collective)" % world,
                        "blocks_per_s": value * (2 if alg == 0 else 5)},
-            "phases_ms": mean, "verified_ok": ok, "init_s": t_init,
+            "phases_ms": mean, "solver_ok": ok, "init_s": t_init, "setup_s": t_setup,
             "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate<Fp> (bucket accumulation of the quotient MSM over G1.Z)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launch_ms": zdur_ms, "algorithmic_bytes_per_launch": zbytes,
@@ -136,12 +138,13 @@ def main():
             # CPU baseline: the oracle (C restatement of gnark's prover), one single-threaded proof per host
             # thread, all host threads busy at once (proof-level parallelism, the throughput-optimal CPU schedule)
             from concurrent.futures import ThreadPoolExecutor
+            import helpers as OH          # tests/helpers.py: oracle fixtures (CPU baseline leg only)
             from oracle import ref
             ncores = os.cpu_count() or 1
             nproofs = args.cpu_proofs if args.cpu_proofs > 0 else ncores
             ref.set_threads(1)
-            pk = H.oracle_pk(alg)
-            sample = [(H.oracle_witness(alg, inst)[0], inst) for inst in (insts * (nproofs // len(insts) + 1))[:nproofs]]
+            pk = OH.oracle_pk(alg)
+            sample = [(OH.oracle_witness(alg, inst)[0], inst) for inst in (insts * (nproofs // len(insts) + 1))[:nproofs]]
             t0 = time.perf_counter()
             with ThreadPoolExecutor(max_workers=ncores) as ex:
                 list(ex.map(lambda wi: pk.prove(wi[0], wi[1]["r"], wi[1]["s"], wi[1]["randomize"])["timings"], sample))

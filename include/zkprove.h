@@ -56,6 +56,11 @@ ProveReturn ProveBatch(GoSlice params);
  * the only source of non-determinism in a proof; fixing them makes proofs reproducible for parity tests. */
 ProveReturn ZkpProveDeterministic(GoSlice params, const uint8_t *r32, const uint8_t *s32, const uint8_t *randomize32);
 
+/* Groth16 key generation on the GPU (single-party; replaces gnark/keygen/keygen.go:94-132 = groth16.Setup + pk/vk WriteTo).
+ * toxic192 = alpha, beta, gamma, delta, tau, sigma as canonical little-endian 32-byte scalars.  raw != 0 writes
+ * uncompressed points (ProvingKey.WriteRawTo), else compressed (WriteTo).  Buffers are malloc'd; release with Free. */
+int ZkpSetup(GoSlice r1cs, const uint8_t *toxic192, int raw, void **pk_out, long long *pk_len, void **vk_out, long long *vk_len);
+
 /* Device-resident batch benchmark (bench.py).  inputs: [batch][n_inputs] u32 witness assignment
  * (public inputs without the constant one, then secret), r/s/randomize: [batch][32] canonical LE.
  * zkp_bench_step = one pass of the whole proving path over the resident batch; times7 (ms, HIP events):

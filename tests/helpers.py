@@ -17,47 +17,10 @@ NAMES = {0: "chacha20", 1: "aes128", 2: "aes256"}
 CIPHER = {0: "chacha20", 1: "aes-128-ctr", 2: "aes-256-ctr"}
 
 
-class SplitMix64:
-    def __init__(self, seed):
-        self.s = seed & (2 ** 64 - 1)
+import importlib as _il
 
-    def next(self):
-        self.s = (self.s + 0x9E3779B97F4A7C15) & (2 ** 64 - 1)
-        z = self.s
-        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & (2 ** 64 - 1)
-        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & (2 ** 64 - 1)
-        return z ^ (z >> 31)
-
-    def bytes(self, n):
-        out = b""
-        while len(out) < n:
-            out += self.next().to_bytes(8, "little")
-        return out[:n]
-
-    def fr(self):
-        return int.from_bytes(self.bytes(40), "little") % R
-
-
-def make_instance(alg: int, rng: SplitMix64):
-    """key, nonce, counter, plaintext, r, s, randomize -- consumed in this order"""
-    key = rng.bytes(32 if alg != 1 else 16)
-    nonce = rng.bytes(12)
-    ctr = rng.next() & 0xFFFFFFFF
-    nblk = 2 if alg == 0 else 5
-    ctr = min(ctr, 0xFFFFFFFF - nblk)
-    data = rng.bytes(128 if alg == 0 else 80)
-    r, s, rnd = rng.fr(), rng.fr(), rng.fr()
-    counters = [ctr + i for i in range(nblk)]
-    return dict(key=key, nonces=[nonce] * nblk, counters=counters, data=data, r=r, s=s, randomize=rnd)
-
-
-def request_json(alg: int, inst) -> bytes:
-    b64 = lambda b: base64.b64encode(b).decode()
-    return json.dumps({
-        "cipher": CIPHER[alg], "key": b64(inst["key"]),
-        "blocks": [{"nonce": b64(n), "counter": c, "boundary": None} for n, c in zip(inst["nonces"], inst["counters"])],
-        "input": b64(inst["data"]), "toprf": {},
-    }).encode()
+_synth = _il.import_module("zk-symmetric-crypto_amd.synth")      # product-side synthetic workload generator
+SplitMix64, make_instance, request_json = _synth.SplitMix64, _synth.make_instance, _synth.request_json
 
 
 def oracle_witness(alg: int, inst):

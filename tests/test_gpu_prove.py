@@ -126,3 +126,20 @@ def test_compressed_proving_key_loads_and_proves_identically(zk, oracle, algs):
     b = zk.prove_deterministic_raw(H.request_json(0, inst), inst["r"], inst["s"], 0)
     assert a == b and b"proof" in a
     zk.lib.ZkpReset()
+
+
+@pytest.mark.parametrize("alg", [0, 1])
+def test_gpu_setup_matches_oracle_setup(zk, oracle, alg):
+    """ZkpSetup (product key generator, gnark/keygen/keygen.go:94-132) == oracle setup for the same toxic waste,
+    byte for byte, in both gnark encodings; the verifying key has the reference's vk file size."""
+    r1cs = rf.load_r1cs_bytes(H.NAMES[alg])
+    tox = oracle.toxic_from_seed(1)
+    assert tox == zk.synth.toxic_from_seed(1)
+    pk_raw, vk = zk.setup(r1cs, tox, raw=True)
+    opk = H.oracle_pk(alg, 1)
+    assert pk_raw == gf.pk_bytes(opk, raw=True)
+    assert vk == gf.vk_bytes(gf.vk_from_pk(opk))
+    assert len(vk) == (74060 if alg == 0 else 7696)
+    if alg == 0:
+        pk_c, vk_c = zk.setup(r1cs, tox, raw=False)
+        assert vk_c == vk and pk_c == H.pk_file_bytes(0, raw=False)

@@ -195,3 +195,23 @@ def shard_range(total: int, rank: int, world: int):
     base, rem = divmod(total, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+_sig("ZkpSetup", _i32, [GoSlice, _vp, _i32, C.POINTER(C.c_void_p), C.POINTER(C.c_longlong), C.POINTER(C.c_void_p), C.POINTER(C.c_longlong)])
+
+
+def setup(r1cs: bytes, toxic, raw: bool = True):
+    """Groth16 key generation on the GPU (gnark/keygen/keygen.go:94-132) -> (pk bytes, vk bytes) in gnark's formats."""
+    s, keep = _slice(r1cs)
+    tox = _np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in toxic), _np.uint8).copy()
+    pk, vk = C.c_void_p(), C.c_void_p()
+    npk, nvk = C.c_longlong(0), C.c_longlong(0)
+    if lib.ZkpSetup(s, tox.ctypes.data, int(raw), C.byref(pk), C.byref(npk), C.byref(vk), C.byref(nvk)) != 0:
+        raise RuntimeError("ZkpSetup failed")
+    out = (C.string_at(pk.value, npk.value), C.string_at(vk.value, nvk.value))
+    lib.Free(pk)
+    lib.Free(vk)
+    return out
+
+
+from . import synth  # noqa: E402  (synthetic workload generator used by bench.py / tests)

@@ -1,5 +1,6 @@
 // Groth16 batch pipeline on one MI355X (see prover.h).
 #include "prover.h"
+#include "fixedbase.cuh"
 #include <string.h>
 #include <algorithm>
 
@@ -84,17 +85,6 @@ static uint32_t bitrev32(uint32_t v, int bits) {
     return r;
 }
 }  // namespace
-
-// Fixed-base table for delta (the only base of r*delta, s*delta, -rs*delta): tab[w*255 + d-1] = d * 2^(8w) * base
-template <class F>
-__global__ __launch_bounds__(64) void k_fixed_table(const Affine<F> *__restrict__ base, Affine<F> *__restrict__ tab) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= 32 * 255) return;
-    const uint32_t w = t / 255, d = t % 255 + 1;
-    uint32_t k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    k[w >> 2] = d << ((w & 3) * 8);
-    tab[t] = scalar_mul(*base, k, 256).to_affine();
-}
 
 // ---------------------------------------------------------------------------- device state
 struct Algorithm::Resident {
@@ -212,15 +202,6 @@ __global__ __launch_bounds__(64) void k_u256_to_mont(const U256 *in, Fr *out, si
 __device__ __forceinline__ void store_fp(U256 &dst, const Fp &v) {
 #pragma unroll
     for (int k = 0; k < 8; k++) dst.l[k] = v.l[k];
-}
-template <class F>
-__device__ __forceinline__ XYZZ<F> fixed_mul(const Affine<F> *__restrict__ tab, const uint32_t *k) {
-    XYZZ<F> acc = XYZZ<F>::inf();
-    for (int w = 0; w < 32; w++) {
-        const uint32_t d = (k[w >> 2] >> ((w & 3) * 8)) & 0xff;
-        if (d) acc.madd(tab[w * 255 + d - 1]);
-    }
-    return acc;
 }
 // Stage 1 (blockIdx.y = task, lanes = instances): 0: Ar = A + alpha + r*delta   1: Bs1 = B + beta + s*delta   2: T = (-rs)*delta
 __global__ __launch_bounds__(64) void k_finalize_stage1(const G1XYZZ *__restrict__ m_ar, const G1XYZZ *__restrict__ m_bs1, const G1Affine *__restrict__ misc,
