@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=1024, help="proofs per GPU per step")
     ap.add_argument("--alg", type=int, default=0, help="0 chacha20 (headline), 1 aes-128-ctr, 2 aes-256-ctr")
-    ap.add_argument("--cpu-proofs", type=int, default=-1, help="size of the cpu_baseline sample (0 = skip, -1 = one per host thread)")
+    ap.add_argument("--cpu-proofs", type=int, default=-1, help="cpu_baseline sample: proofs per worker process (0 = skip, -1 = default 2)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -135,23 +135,17 @@ def main():
                                  "mixed_add_peak = back-to-back G1 mixed additions measured by scripts/gpu_microbench.py; MFMA not applicable"},
         }
         if args.cpu_proofs != 0:
-            # CPU baseline: the oracle (C restatement of gnark's prover), one single-threaded proof per host
-            # thread, all host threads busy at once (proof-level parallelism, the throughput-optimal CPU schedule)
-            from concurrent.futures import ThreadPoolExecutor
-            import helpers as OH          # tests/helpers.py: oracle fixtures (CPU baseline leg only)
-            from oracle import ref
-            ncores = os.cpu_count() or 1
-            nproofs = args.cpu_proofs if args.cpu_proofs > 0 else ncores
-            ref.set_threads(1)
-            pk = OH.oracle_pk(alg)
-            sample = [(OH.oracle_witness(alg, inst)[0], inst) for inst in (insts * (nproofs // len(insts) + 1))[:nproofs]]
-            t0 = time.perf_counter()
-            with ThreadPoolExecutor(max_workers=ncores) as ex:
-                list(ex.map(lambda wi: pk.prove(wi[0], wi[1]["r"], wi[1]["s"], wi[1]["randomize"])["timings"], sample))
-            tc = time.perf_counter() - t0
-            out["cpu_baseline"] = {"value": nproofs / tc, "unit": "proofs/s", "cores": min(ncores, nproofs), "kind": "port",
-                                   "sample": "%d proofs of the same synthetic batch in %.1f s, oracle/liboracle.so (C restatement of gnark's prover), one single-threaded proof per host thread, %d concurrent"
-                                             % (nproofs, tc, min(ncores, nproofs))}
+            # CPU baseline: scripts/cpu_baseline.py in its own interpreter (no GPU runtime): one single-threaded oracle
+            # prover process per worker, forked after key generation; best of {cores/2, cores} workers
+            import subprocess
+            per = args.cpu_proofs if args.cpu_proofs > 0 else 2
+            try:
+                res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "cpu_baseline.py"), str(alg), str(per)],
+                                     capture_output=True, text=True, timeout=900)
+                line = [l for l in res.stdout.splitlines() if l.startswith("{")]
+                out["cpu_baseline"] = json.loads(line[-1]) if line else {"error": (res.stderr or "no output")[-400:]}
+            except Exception as e:          # the baseline must never take the GPU result down with it
+                out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
