@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=1024, help="proofs per GPU per step")
     ap.add_argument("--alg", type=int, default=0, help="0 chacha20 (headline), 1 aes-128-ctr, 2 aes-256-ctr")
-    ap.add_argument("--cpu-proofs", type=int, default=-1, help="cpu_baseline sample: proofs per worker process (0 = skip, -1 = default 2)")
+    ap.add_argument("--cpu-proofs", type=int, default=-1, help="cpu_baseline sample: proofs per worker process (0 = skip, -1 = default 8)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -138,7 +138,7 @@ def main():
             # CPU baseline: scripts/cpu_baseline.py in its own interpreter (no GPU runtime): one single-threaded oracle
             # prover process per worker, forked after key generation; best of {cores/2, cores} workers
             import subprocess
-            per = args.cpu_proofs if args.cpu_proofs > 0 else 2
+            per = args.cpu_proofs if args.cpu_proofs > 0 else 8
             try:
                 res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "cpu_baseline.py"), str(alg), str(per)],
                                      capture_output=True, text=True, timeout=900)

@@ -33,7 +33,14 @@ def main():
     alg = int(sys.argv[1])
     per = int(sys.argv[2])
     ncpu = os.cpu_count() or 1
-    workers_list = [int(x) for x in sys.argv[3:]] or sorted({max(1, ncpu // 2), ncpu})
+    quota = ncpu                 # the container may be limited by a cgroup CPU quota (the GPU boxes: 16 of 256 threads)
+    try:
+        q, per_us = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, min(ncpu, int(round(int(q) / int(per_us)))))
+    except Exception:
+        pass
+    workers_list = [int(x) for x in sys.argv[3:]] or sorted({quota, min(ncpu, quota + quota // 2)})
     import helpers as H
     from oracle import ref
     ref.set_threads(1)
@@ -49,9 +56,9 @@ def main():
             t0 = time.perf_counter()
             done = sum(pool.map(_work, [(i, per) for i in range(workers)], chunksize=1))
             dt = time.perf_counter() - t0
-        res = {"value": done / dt, "unit": "proofs/s", "cores": workers, "kind": "port",
+        res = {"value": done / dt, "unit": "proofs/s", "cores": min(workers, quota), "kind": "port",
                "sample": "%d proofs (%d per worker) of the bench's synthetic batch in %.1f s; oracle/liboracle.so (C restatement of gnark's Groth16 "
-                         "prover), one single-threaded prover process per worker, %d workers on %d host threads" % (done, per, dt, workers, ncpu)}
+                         "prover), one single-threaded prover process per worker, %d workers, cgroup CPU quota %d of %d host threads" % (done, per, dt, workers, quota, ncpu)}
         if best is None or res["value"] > best["value"]:
             best = res
     print(json.dumps(best), flush=True)
