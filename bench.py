@@ -134,7 +134,7 @@ def main():
                                  "64-byte window multiple per addition (traffic = 16 x 64 B per term by design, served mostly from MALL/HBM); "
                                  "mixed_add_peak = back-to-back G1 mixed additions measured by scripts/gpu_microbench.py; MFMA not applicable"},
         }
-        if args.cpu_proofs != 0:
+        if args.cpu_proofs != 0 and world == 1:
             # CPU baseline: scripts/cpu_baseline.py in its own interpreter (no GPU runtime): one single-threaded oracle
             # prover process per worker, forked after key generation; best of {cores/2, cores} workers
             import subprocess
