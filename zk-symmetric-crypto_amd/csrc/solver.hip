@@ -325,6 +325,37 @@ __device__ __forceinline__ Fr eval_linexp(const SolveCtx &cx, const uint32_t *&p
     uint32_t n = *p++;
     return eval_terms(cx, p, n, b);
 }
+// Cooperative evaluation of a long linear expression by the SL "slices" of a workgroup (threadIdx.y): the add32 /
+// FromBinary constraints have ~100 terms and, evaluated by one lane, set the latency of every dependency level.
+// Must be called by all threads of the workgroup (n and p are workgroup-uniform).  Result valid in slice 0.
+static constexpr int SL = 4;
+static constexpr int COOP_MIN_TERMS = 16;
+__device__ __forceinline__ Fr eval_terms_coop(const SolveCtx &cx, const uint32_t *&p, uint32_t n, size_t b, Fr *red) {
+    const int slice = threadIdx.y, lane = threadIdx.x;
+    if (n < COOP_MIN_TERMS) {
+        if (slice == 0) return eval_terms(cx, p, n, b);
+        p += 2 * n;
+        return Fr::zero();
+    }
+    const uint32_t chunk = (n + SL - 1) / SL;
+    const uint32_t lo = slice * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    const uint32_t *q = p + 2 * lo;
+    Fr part = lo < hi ? eval_terms(cx, q, hi - lo, b) : Fr::zero();
+    p += 2 * n;
+    red[slice * 64 + lane] = part;
+    __syncthreads();
+    Fr acc = Fr::zero();
+    if (slice == 0) {
+#pragma unroll
+        for (int k = 0; k < SL; k++) acc = acc + red[k * 64 + lane];
+    }
+    __syncthreads();
+    return acc;
+}
+__device__ __forceinline__ Fr eval_linexp_coop(const SolveCtx &cx, const uint32_t *&p, size_t b, Fr *red) {
+    uint32_t n = *p++;
+    return eval_terms_coop(cx, p, n, b, red);
+}
 __device__ __forceinline__ void report(const SolveCtx &cx, size_t b, uint32_t code, uint32_t detail) {
     atomicCAS(&cx.err[b], 0u, code | (detail << 8));
 }
@@ -339,20 +370,26 @@ __device__ __forceinline__ bool small_index(const Fr &v_mont, uint32_t bound, ui
 
 __global__ __launch_bounds__(256) void k_solve_level(SolveCtx cx, const uint32_t *__restrict__ instr_off, const uint32_t *__restrict__ level_instr,
                                                      uint32_t count) {
-    // grid = (ceil(B / 256), instructions of the level): the instruction is uniform per workgroup, so the program
-    // words are scalar loads and all control flow on them is wave-uniform
+    // grid = (ceil(B / 64), instructions of the level), block = (64 instances, SL slices): the instruction is uniform per
+    // workgroup, so the program words are scalar loads and all control flow on them is wave-uniform; the slices share
+    // the evaluation of long linear expressions, slice 0 finishes the instruction
+    __shared__ Fr red[SL * 64];
     const size_t B = cx.B;
-    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B || blockIdx.y >= count) return;
+    const size_t b_raw = (size_t)blockIdx.x * 64 + threadIdx.x;
+    const bool live = b_raw < B;
+    const size_t b = live ? b_raw : B - 1;            // dead lanes shadow the last instance (no early exit before barriers)
+    const bool lead = threadIdx.y == 0 && live;
+    if (blockIdx.y >= count) return;
     const uint32_t instr = level_instr[blockIdx.y];
     const uint32_t *p = cx.prog + instr_off[instr];
     const uint32_t op = p[0];
     if (op == OP_R1C) {
         const uint32_t cons = p[1], nL = p[2], nR = p[3], nO = p[4], loc = p[5], sw = p[6], sc = p[7];
         p += 8;
-        Fr vL = eval_terms(cx, p, nL, b);
-        Fr vR = eval_terms(cx, p, nR, b);
-        Fr vO = eval_terms(cx, p, nO, b);
+        Fr vL = eval_terms_coop(cx, p, nL, b, red);
+        Fr vR = eval_terms_coop(cx, p, nR, b, red);
+        Fr vO = eval_terms_coop(cx, p, nO, b, red);
+        if (!lead) return;
         if (loc == 0) {
             if (mul_fast(vL, vR) != vO) report(cx, b, SERR_UNSATISFIED, cons);
         } else {
@@ -379,12 +416,16 @@ __global__ __launch_bounds__(256) void k_solve_level(SolveCtx cx, const uint32_t
     } else if (op == OP_NBITS) {
         const uint32_t nout = p[1], out0 = p[2];
         p += 3;
-        Fr v = eval_linexp(cx, p, b).from_mont();
+        Fr v = eval_linexp_coop(cx, p, b, red);
+        if (!lead) return;
+        v = v.from_mont();
         const Fr one = Fr::one(), zero = Fr::zero();
         for (uint32_t k = 0; k < nout; k++) {
             const bool bit = k < 256 && ((v.l[k >> 5] >> (k & 31)) & 1);
             cx.wires[(size_t)(out0 + k) * B + b] = bit ? one : zero;
         }
+    } else if (!lead) {
+        return;                                   // the remaining ops have short expressions: slice 0 alone
     } else if (op == OP_LOOKUP) {
         const uint32_t tb = p[1], nq = p[2], w0 = p[3], nent = p[4];
         p += 5;
@@ -491,7 +532,7 @@ void solver_run_levels(const SolverProgram &p, SolverBuffers &buf, size_t first_
         if (!lv.count) continue;
         for (uint32_t off = 0; off < lv.count; off += 65535) {       // grid.y limit
             const uint32_t cnt = lv.count - off < 65535 ? lv.count - off : 65535;
-            hipLaunchKernelGGL(k_solve_level, dim3(ceil_div(buf.B, 256), cnt), dim3(256), 0, s, cx, p.instr_off.p, p.level_instr.p + lv.first + off, cnt);
+            hipLaunchKernelGGL(k_solve_level, dim3(ceil_div(buf.B, 64), cnt), dim3(64, SL), 0, s, cx, p.instr_off.p, p.level_instr.p + lv.first + off, cnt);
         }
         if (lv.div_count)
             hipLaunchKernelGGL(k_solve_divisions, dim3(ceil_div(buf.B, 256), ceil_div(lv.div_count, DIV_GROUP)), dim3(256), 0, s, cx,
