@@ -70,6 +70,9 @@ int ZkpSetup(GoSlice r1cs, const uint8_t *toxic192, int raw, void **pk_out, long
 long zkp_n_inputs(int algorithmID);
 int zkp_bench_upload(int algorithmID, long batch, const uint32_t *inputs, const uint8_t *r, const uint8_t *s, const uint8_t *randomize);
 int zkp_bench_step(int algorithmID, float *times7);
+/* nsteps passes back to back; the witness solve of pass k+1 runs on a second stream under the NTT + MSM stage of pass k.
+ * times8: phase times of the last pass, [6] = whole call / nsteps */
+int zkp_bench_steps(int algorithmID, int nsteps, float *times8);
 int zkp_bench_fetch(int algorithmID, uint8_t *proofs, uint32_t *errs);
 /* after a step: copy out the solved wire vectors [batch][n_wires][32] and quotient coefficients
  * [batch][N][32] (canonical LE, natural order) -- parity tests only */

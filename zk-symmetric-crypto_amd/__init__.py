@@ -79,6 +79,7 @@ _sig("zkp_n_inputs", _i64, [_i32])
 _sig("zkp_bench_upload", _i32, [_i32, _i64, _vp, _vp, _vp, _vp])
 _sig("zkp_bench_step", _i32, [_i32, _vp])
 _sig("zkp_bench_fetch", _i32, [_i32, _vp, _vp])
+_sig("zkp_bench_steps", _i32, [_i32, _i32, _vp])
 _sig("zkp_debug_fetch", _i32, [_i32, _vp, _vp])
 _sig("zkp_request_witness", _i32, [GoSlice, _vp, _i64, _vp, _i64, C.POINTER(C.c_long), C.POINTER(C.c_long)])
 _sig("zkp_last_panic", C.c_char_p, [])
@@ -166,6 +167,14 @@ class ResidentBatch:
         t = _np.zeros(8, _np.float32)
         if lib.zkp_bench_step(self.alg, t.ctypes.data) != 0:
             raise RuntimeError("zkp_bench_step failed")
+        return dict(zip(("solve", "commit", "ntt", "msm_g1", "msm_g2", "finalize", "total", "z_segments"), [float(x) for x in t]))
+
+    def steps(self, n: int):
+        """n passes back to back, solve(k+1) overlapped with NTT+MSM(k); returns phase times of the last pass
+        ('total' = whole call / n)"""
+        t = _np.zeros(8, _np.float32)
+        if lib.zkp_bench_steps(self.alg, int(n), t.ctypes.data) != 0:
+            raise RuntimeError("zkp_bench_steps failed")
         return dict(zip(("solve", "commit", "ntt", "msm_g1", "msm_g2", "finalize", "total", "z_segments"), [float(x) for x in t]))
 
     def fetch(self):

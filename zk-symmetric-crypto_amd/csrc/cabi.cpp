@@ -396,6 +396,16 @@ int zkp_bench_step(int id, float *times7) {
     return 0;
     CABI_CATCH
 }
+int zkp_bench_steps(int id, int nsteps, float *times8) {
+    CABI_TRY
+    Algorithm *a = (id >= 0 && id < 3) ? get_alg(id) : nullptr;
+    if (!a || !a->res) throw ZkError("algorithm not initialised / nothing uploaded");
+    PhaseTimes t;
+    a->resident_prove_pipelined(nsteps, &t);
+    if (times8) { times8[0] = t.solve; times8[1] = t.commit; times8[2] = t.ntt; times8[3] = t.msm_g1; times8[4] = t.msm_g2; times8[5] = t.finalize; times8[6] = t.total; times8[7] = t.z_segments; }
+    return 0;
+    CABI_CATCH
+}
 int zkp_bench_fetch(int id, uint8_t *proofs, uint32_t *errs) {
     CABI_TRY
     Algorithm *a = (id >= 0 && id < 3) ? get_alg(id) : nullptr;

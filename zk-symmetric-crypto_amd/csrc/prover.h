@@ -54,10 +54,14 @@ class Algorithm {
 
     // device-resident variant for the benchmark: inputs already in HBM as [n_inputs][B] (see bench.py)
     struct Resident;
+    void enqueue_solve(struct SolveSet &S, MsmScratch &commit_scratch, hipStream_t st);
+    void enqueue_main(struct SolveSet &S, hipStream_t st);
+    void collect_times(struct SolveSet &S, PhaseTimes *times);
     std::unique_ptr<Resident> res;
     void resident_reserve(size_t B);
     void resident_upload(size_t B, const uint32_t *inputs_rowmajor_instance, const U256 *r, const U256 *s, const U256 *randomize);
-    void resident_prove(PhaseTimes *times);                  // timed region of bench.py
+    void resident_prove(PhaseTimes *times);                  // one batch, one stream
+    void resident_prove_pipelined(int nsteps, PhaseTimes *times);   // timed region of bench.py: solve(k+1) under NTT+MSM(k)
     void resident_download(ProofPoints *out, uint32_t *errs);
     void debug_fetch(uint8_t *wires_out, uint8_t *h_out);   // parity tests
 

@@ -87,27 +87,50 @@ static uint32_t bitrev32(uint32_t v, int bits) {
 }  // namespace
 
 // ---------------------------------------------------------------------------- device state
-struct Algorithm::Resident {
-    size_t B = 0, cap = 0;
+// Everything one batch's SOLVE stage writes and its MSM/NTT stage reads; two of them allow the (latency-bound) solver
+// of batch k+1 to run on a second stream under the (ALU-bound) NTT + MSM stage of batch k.
+struct SolveSet {
     SolverBuffers sb;
-    MsmScratch ms;
-    DevBuf<G1XYZZ> m_ar, m_bs1, m_k, m_z, m_com, m_pok;
-    DevBuf<G2XYZZ> m_bs2;
-    DevBuf<U256> r, s, rnd, chal;
-    DevBuf<G1Affine> com_aff, pok_aff, ar_aff, bs1_aff;
-    DevBuf<G1XYZZ> f_t, f_u, f_v;
-    DevBuf<ProofPoints> out;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[10] = {};
+    DevBuf<G1XYZZ> m_com, m_pok;
+    DevBuf<G1Affine> com_aff, pok_aff;
+    DevBuf<U256> chal;
     std::vector<G1Affine> h_com;
     std::vector<U256> h_chal;
+    hipEvent_t solved = nullptr, consumed = nullptr, t0 = nullptr, t1 = nullptr, t2 = nullptr, t3 = nullptr;
+    bool ready = false;
+    void reserve(const SolverProgram &prog, size_t B) {
+        sb.reserve(prog, B);
+        m_com.ensure(B); m_pok.ensure(B); com_aff.ensure(B); pok_aff.ensure(B); chal.ensure(B);
+        h_com.resize(B); h_chal.resize(B);
+        if (!solved) {
+            ZK_HIP(hipEventCreate(&solved)); ZK_HIP(hipEventCreate(&consumed));
+            ZK_HIP(hipEventCreate(&t0)); ZK_HIP(hipEventCreate(&t1)); ZK_HIP(hipEventCreate(&t2)); ZK_HIP(hipEventCreate(&t3));
+        }
+        ready = true;
+    }
+};
+
+struct Algorithm::Resident {
+    size_t B = 0, cap = 0;
+    SolveSet set[2];
+    MsmScratch ms, ms2;             // ms2: the commitment MSMs of the solve stage when it runs on the second stream
+    DevBuf<G1XYZZ> m_ar, m_bs1, m_k, m_z;
+    DevBuf<G2XYZZ> m_bs2;
+    DevBuf<U256> r, s, rnd;
+    DevBuf<G1Affine> ar_aff, bs1_aff;
+    DevBuf<G1XYZZ> f_t, f_u, f_v;
+    DevBuf<ProofPoints> out;
+    hipStream_t stream = nullptr, stream2 = nullptr;
+    hipEvent_t ev[10] = {};
 };
 
 Algorithm::Algorithm() {}
 Algorithm::~Algorithm() {
     if (res) {
         for (auto &e : res->ev) if (e) (void)hipEventDestroy(e);
+        for (auto &st : res->set) for (hipEvent_t e : {st.solved, st.consumed, st.t0, st.t1, st.t2, st.t3}) if (e) (void)hipEventDestroy(e);
         if (res->stream) (void)hipStreamDestroy(res->stream);
+        if (res->stream2) (void)hipStreamDestroy(res->stream2);
     }
 }
 
@@ -290,13 +313,15 @@ void Algorithm::resident_reserve(size_t B) {
     if (!res) {
         res.reset(new Resident());
         ZK_HIP(hipStreamCreate(&res->stream));
+        ZK_HIP(hipStreamCreate(&res->stream2));
         for (auto &e : res->ev) ZK_HIP(hipEventCreate(&e));
     }
     Resident &R = *res;
     R.B = B;
-    if (B <= R.cap) { R.sb.B = B; R.ms.B = B; return; }
+    if (B <= R.cap) { for (auto &st : R.set) st.sb.B = B; R.ms.B = B; R.ms2.B = B; return; }
     R.cap = B;
-    R.sb.reserve(prog, B);
+    R.set[0].reserve(prog, B);
+    if (R.set[1].ready) R.set[1].reserve(prog, B);
     size_t max_entries = 0, max_nb = 0, max_part = 0;
     auto acc = [&](size_t n, int c, int W) {
         max_entries = std::max(max_entries, n * (size_t)W);
@@ -313,11 +338,10 @@ void Algorithm::resident_reserve(size_t B) {
         size_t nb1 = (size_t)1 << (std::max({pk.A.c, pk.B1.c, pk.K.c, pk.Z.c, has_commit ? pk.ped.c : 1}) - 1);
         R.ms.reserve_sums(B, nb1, (size_t)1 << (pk.B2.c - 1));
     }
-    R.m_ar.alloc(B); R.m_bs1.alloc(B); R.m_k.alloc(B); R.m_z.alloc(B); R.m_com.alloc(B); R.m_pok.alloc(B); R.m_bs2.alloc(B);
-    R.r.alloc(B); R.s.alloc(B); R.rnd.alloc(B); R.chal.alloc(B);
-    R.com_aff.alloc(B); R.pok_aff.alloc(B); R.out.alloc(B);
+    R.m_ar.alloc(B); R.m_bs1.alloc(B); R.m_k.alloc(B); R.m_z.alloc(B); R.m_bs2.alloc(B);
+    R.r.alloc(B); R.s.alloc(B); R.rnd.alloc(B);
+    R.out.alloc(B);
     R.ar_aff.alloc(B); R.bs1_aff.alloc(B); R.f_t.alloc(B); R.f_u.alloc(B); R.f_v.alloc(B);
-    R.h_com.resize(B); R.h_chal.resize(B);
 }
 
 void Algorithm::resident_upload(size_t B, const uint32_t *inputs, const U256 *r, const U256 *s, const U256 *randomize) {
@@ -327,7 +351,8 @@ void Algorithm::resident_upload(size_t B, const uint32_t *inputs, const U256 *r,
     std::vector<uint32_t> tr(ni * B);
     for (size_t b = 0; b < B; b++)
         for (size_t i = 0; i < ni; i++) tr[i * B + b] = inputs[b * ni + i];
-    ZK_HIP(hipMemcpyAsync(R.sb.inputs.p, tr.data(), tr.size() * 4, hipMemcpyHostToDevice, R.stream));
+    ZK_HIP(hipMemcpyAsync(R.set[0].sb.inputs.p, tr.data(), tr.size() * 4, hipMemcpyHostToDevice, R.stream));
+    if (R.set[1].ready) ZK_HIP(hipMemcpyAsync(R.set[1].sb.inputs.p, tr.data(), tr.size() * 4, hipMemcpyHostToDevice, R.stream));
     ZK_HIP(hipMemcpyAsync(R.r.p, r, B * sizeof(U256), hipMemcpyHostToDevice, R.stream));
     ZK_HIP(hipMemcpyAsync(R.s.p, s, B * sizeof(U256), hipMemcpyHostToDevice, R.stream));
     if (randomize) ZK_HIP(hipMemcpyAsync(R.rnd.p, randomize, B * sizeof(U256), hipMemcpyHostToDevice, R.stream));
@@ -335,74 +360,136 @@ void Algorithm::resident_upload(size_t B, const uint32_t *inputs, const U256 *r,
     ZK_HIP(hipStreamSynchronize(R.stream));
 }
 
-void Algorithm::resident_prove(PhaseTimes *times) {
+// SOLVE stage of one batch (witness solve incl. the BSB22 commitment round trip) on stream st.  Events t0..t3 of the set
+// bracket: [t0 levels-before-commit t1 commitment t2 remaining-levels t3].
+void Algorithm::enqueue_solve(SolveSet &S, MsmScratch &commit_scratch, hipStream_t st) {
     Resident &R = *res;
     const size_t B = R.B;
-    hipStream_t st = R.stream;
-    ZK_HIP(hipEventRecord(R.ev[0], st));
-    hipLaunchKernelGGL(k_u256_to_mont, dim3(ceil_div(B, 64)), dim3(64), 0, st, R.rnd.p, R.sb.randomize.p, B);
-    solver_begin(prog, R.sb, st);
+    ZK_HIP(hipEventRecord(S.t0, st));
+    hipLaunchKernelGGL(k_u256_to_mont, dim3(ceil_div(B, 64)), dim3(64), 0, st, R.rnd.p, S.sb.randomize.p, B);
+    solver_begin(prog, S.sb, st);
     if (has_commit) {
-        solver_run_levels(prog, R.sb, 0, commit_level, st);
-        ZK_HIP(hipEventRecord(R.ev[1], st));
+        solver_run_levels(prog, S.sb, 0, commit_level, st);
+        ZK_HIP(hipEventRecord(S.t1, st));
         // BSB22 commitment: C = sum v_i * Basis_i ; challenge = H2F(C.Marshal(), "bsb22-commitment") ; PoK = sum v_i * BasisExpSigma_i
-        msm_batch(pk.ped, R.sb.wires.p, B, R.ms, R.m_com.p, st);
-        msm_batch(pk.ped_sigma, R.sb.wires.p, B, R.ms, R.m_pok.p, st);
-        g1_to_affine_canonical(R.m_com.p, R.com_aff.p, B, st);
-        g1_to_affine_canonical(R.m_pok.p, R.pok_aff.p, B, st);
-        ZK_HIP(hipMemcpyAsync(R.h_com.data(), R.com_aff.p, B * sizeof(G1Affine), hipMemcpyDeviceToHost, st));
+        msm_batch(pk.ped, S.sb.wires.p, B, commit_scratch, S.m_com.p, st);
+        msm_batch(pk.ped_sigma, S.sb.wires.p, B, commit_scratch, S.m_pok.p, st);
+        g1_to_affine_canonical(S.m_com.p, S.com_aff.p, B, st);
+        g1_to_affine_canonical(S.m_pok.p, S.pok_aff.p, B, st);
+        ZK_HIP(hipMemcpyAsync(S.h_com.data(), S.com_aff.p, B * sizeof(G1Affine), hipMemcpyDeviceToHost, st));
         ZK_HIP(hipStreamSynchronize(st));
         for (size_t b = 0; b < B; b++) {
             uint8_t ser[64];
             U256 x, y;
-            memcpy(x.l, R.h_com[b].x.l, 32); memcpy(y.l, R.h_com[b].y.l, 32);
+            memcpy(x.l, S.h_com[b].x.l, 32); memcpy(y.l, S.h_com[b].y.l, 32);
             u256_to_be(x, ser); u256_to_be(y, ser + 32);
-            R.h_chal[b] = hash_to_fr(ser, 64, "bsb22-commitment");
+            S.h_chal[b] = hash_to_fr(ser, 64, "bsb22-commitment");
         }
-        ZK_HIP(hipMemcpyAsync(R.chal.p, R.h_chal.data(), B * sizeof(U256), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_u256_to_mont, dim3(ceil_div(B, 64)), dim3(64), 0, st, R.chal.p, R.sb.challenge.p, B);
-        ZK_HIP(hipEventRecord(R.ev[2], st));
-        solver_run_levels(prog, R.sb, commit_level, prog.levels.size(), st);
+        ZK_HIP(hipMemcpyAsync(S.chal.p, S.h_chal.data(), B * sizeof(U256), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_u256_to_mont, dim3(ceil_div(B, 64)), dim3(64), 0, st, S.chal.p, S.sb.challenge.p, B);
+        ZK_HIP(hipEventRecord(S.t2, st));
+        solver_run_levels(prog, S.sb, commit_level, prog.levels.size(), st);
     } else {
-        ZK_HIP(hipEventRecord(R.ev[1], st));
-        ZK_HIP(hipEventRecord(R.ev[2], st));
-        solver_run_levels(prog, R.sb, 0, prog.levels.size(), st);
+        ZK_HIP(hipEventRecord(S.t1, st));
+        ZK_HIP(hipEventRecord(S.t2, st));
+        solver_run_levels(prog, S.sb, 0, prog.levels.size(), st);
     }
+    ZK_HIP(hipEventRecord(S.t3, st));
+}
+
+// NTT + MSM + tail of one solved batch on stream st.  R.ev[3..9] bracket the phases.
+void Algorithm::enqueue_main(SolveSet &S, hipStream_t st) {
+    Resident &R = *res;
+    const size_t B = R.B;
     ZK_HIP(hipEventRecord(R.ev[3], st));
-    dom.compute_h(R.sb.a.p, R.sb.b.p, R.sb.c.p, B, st);
+    dom.compute_h(S.sb.a.p, S.sb.b.p, S.sb.c.p, B, st);
     ZK_HIP(hipEventRecord(R.ev[4], st));
-    msm_batch(pk.A, R.sb.wires.p, B, R.ms, R.m_ar.p, st);
-    msm_batch(pk.B1, R.sb.wires.p, B, R.ms, R.m_bs1.p, st);
-    msm_batch(pk.K, R.sb.wires.p, B, R.ms, R.m_k.p, st);
-    fr_transpose(R.sb.a.p, R.sb.b.p, (size_t)1 << prog.log_domain, B, (size_t)1 << prog.log_domain, st);   // b is free after computeH
-    msm_batch(pk.Z, R.sb.b.p, B, R.ms, R.m_z.p, st, &R.ev[8]);
+    msm_batch(pk.A, S.sb.wires.p, B, R.ms, R.m_ar.p, st);
+    msm_batch(pk.B1, S.sb.wires.p, B, R.ms, R.m_bs1.p, st);
+    msm_batch(pk.K, S.sb.wires.p, B, R.ms, R.m_k.p, st);
+    fr_transpose(S.sb.a.p, S.sb.b.p, (size_t)1 << prog.log_domain, B, (size_t)1 << prog.log_domain, st);   // b is free after computeH
+    msm_batch(pk.Z, S.sb.b.p, B, R.ms, R.m_z.p, st, &R.ev[8]);
     ZK_HIP(hipEventRecord(R.ev[5], st));
-    msm_batch(pk.B2, R.sb.wires.p, B, R.ms, R.m_bs2.p, st);
+    msm_batch(pk.B2, S.sb.wires.p, B, R.ms, R.m_bs2.p, st);
     ZK_HIP(hipEventRecord(R.ev[6], st));
     hipLaunchKernelGGL(k_finalize_stage1, dim3(ceil_div(B, 64), 3), dim3(64), 0, st, R.m_ar.p, R.m_bs1.p, pk.g1_misc.p, pk.delta_tab.p, R.r.p, R.s.p,
                        R.ar_aff.p, R.bs1_aff.p, R.f_t.p, B);
     hipLaunchKernelGGL(k_finalize_g2, dim3(ceil_div(B, 64)), dim3(64), 0, st, R.m_bs2.p, pk.g2_misc.p, pk.delta2_tab.p, R.s.p, R.out.p, B);
     hipLaunchKernelGGL(k_finalize_stage2, dim3(ceil_div(B, 64), 2), dim3(64), 0, st, R.ar_aff.p, R.bs1_aff.p, R.r.p, R.s.p, R.f_u.p, R.f_v.p, B);
     hipLaunchKernelGGL(k_finalize_stage3, dim3(ceil_div(B, 64)), dim3(64), 0, st, R.m_k.p, R.m_z.p, R.f_t.p, R.f_u.p, R.f_v.p, R.ar_aff.p, R.out.p, B);
-    hipLaunchKernelGGL(k_store_commit, dim3(ceil_div(B, 64)), dim3(64), 0, st, R.com_aff.p, R.pok_aff.p, R.out.p, B, has_commit ? 1 : 0);
+    hipLaunchKernelGGL(k_store_commit, dim3(ceil_div(B, 64)), dim3(64), 0, st, S.com_aff.p, S.pok_aff.p, R.out.p, B, has_commit ? 1 : 0);
     ZK_HIP(hipGetLastError());
     ZK_HIP(hipEventRecord(R.ev[7], st));
+}
+
+void Algorithm::collect_times(SolveSet &S, PhaseTimes *times) {
+    Resident &R = *res;
+    float t01, t12, t23, t34, t45, t56, t67;
+    ZK_HIP(hipEventElapsedTime(&t01, S.t0, S.t1)); ZK_HIP(hipEventElapsedTime(&t12, S.t1, S.t2)); ZK_HIP(hipEventElapsedTime(&t23, S.t2, S.t3));
+    ZK_HIP(hipEventElapsedTime(&t34, R.ev[3], R.ev[4])); ZK_HIP(hipEventElapsedTime(&t45, R.ev[4], R.ev[5]));
+    ZK_HIP(hipEventElapsedTime(&t56, R.ev[5], R.ev[6])); ZK_HIP(hipEventElapsedTime(&t67, R.ev[6], R.ev[7]));
+    ZK_HIP(hipEventElapsedTime(&times->z_segments, R.ev[8], R.ev[9]));
+    times->solve = t01 + t23; times->commit = t12; times->ntt = t34; times->msm_g1 = t45; times->msm_g2 = t56; times->finalize = t67;
+}
+
+void Algorithm::resident_prove(PhaseTimes *times) {
+    Resident &R = *res;
+    hipStream_t st = R.stream;
+    enqueue_solve(R.set[0], R.ms, st);
+    enqueue_main(R.set[0], st);
     ZK_HIP(hipStreamSynchronize(st));
     if (times) {
-        float t01, t12, t23, t34, t45, t56, t67, t07;
-        ZK_HIP(hipEventElapsedTime(&t01, R.ev[0], R.ev[1])); ZK_HIP(hipEventElapsedTime(&t12, R.ev[1], R.ev[2]));
-        ZK_HIP(hipEventElapsedTime(&t23, R.ev[2], R.ev[3])); ZK_HIP(hipEventElapsedTime(&t34, R.ev[3], R.ev[4]));
-        ZK_HIP(hipEventElapsedTime(&t45, R.ev[4], R.ev[5])); ZK_HIP(hipEventElapsedTime(&t56, R.ev[5], R.ev[6]));
-        ZK_HIP(hipEventElapsedTime(&t67, R.ev[6], R.ev[7])); ZK_HIP(hipEventElapsedTime(&t07, R.ev[0], R.ev[7]));
-        ZK_HIP(hipEventElapsedTime(&times->z_segments, R.ev[8], R.ev[9]));
-        times->solve = t01 + t23; times->commit = t12; times->ntt = t34; times->msm_g1 = t45; times->msm_g2 = t56; times->finalize = t67; times->total = t07;
+        collect_times(R.set[0], times);
+        ZK_HIP(hipEventElapsedTime(&times->total, R.set[0].t0, R.ev[7]));
+    }
+}
+
+// nsteps batches back to back (the same resident inputs are re-proved each time), the SOLVE stage of batch k+1 overlapped
+// with the NTT + MSM stage of batch k.  times (optional) = phase times of the LAST batch; total = whole call / nsteps.
+void Algorithm::resident_prove_pipelined(int nsteps, PhaseTimes *times) {
+    Resident &R = *res;
+    if (nsteps <= 0) return;
+    if (!R.set[1].ready) {
+        R.set[1].reserve(prog, R.cap);
+        R.set[1].sb.B = R.B;
+        ZK_HIP(hipMemcpy(R.set[1].sb.inputs.p, R.set[0].sb.inputs.p, prog.n_inputs * R.B * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+        // the commitment MSMs of the overlapped solve stage need their own scratch
+        if (has_commit) {
+            R.ms2.reserve(R.cap, pk.ped.n * (size_t)pk.ped.W, (size_t)1 << (pk.ped.c - 1), msm_part_stride(pk.ped.n, pk.ped.c));
+            R.ms2.reserve_compact(R.cap, pk.ped.n);
+            R.ms2.reserve_sums(R.cap, (size_t)1 << (pk.ped.c - 1), 1);
+        }
+    }
+    hipStream_t M = R.stream, S = R.stream2;
+    ZK_HIP(hipEventRecord(R.ev[0], M));
+    ZK_HIP(hipStreamWaitEvent(S, R.ev[0], 0));
+    enqueue_solve(R.set[0], has_commit ? R.ms2 : R.ms, S);
+    ZK_HIP(hipEventRecord(R.set[0].solved, S));
+    for (int k = 0; k < nsteps; k++) {
+        SolveSet &cur = R.set[k & 1], &nxt = R.set[(k + 1) & 1];
+        ZK_HIP(hipStreamWaitEvent(M, cur.solved, 0));
+        enqueue_main(cur, M);
+        ZK_HIP(hipEventRecord(cur.consumed, M));
+        if (k + 1 < nsteps) {
+            if (k >= 1) ZK_HIP(hipStreamWaitEvent(S, nxt.consumed, 0));      // nxt's buffers were read by batch k-1
+            enqueue_solve(nxt, has_commit ? R.ms2 : R.ms, S);
+            ZK_HIP(hipEventRecord(nxt.solved, S));
+        }
+    }
+    ZK_HIP(hipStreamSynchronize(S));
+    ZK_HIP(hipStreamSynchronize(M));
+    if (times) {
+        collect_times(R.set[(nsteps - 1) & 1], times);
+        float tot;
+        ZK_HIP(hipEventElapsedTime(&tot, R.ev[0], R.ev[7]));
+        times->total = tot / nsteps;
     }
 }
 
 void Algorithm::resident_download(ProofPoints *out, uint32_t *errs) {
     Resident &R = *res;
     ZK_HIP(hipMemcpy(out, R.out.p, R.B * sizeof(ProofPoints), hipMemcpyDeviceToHost));
-    if (errs) ZK_HIP(hipMemcpy(errs, R.sb.err.p, R.B * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (errs) ZK_HIP(hipMemcpy(errs, R.set[0].sb.err.p, R.B * sizeof(uint32_t), hipMemcpyDeviceToHost));
 }
 
 void Algorithm::prove_batch(size_t batch, const uint32_t *inputs, const U256 *r, const U256 *s, const U256 *randomize, ProofPoints *out,
@@ -434,12 +521,12 @@ void Algorithm::debug_fetch(uint8_t *wires_out, uint8_t *h_out) {
         ZK_HIP(hipMemcpy(tmp.data(), d.p, rows * B * sizeof(Fr), hipMemcpyDeviceToHost));
     };
     if (wires_out) {
-        fetch(R.sb.wires.p, nw);
+        fetch(R.set[0].sb.wires.p, nw);
         for (size_t b = 0; b < B; b++)
             for (size_t w = 0; w < nw; w++) memcpy(wires_out + (b * nw + w) * 32, &tmp[w * B + b], 32);
     }
     if (h_out) {
-        fetch(R.sb.a.p, N);
+        fetch(R.set[0].sb.a.p, N);
         for (size_t b = 0; b < B; b++)
             for (size_t k = 0; k < N; k++) memcpy(h_out + (b * N + k) * 32, &tmp[(size_t)bitrev32((uint32_t)k, logn) * B + b], 32);
     }
