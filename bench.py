@@ -42,7 +42,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("ZKP_BENCH_FORCE_DIST"):       # the env switch exercises the RCCL path on a 1-GPU box
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))

@@ -162,3 +162,21 @@ def test_pipelined_steps_produce_the_same_proofs(zk, oracle, algs):
             assert not errs.any() and np.array_equal(got, ref_proofs), "pipelined pass count %d" % n
         exp, *_ = H.oracle_proof_bytes(alg, insts[3])
         assert zk.proof_serialize(ref_proofs[3], alg != 0) == exp
+
+
+def test_unsatisfiable_witness_is_flagged_per_instance(zk, oracle, algs):
+    """a witness whose Out does not match the cipher output violates a constraint: that instance (only) reports a
+    solver error -- the reference's groth16.Prove returns an error there (panic -> {} at the ABI)"""
+    alg = algs(0)
+    rng = H.SplitMix64(31)
+    insts = [H.make_instance(alg, rng) for _ in range(4)]
+    wits = np.array([H.oracle_witness(alg, i)[0] for i in insts], np.uint32)
+    wits[2, 1500] ^= 1                      # flip one bit of Out
+    rb = zk.ResidentBatch(alg, wits, [i["r"] for i in insts], [i["s"] for i in insts], [0] * 4)
+    rb.step()
+    proofs, errs = rb.fetch()
+    assert errs[2] != 0 and (errs[2] & 0xFF) == 1 and not errs[[0, 1, 3]].any()
+    exp, *_ = H.oracle_proof_bytes(alg, insts[0])
+    assert zk.proof_serialize(proofs[0], False) == exp
+    with pytest.raises(ValueError, match="not satisfied"):
+        H.circuit(alg).solve([int(x) for x in wits[2]])
