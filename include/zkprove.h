@@ -38,6 +38,16 @@ void Free(void *pointer);
 ProveReturn GenerateOPRFRequestData(GoSlice params);
 ProveReturn TOPRFFinalize(GoSlice params);
 
+/* ---------------------------------------------------------------- 1b. reference verifier ABI (libverify.go)
+ * gnark/libraries/verifier/libverify.go:18-26 -> verifier/impl/library.go:162-182, verifiers.go:29-161.
+ * params = {"cipher":str,"proof":b64,"publicSignals":{"ciphertext":b64,"blocks":[{nonce,counter,boundary}],"input":b64}}.
+ * Returns 1 iff the Groth16 proof verifies (host-side BN254 pairing); any malformed input -> 0, never throws.
+ * The reference embeds vk.* at build time; here the key is supplied with ZkpInitVerifier (gnark VerifyingKey.WriteTo
+ * bytes, e.g. the vk returned by ZkpSetup or one of the reference's generated/vk.* files). */
+unsigned char Verify(GoSlice params);
+void VFree(void *pointer);
+unsigned char ZkpInitVerifier(unsigned char algorithmID, GoSlice vk);
+
 /* ---------------------------------------------------------------- 2. extensions */
 /* Accept proving keys whose SHA-256 differs from the pinned KeyHash (impl/library.go:37,42,47).
  * Needed because the reference's pk.* files are not distributable with this repo; default 0 (strict,

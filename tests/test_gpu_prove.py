@@ -180,3 +180,23 @@ def test_unsatisfiable_witness_is_flagged_per_instance(zk, oracle, algs):
     assert zk.proof_serialize(proofs[0], False) == exp
     with pytest.raises(ValueError, match="not satisfied"):
         H.circuit(alg).solve([int(x) for x in wits[2]])
+
+
+@pytest.mark.parametrize("alg", [0, 1, 2])
+def test_reference_full_test_prove_then_verify_through_both_abis(zk, alg):
+    """gnark/libraries/test_helpers.go:292-411 RunFullTest with the product on both sides: keys from ZkpSetup,
+    prover.Prove(json) then verifier.Verify(json) must be true; js/src/tests/lib.test.ts:124-158: tampered -> false"""
+    r1cs = zk.synth.r1cs_bytes(alg)
+    pk, vk = zk.setup(r1cs, zk.synth.toxic_from_seed(7), raw=True)
+    zk.lib.ZkpReset()
+    assert zk.init_algorithm(alg, pk, r1cs) and zk.init_verifier(alg, vk)
+    rng = H.SplitMix64(2024 + alg)
+    for _ in range(2):
+        inst = H.make_instance(alg, rng)
+        res = zk.prove(json.loads(H.request_json(alg, inst)))
+        proof, ct = base64.b64decode(res["proof"]), base64.b64decode(res["ciphertext"])
+        blocks = list(zip(inst["nonces"], inst["counters"]))
+        assert zk.verify(H.CIPHER[alg], proof, ct, blocks, inst["data"])
+        bad = bytearray(ct); bad[0] ^= 1
+        assert not zk.verify(H.CIPHER[alg], proof, bytes(bad), blocks, inst["data"])
+    zk.lib.ZkpReset()

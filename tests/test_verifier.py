@@ -1,0 +1,60 @@
+"""CPU tests of the product's verifier (libverify ABI; host-only code, no GPU needed): it must agree
+with the oracle's independent pairing on oracle-made proofs -- the reference's own check `verifier.Verify(prover.Prove(x))`
+(gnark/libraries/test_helpers.go:332-339, 403-410) and its tamper tests (js/src/tests/lib.test.ts:124-158)."""
+import base64
+import json
+import os
+
+import pytest
+
+from oracle import gnark_format as gf
+from oracle import pairing
+
+import helpers as H
+
+
+def _req(alg, inst, proof, out):
+    b = lambda x: base64.b64encode(x).decode()
+    return {"cipher": H.CIPHER[alg], "proof": b(proof),
+            "publicSignals": {"ciphertext": b(out), "blocks": [{"nonce": b(n), "counter": c, "boundary": None} for n, c in zip(inst["nonces"], inst["counters"])],
+                              "input": b(inst["data"])}}
+
+
+@pytest.mark.parametrize("alg", [0, 1])
+def test_verify_accepts_oracle_proofs_and_rejects_tampering(zk, oracle, alg):
+    inst = H.make_instance(alg, H.SplitMix64(777 + alg))
+    proof, out, prf, wit = H.oracle_proof_bytes(alg, inst)
+    vk = gf.vk_from_pk(H.oracle_pk(alg))
+    assert zk.init_verifier(alg, gf.vk_bytes(vk))
+    good = _req(alg, inst, proof, out)
+    assert zk.verify_raw(json.dumps(good).encode()) is True
+    npub = H.circuit(alg).r1cs.nb_public - 1
+    assert pairing.groth16_verify(vk, gf.proof_parse(proof), wit[:npub])        # same verdict as the oracle
+    # tampered ciphertext / input / counter / proof -> false (lib.test.ts:124-158 "invalid proof")
+    for field in ("ciphertext", "input"):
+        bad = json.loads(json.dumps(good))
+        raw = bytearray(base64.b64decode(bad["publicSignals"][field])); raw[5] ^= 1
+        bad["publicSignals"][field] = base64.b64encode(bytes(raw)).decode()
+        assert zk.verify_raw(json.dumps(bad).encode()) is False
+    bad = json.loads(json.dumps(good)); bad["publicSignals"]["blocks"][0]["counter"] += 1
+    assert zk.verify_raw(json.dumps(bad).encode()) is False
+    other, *_ = H.oracle_proof_bytes(alg, H.make_instance(alg, H.SplitMix64(1)))
+    bad = json.loads(json.dumps(good)); bad["proof"] = base64.b64encode(other).decode()
+    assert zk.verify_raw(json.dumps(bad).encode()) is False
+    raw = bytearray(proof); raw[40] ^= 0x10
+    bad = json.loads(json.dumps(good)); bad["proof"] = base64.b64encode(bytes(raw)).decode()
+    assert zk.verify_raw(json.dumps(bad).encode()) is False
+
+
+def test_verify_malformed_requests_return_false(zk):
+    for bad in (b"", b"{", b"[]", b'{"cipher":"rot13"}', b'{"cipher":"chacha20","proof":"AAAA","publicSignals":{}}',
+                b'{"cipher":"chacha20","proof":"!!","publicSignals":{"ciphertext":"","blocks":[],"input":""}}'):
+        assert zk.verify_raw(bad) is False
+
+
+def test_reference_verifying_keys_load(zk):
+    """the reference's own vk files (gnark/libraries/verifier/impl/generated/vk.*) decode: every point decompresses onto its curve"""
+    for alg, name in ((0, "chacha20"), (1, "aes128")):
+        buf = open(os.path.join(H.ROOT, "tests", "golden", "vk." + name), "rb").read()
+        assert zk.init_verifier(alg, buf)
+        assert not zk.init_verifier(alg, buf[:-3])

@@ -224,3 +224,27 @@ def setup(r1cs: bytes, toxic, raw: bool = True):
 
 
 from . import synth  # noqa: E402  (synthetic workload generator used by bench.py / tests)
+
+
+_sig("Verify", C.c_ubyte, [GoSlice])
+_sig("VFree", None, [C.c_void_p])
+_sig("ZkpInitVerifier", C.c_ubyte, [C.c_ubyte, GoSlice])
+
+
+def init_verifier(algorithm_id: int, vk: bytes) -> bool:
+    s, keep = _slice(vk)
+    return bool(lib.ZkpInitVerifier(algorithm_id, s))
+
+
+def verify_raw(request_json: bytes) -> bool:
+    """lib.verify(json) (js/src/gnark/operator.ts:33-45 -> libverify.go:19)"""
+    s, keep = _slice(request_json)
+    return bool(lib.Verify(s))
+
+
+def verify(cipher: str, proof: bytes, ciphertext: bytes, blocks, plaintext_input: bytes) -> bool:
+    import base64 as _b64
+    b = lambda x: _b64.b64encode(x).decode()
+    req = {"cipher": cipher, "proof": b(proof),
+           "publicSignals": {"ciphertext": b(ciphertext), "blocks": [{"nonce": b(n), "counter": c} for n, c in blocks], "input": b(plaintext_input)}}
+    return verify_raw(_json.dumps(req).encode())
