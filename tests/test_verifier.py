@@ -58,3 +58,16 @@ def test_reference_verifying_keys_load(zk):
         buf = open(os.path.join(H.ROOT, "tests", "golden", "vk." + name), "rb").read()
         assert zk.init_verifier(alg, buf)
         assert not zk.init_verifier(alg, buf[:-3])
+
+
+def test_vk_directory_fallback(zk, oracle, tmp_path, monkeypatch):
+    """drop-in behaviour: with no ZkpInitVerifier call the key is read from $ZKPROVE_VK_DIR/vk.<ext> on first use"""
+    alg = 2            # no other test initialises the aes-256 verifier in this process
+    inst = H.make_instance(alg, H.SplitMix64(4))
+    proof, out, *_ = H.oracle_proof_bytes(alg, inst)
+    (tmp_path / "vk.aes256").write_bytes(gf.vk_bytes(gf.vk_from_pk(H.oracle_pk(alg))))
+    req = json.dumps(_req(alg, inst, proof, out)).encode()
+    monkeypatch.delenv("ZKPROVE_VK_DIR", raising=False)
+    assert zk.verify_raw(req) is False
+    monkeypatch.setenv("ZKPROVE_VK_DIR", str(tmp_path))
+    assert zk.verify_raw(req) is True

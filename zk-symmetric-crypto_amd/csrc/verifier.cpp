@@ -275,6 +275,24 @@ static bool verify_impl(const uint8_t *data, size_t len) {
         for (uint8_t v : ct) pub.push_back(v);
     }
     std::unique_lock<std::mutex> lk(g_vk_lock);
+    if (!g_vk[alg]) {
+        // the reference embeds generated/vk.* at build time (verifier/impl/library.go:92-160); the drop-in equivalent is a
+        // directory of the same files: $ZKPROVE_VK_DIR/vk.{chacha20,aes128,aes256}
+        static const char *EXT[3] = {"chacha20", "aes128", "aes256"};
+        if (const char *dir = getenv("ZKPROVE_VK_DIR")) {
+            std::string path = std::string(dir) + "/vk." + EXT[alg];
+            if (FILE *f = fopen(path.c_str(), "rb")) {
+                std::vector<uint8_t> buf;
+                uint8_t tmp[65536];
+                size_t n;
+                while ((n = fread(tmp, 1, sizeof(tmp), f)) > 0) buf.insert(buf.end(), tmp, tmp + n);
+                fclose(f);
+                std::unique_ptr<VerifyingKey> k(new VerifyingKey());
+                vk_parse(buf.data(), buf.size(), *k);
+                g_vk[alg] = std::move(k);
+            }
+        }
+    }
     if (!g_vk[alg]) { printf("verifying key for %s is not initialised\n", NAMES[alg]); return false; }
     const VerifyingKey vk = *g_vk[alg];
     lk.unlock();
