@@ -200,3 +200,22 @@ def test_reference_full_test_prove_then_verify_through_both_abis(zk, alg):
         bad = bytearray(ct); bad[0] ^= 1
         assert not zk.verify(H.CIPHER[alg], proof, bytes(bad), blocks, inst["data"])
     zk.lib.ZkpReset()
+
+
+def test_concurrent_init_and_prove(zk, oracle):
+    """gnark/libraries/aux_test.go:40-83 TestInit: InitAlgorithm from many threads at once is safe and idempotent;
+    Prove is re-entrant"""
+    from concurrent.futures import ThreadPoolExecutor
+    zk.lib.ZkpReset()
+    zk.lib.ZkpAllowUnpinnedKeys(1)
+    pk, r1cs = H.pk_file_bytes(0), rf.load_r1cs_bytes("chacha20")
+    with ThreadPoolExecutor(max_workers=12) as ex:
+        assert all(ex.map(lambda _: zk.init_algorithm(0, pk, r1cs), range(24)))
+    rng = H.SplitMix64(5150)
+    insts = [H.make_instance(0, rng) for _ in range(6)]
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        res = list(ex.map(lambda i: zk.prove_deterministic_raw(H.request_json(0, i), i["r"], i["s"], 0), insts))
+    for inst, raw in zip(insts, res):
+        exp, out, *_ = H.oracle_proof_bytes(0, inst)
+        got = json.loads(raw)
+        assert base64.b64decode(got["proof"]) == exp and base64.b64decode(got["ciphertext"]) == out
