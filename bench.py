@@ -37,6 +37,13 @@ def main():
     ap.add_argument("--cpu-proofs", type=int, default=-1, help="cpu_baseline sample: proofs per worker process (0 = skip, -1 = default 8)")
     args = ap.parse_args()
 
+    # stdout must carry exactly ONE JSON line: everything else that writes to fd 1 (the library mirrors the reference's
+    # "Initialized <alg>" println, RCCL banners, ...) is sent to stderr; the JSON goes to the saved descriptor at the end
+    import ctypes
+    real_stdout = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -155,7 +162,9 @@ def main():
                 out["cpu_baseline"] = json.loads(line[-1]) if line else {"error": (res.stderr or "no output")[-400:]}
             except Exception as e:          # the baseline must never take the GPU result down with it
                 out["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 
