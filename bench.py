@@ -140,7 +140,7 @@ def main():
                                    % (H.CIPHER[alg], 2 if alg == 0 else 5, B),
                        "algorithm_id": alg, "batch_per_gpu": B, "pipelined_steps": not args.no_pipeline, "parallelism": "dp%d (independent proofs, no collective)" % world,
                        "blocks_per_s": value * (2 if alg == 0 else 5)},
-            "phases_ms": mean, "solver_ok": ok, "init_s": t_init, "setup_s": t_setup,
+            "phases_ms": mean, "phases_note": ("pipelined: 'solve' (+'commit') ran on a second stream UNDER the previous pass's ntt/msm and is not additive; total = whole call / steps" if not args.no_pipeline else "single stream: phases are additive"), "solver_ok": ok, "init_s": t_init, "setup_s": t_setup,
             "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate<Fp> (bucket accumulation of the quotient MSM over G1.Z)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launch_ms": zdur_ms, "algorithmic_bytes_per_launch": zbytes,
