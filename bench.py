@@ -127,7 +127,7 @@ def main():
             pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
             if pm and alg == 0 and B == 1024:
                 for k, v in json.load(open(pm[-1]))["kernels"].items():
-                    if "k_msm_accumulate<zk::Field<zk::FpParams>" in k:
+                    if "k_msm_accumulate<zk::Field<zk::FpParams>, true>" in k:
                         traffic = (v["FETCH_SIZE_KB_per_launch_max"] + v["WRITE_SIZE_KB_per_launch_max"]) * 1024.0
         except Exception:
             traffic = None
@@ -141,7 +141,7 @@ def main():
                        "algorithm_id": alg, "batch_per_gpu": B, "pipelined_steps": not args.no_pipeline, "parallelism": "dp%d (independent proofs, no collective)" % world,
                        "blocks_per_s": value * (2 if alg == 0 else 5)},
             "phases_ms": mean, "phases_note": ("pipelined: 'solve' (+'commit') ran on a second stream UNDER the previous pass's ntt/msm and is not additive; total = whole call / steps" if not args.no_pipeline else "single stream: phases are additive"), "solver_ok": ok, "init_s": t_init, "setup_s": t_setup,
-            "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate<Fp> (bucket accumulation of the quotient MSM over G1.Z)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate<Fp, dense> (bucket accumulation of the quotient MSM over G1.Z)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launch_ms": zdur_ms, "algorithmic_bytes_per_launch": zbytes,
                          "whole_path_GBps": value / world * BYTES_PER_PROOF[alg] / 1e9,

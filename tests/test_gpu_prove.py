@@ -219,3 +219,18 @@ def test_concurrent_init_and_prove(zk, oracle):
         exp, out, *_ = H.oracle_proof_bytes(0, inst)
         got = json.loads(raw)
         assert base64.b64decode(got["proof"]) == exp and base64.b64decode(got["ciphertext"]) == out
+
+
+def test_prove_batch_larger_than_one_gpu_chunk(zk, oracle, algs):
+    """ProveBatch with more requests than the 1024-instance device chunk: processed in chunks, order preserved"""
+    alg = algs(0)
+    rng = H.SplitMix64(8080)
+    insts = [H.make_instance(alg, rng) for _ in range(1030)]
+    reqs = "[" + ",".join(H.request_json(alg, i).decode() for i in insts) + "]"
+    res = json.loads(zk.prove_batch_raw(reqs.encode()))
+    assert len(res) == 1030 and all("proof" in r for r in res)
+    vk = gf.vk_from_pk(H.oracle_pk(alg))
+    for k in (0, 1023, 1024, 1029):
+        wit, out = H.oracle_witness(alg, insts[k])
+        assert base64.b64decode(res[k]["ciphertext"]) == out
+        assert pairing.groth16_verify(vk, gf.proof_parse(base64.b64decode(res[k]["proof"])), wit[:2304])

@@ -333,7 +333,8 @@ __global__ __launch_bounds__(256) void k_msm_binsort(const uint32_t *__restrict_
 // to the spread of Poisson(32) bucket sizes across the 64 lanes.
 // sums[b * nb + k] receives the sum of bucket k when it is non-empty (empty buckets are never written;
 // the reduce kernel reads emptiness from bucket_start).
-template <class F>
+// DENSE only names the instantiation (quotient MSM vs. wire MSMs) so that profiler summaries keep the dominant launch apart.
+template <class F, bool DENSE>
 __global__ __launch_bounds__(64) void k_msm_accumulate(const Affine<F> *__restrict__ table, const uint32_t *__restrict__ bucket_start,
                                                        const uint32_t *__restrict__ entries, size_t max_entries, int c, size_t B,
                                                        uint32_t nlanes, XYZZ<F> *__restrict__ sums) {
@@ -361,7 +362,9 @@ __global__ __launch_bounds__(64) void k_msm_accumulate(const Affine<F> *__restri
     uint32_t e = bs[k0];
     const uint32_t e_end = bs[k1];
     if (e >= e_end) return;
+    // bucket boundaries are prefetched one ahead: leaving a bucket then costs no dependent memory round trip
     uint32_t cur = k0, cur_start = e, next_b = bs[k0 + 1];
+    uint32_t next_b2 = bs[(k0 + 2 <= nb) ? k0 + 2 : nb];
     XYZZ<F> acc = XYZZ<F>::inf();
     uint32_t v = ent[e];
     Affine<F> p = table[v & 0x7fffffffu];
@@ -370,7 +373,8 @@ __global__ __launch_bounds__(64) void k_msm_accumulate(const Affine<F> *__restri
             if (next_b > cur_start) { out[cur] = acc; acc = XYZZ<F>::inf(); }   // every non-empty bucket is written, even if its sum is infinity
             cur++;
             cur_start = next_b;
-            next_b = bs[cur + 1];
+            next_b = next_b2;
+            next_b2 = bs[(cur + 2 <= nb) ? cur + 2 : nb];
         }
         // prefetch the next entry's base point before the long dependent chain of the mixed addition
         const uint32_t e_next = e + 1;
@@ -571,8 +575,12 @@ static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, M
     XYZZ<F> *sums = SumsSel<F>::get(sc);
     if (SumsSel<F>::cap(sc) < B * (size_t)nb) throw ZkError("msm bucket-sum scratch too small");
     if (seg_events) ZK_HIP(hipEventRecord(seg_events[0], s));
-    hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(ceil_div((size_t)nlanes * B, 64)), dim3(64), 0, s, mb.table.p, sc.bucket_start.p, sc.entries.p,
-                       max_entries, c, B, nlanes, sums);
+    if (mb.dense)
+        hipLaunchKernelGGL((k_msm_accumulate<F, true>), dim3(ceil_div((size_t)nlanes * B, 64)), dim3(64), 0, s, mb.table.p, sc.bucket_start.p, sc.entries.p,
+                           max_entries, c, B, nlanes, sums);
+    else
+        hipLaunchKernelGGL((k_msm_accumulate<F, false>), dim3(ceil_div((size_t)nlanes * B, 64)), dim3(64), 0, s, mb.table.p, sc.bucket_start.p, sc.entries.p,
+                           max_entries, c, B, nlanes, sums);
     if (seg_events) ZK_HIP(hipEventRecord(seg_events[1], s));
     hipLaunchKernelGGL(k_msm_bucket_reduce<F>, dim3(ceil_div(nseg * B, 64)), dim3(64), 0, s, sums, sc.bucket_start.p, c, B, part, stride, nchunks);
     hipLaunchKernelGGL(k_sum_groups<F>, dim3(ceil_div(nlvl1 * B, 64)), dim3(64), 0, s, part, stride, npart, GROUP, part + npart, stride, B);
