@@ -106,6 +106,8 @@ int zkp_compute_h(int logn, long batch, long ncons, const uint8_t *a, const uint
 /* points n*64 (G1: x|y) / n*128 (G2: x.a0|x.a1|y.a0|y.a1) canonical LE; scalars [batch][n][32]; c = window bits */
 int zkp_msm_g1(long n, long batch, const uint8_t *points, const uint8_t *scalars, uint8_t *out, int c);
 int zkp_msm_g2(long n, long batch, const uint8_t *points, const uint8_t *scalars, uint8_t *out, int c);
+/* same as zkp_msm_g1 through the dense (quotient-MSM) sort path: no 0/+-1 fast path, two-level sort when c >= 9 */
+int zkp_msm_g1_dense(long n, long batch, const uint8_t *points, const uint8_t *scalars, uint8_t *out, int c);
 /* kind 0: Fp mul (2/iter) 1: G1 mixed add 2: G2 mixed add; returns milliseconds */
 double zkp_microbench(int kind, long threads, int iters);
 

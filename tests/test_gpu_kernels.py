@@ -109,3 +109,21 @@ def test_msm_all_zero_and_all_one(zk, oracle):
     assert zk.lib.zkp_msm_g1(n, batch, pts.ctypes.data, sc.ctypes.data, got.ctypes.data, 9) == 0
     assert np.array_equal(got, exp)
     assert not got[0].any()      # empty sum = infinity = (0,0)
+
+
+@pytest.mark.parametrize("n,batch,c", [(1, 1, 8), (300, 3, 8), (900, 5, 12), (2500, 2, 16), (70000, 1, 16)])
+def test_msm_g1_dense_path_matches_oracle(zk, oracle, n, batch, c):
+    """quotient-MSM path: instance-major scalars, single-level (c <= 8) and two-level (c >= 9) bucket sort"""
+    rng = np.random.default_rng(7000 + n + c)
+    pts = oracle.g1_fixed_base(_rand_fr(rng, n))
+    sc = np.stack([_rand_fr(rng, n) for _ in range(batch)])
+    if n > 10:
+        sc[0, :4] = 0
+        sc[0, 4, :] = 0; sc[0, 4, 0] = 1                    # 0 and 1 are ordinary digits here
+        sc[0, 5] = np.frombuffer((R - 1).to_bytes(32, "little"), np.uint8)
+        sc[0, 6:40] = sc[0, 41]                              # many equal scalars -> one hot bucket per window
+    exp = np.stack([oracle.msm_g1(pts, sc[b]) for b in range(batch)])
+    got = np.zeros((batch, 64), np.uint8)
+    rc = zk.lib.zkp_msm_g1_dense(n, batch, pts.ctypes.data, sc.ctypes.data, got.ctypes.data, c)
+    assert rc == 0, zk.last_error()
+    assert np.array_equal(got, exp)

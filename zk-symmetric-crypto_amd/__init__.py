@@ -45,6 +45,7 @@ _sig("zkp_ntt", _i32, [_i32, _i64, _vp, _i32])
 _sig("zkp_compute_h", _i32, [_i32, _i64, _i64, _vp, _vp, _vp, _vp])
 _sig("zkp_msm_g1", _i32, [_i64, _i64, _vp, _vp, _vp, _i32])
 _sig("zkp_msm_g2", _i32, [_i64, _i64, _vp, _vp, _vp, _i32])
+_sig("zkp_msm_g1_dense", _i32, [_i64, _i64, _vp, _vp, _vp, _i32])
 _sig("zkp_microbench", C.c_double, [_i32, _i64, _i32])
 
 

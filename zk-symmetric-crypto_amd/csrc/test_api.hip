@@ -104,7 +104,7 @@ extern "C" int zkp_compute_h(int logn, long batch, long ncons, const uint8_t *a,
 }
 
 template <class F>
-static int msm_test(long n_, long batch, const uint8_t *points, const uint8_t *scalars, uint8_t *out, int c) {
+static int msm_test(long n_, long batch, const uint8_t *points, const uint8_t *scalars, uint8_t *out, int c, bool dense = false) {
     const size_t n = (size_t)n_, B = (size_t)batch;
     constexpr size_t PB = sizeof(Affine<F>);          // 64 or 128
     // points arrive canonical LE (x|y) resp. (x0|x1|y0|y1): upload and convert to Montgomery on device
@@ -114,15 +114,18 @@ static int msm_test(long n_, long batch, const uint8_t *points, const uint8_t *s
     std::vector<uint32_t> rows(n);
     for (size_t j = 0; j < n; j++) rows[j] = (uint32_t)j;
     MsmBases<F> mb;
-    msm_bases_build(mb, dp.p, n, rows.data(), c, 0);
+    msm_bases_build(mb, dp.p, n, dense ? nullptr : rows.data(), c, 0);
+    mb.dense_stride = n;
     std::vector<Fr> hs;
-    transpose_in(hs, scalars, B, n);
+    if (dense) { hs.resize(n * B); memcpy(hs.data(), scalars, n * B * 32); }      // dense path reads the instance-major layout directly
+    else transpose_in(hs, scalars, B, n);
     DevBuf<Fr> ds(n * B + 1);
     ds.upload(hs.data(), n * B);
     fr_to_mont(ds.p, n * B, 0);
     MsmScratch sc;
     sc.reserve(B, n * mb.W, (size_t)1 << (c - 1), msm_part_stride(n, c));
     sc.reserve_compact(B, n);
+    if (dense) sc.reserve_dense(B, n * mb.W);
     sc.reserve_sums(B, sizeof(F) == 32 ? (size_t)1 << (c - 1) : 1, sizeof(F) == 32 ? 1 : (size_t)1 << (c - 1));
     DevBuf<XYZZ<F>> res(B);
     DevBuf<Affine<F>> aff(B);
@@ -136,6 +139,12 @@ static int msm_test(long n_, long batch, const uint8_t *points, const uint8_t *s
 extern "C" int zkp_msm_g1(long n, long batch, const uint8_t *points, const uint8_t *scalars, uint8_t *out, int c) {
     ZKP_TRY
     return msm_test<Fp>(n, batch, points, scalars, out, c);
+    ZKP_CATCH(-1)
+}
+// dense (quotient-MSM) path: every scalar goes through the bucket pipeline, scalars read instance-major
+extern "C" int zkp_msm_g1_dense(long n, long batch, const uint8_t *points, const uint8_t *scalars, uint8_t *out, int c) {
+    ZKP_TRY
+    return msm_test<Fp>(n, batch, points, scalars, out, c, true);
     ZKP_CATCH(-1)
 }
 // points: n*128 canonical LE (x.a0|x.a1|y.a0|y.a1)
