@@ -234,3 +234,25 @@ def test_prove_batch_larger_than_one_gpu_chunk(zk, oracle, algs):
         wit, out = H.oracle_witness(alg, insts[k])
         assert base64.b64decode(res[k]["ciphertext"]) == out
         assert pairing.groth16_verify(vk, gf.proof_parse(base64.b64decode(res[k]["proof"])), wit[:2304])
+
+
+@pytest.mark.parametrize("alg", [0, 2])
+def test_extreme_inputs(zk, oracle, algs, alg):
+    """maximum counters, all-zero and all-ones keys / plaintexts, per-block distinct nonces (aux_test.go:192-322)"""
+    algs(alg)
+    nblk = 2 if alg == 0 else 5
+    n = 128 if alg == 0 else 80
+    klen = 32
+    cases = [
+        dict(key=bytes(klen), nonces=[bytes(12)] * nblk, counters=[0] * nblk, data=bytes(n)),
+        dict(key=b"\xff" * klen, nonces=[b"\xff" * 12] * nblk, counters=[0xFFFFFFFF] * nblk, data=b"\xff" * n),
+        dict(key=bytes(range(klen)), nonces=[bytes([b] * 12) for b in range(nblk)], counters=[0xFFFFFFFF - b for b in range(nblk)], data=bytes(range(n))),
+    ]
+    for k, c in enumerate(cases):
+        inst = dict(c, r=12345 + k, s=R_TEST - 1 - k, randomize=7 * k)
+        res = json.loads(zk.prove_deterministic_raw(H.request_json(alg, inst), inst["r"], inst["s"], inst["randomize"]))
+        exp, out, *_ = H.oracle_proof_bytes(alg, inst)
+        assert base64.b64decode(res["ciphertext"]) == out and base64.b64decode(res["proof"]) == exp
+
+
+R_TEST = rf.R_MOD

@@ -455,16 +455,25 @@ __global__ __launch_bounds__(256) void k_msm_ones(const Affine<F> *__restrict__ 
         }
     }
     XYZZ<F> acc = XYZZ<F>::inf();
-#pragma unroll
-    for (int wd = 0; wd < 4; wd++) {
-        uint32_t m = pos[wd] | neg[wd];
-        while (m) {
-            const int bit = __ffs((int)m) - 1;
-            m &= m - 1;
-            Affine<F> p = base[j0 + wd * 32 + bit];
-            if ((neg[wd] >> bit) & 1) p.y = p.y.neg();
-            acc.madd(p);
-        }
+    // walk the set bits with the next base point prefetched under the current mixed addition
+    uint64_t mlo = (uint64_t)(pos[0] | neg[0]) | ((uint64_t)(pos[1] | neg[1]) << 32);
+    uint64_t mhi = (uint64_t)(pos[2] | neg[2]) | ((uint64_t)(pos[3] | neg[3]) << 32);
+    const uint64_t nlo = (uint64_t)neg[0] | ((uint64_t)neg[1] << 32), nhi = (uint64_t)neg[2] | ((uint64_t)neg[3] << 32);
+    auto next_bit = [&]() -> int {          // index in [0,128) of the lowest remaining bit, -1 when done
+        if (mlo) { const int k = __ffsll((long long)mlo) - 1; mlo &= mlo - 1; return k; }
+        if (mhi) { const int k = __ffsll((long long)mhi) - 1; mhi &= mhi - 1; return 64 + k; }
+        return -1;
+    };
+    int k = next_bit();
+    Affine<F> p = base[j0 + (k < 0 ? 0 : k)];
+    while (k >= 0) {
+        const int kn = next_bit();
+        Affine<F> pn = p;
+        if (kn >= 0) pn = base[j0 + kn];
+        const bool ng = k < 64 ? ((nlo >> k) & 1) : ((nhi >> (k - 64)) & 1);
+        if (ng) p.y = p.y.neg();
+        acc.madd(p);
+        k = kn; p = pn;
     }
     part[b * part_stride + part_off + chunk] = acc;
 }
