@@ -215,7 +215,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_msm_partition(const Fr *__rest
     uint32_t *tile_cnt = bin_cursor + MAX_COARSE;     // [nbin]
     uint32_t *tile_off = tile_cnt + MAX_COARSE;       // [nbin]
     uint32_t *tile_ent = tile_off + MAX_COARSE;       // [PART_THREADS * W]
-    uint32_t *tile_dst = tile_ent + PART_THREADS * 24;
+    uint32_t *tile_dst = tile_ent + PART_THREADS * W;     // tiles sized by the actual window count: 73 KiB at W = 16 -> two workgroups per CU
     const size_t b = blockIdx.x;
     const int tid = threadIdx.x, wave = tid >> 6;
     const Fr *sc = dense + b * dense_stride;
@@ -559,7 +559,7 @@ static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, M
         ZK_HIP(hipMemsetAsync(part, 0, B * stride * sizeof(XYZZ<F>), s));
         if (c - 1 > FINE_BITS && c - 1 - FINE_BITS <= 8 && W <= 24 && n * (size_t)W < (1u << 21) && sc.entries2.n >= B * max_entries + 1) {
             static bool attr2 = false;
-            const size_t lds2 = (size_t)(PART_THREADS / 64 * MAX_COARSE + (MAX_COARSE + 1) + 3 * MAX_COARSE + 2 * PART_THREADS * 24) * sizeof(uint32_t);
+            const size_t lds2 = (size_t)(PART_THREADS / 64 * MAX_COARSE + (MAX_COARSE + 1) + 3 * MAX_COARSE + 2 * PART_THREADS * (size_t)W) * sizeof(uint32_t);
             if (!attr2) { ZK_HIP(hipFuncSetAttribute((const void *)k_msm_partition, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)); attr2 = true; }
             sc.coarse_base.ensure(B * (MAX_COARSE + 1));
             hipLaunchKernelGGL(k_msm_partition, dim3((unsigned)B), dim3(PART_THREADS), lds2, s, scalars, mb.dense_stride, n, c, W, sc.coarse_base.p,
