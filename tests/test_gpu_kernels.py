@@ -127,3 +127,19 @@ def test_msm_g1_dense_path_matches_oracle(zk, oracle, n, batch, c):
     rc = zk.lib.zkp_msm_g1_dense(n, batch, pts.ctypes.data, sc.ctypes.data, got.ctypes.data, c)
     assert rc == 0, zk.last_error()
     assert np.array_equal(got, exp)
+
+
+def test_msm_dense_all_equal_scalars_overflows_lds_bins(zk, oracle):
+    """adversarial input: identical scalars put every entry of a window into ONE bucket (bins far beyond the LDS capacity
+    of the bin sort, one thread's piece spanning a single huge bucket)"""
+    rng = np.random.default_rng(99)
+    n, batch = 9000, 2
+    pts = oracle.g1_fixed_base(_rand_fr(rng, n))
+    sc = np.zeros((batch, n, 32), np.uint8)
+    sc[0, :] = _rand_fr(rng, 1)[0]
+    sc[1, : n // 2] = _rand_fr(rng, 1)[0]
+    sc[1, n // 2:] = _rand_fr(rng, n - n // 2)
+    exp = np.stack([oracle.msm_g1(pts, sc[b]) for b in range(batch)])
+    got = np.zeros((batch, 64), np.uint8)
+    assert zk.lib.zkp_msm_g1_dense(n, batch, pts.ctypes.data, sc.ctypes.data, got.ctypes.data, 16) == 0
+    assert np.array_equal(got, exp)

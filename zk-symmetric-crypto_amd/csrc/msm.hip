@@ -295,34 +295,52 @@ __global__ __launch_bounds__(PART_THREADS) void k_msm_partition(const Fr *__rest
     }
 }
 
-// grid (nbin, B), 256 threads
+// grid (nbin, B), 256 threads.  Bins that fit BIN_CAP entries (the normal case: ~4096 +- 64) are sorted entirely in LDS and
+// written back as one linear run; larger bins (adversarial scalar sets) fall back to scattering inside the bin's window.
+static constexpr uint32_t BIN_CAP = 6144;
 __global__ __launch_bounds__(256) void k_msm_binsort(const uint32_t *__restrict__ coarse_base, const uint32_t *__restrict__ part_entries,
                                                      uint32_t *__restrict__ entries, size_t max_entries, int c,
                                                      uint32_t *__restrict__ bucket_start) {
     __shared__ uint32_t hist[1 << FINE_BITS];
     __shared__ uint32_t cursor[1 << FINE_BITS];
+    __shared__ uint32_t buf_in[BIN_CAP], buf_out[BIN_CAP];
     const uint32_t nb = 1u << (c - 1);
     const uint32_t bin = blockIdx.x;
     const size_t b = blockIdx.y;
     const int tid = threadIdx.x;
     const uint32_t lo = coarse_base[b * (MAX_COARSE + 1) + bin], hi = coarse_base[b * (MAX_COARSE + 1) + bin + 1];
+    const uint32_t cnt = hi - lo;
+    const bool fits = cnt <= BIN_CAP;
     const uint32_t *in = part_entries + b * max_entries;
     uint32_t *out = entries + b * max_entries;
     uint32_t *bs = bucket_start + b * (nb + 1) + ((size_t)bin << FINE_BITS);
+    const uint32_t fmask = (1u << FINE_BITS) - 1;
     if (tid < (1 << FINE_BITS)) hist[tid] = 0;
     __syncthreads();
-    for (uint32_t i = lo + tid; i < hi; i += 256) atomicAdd(&hist[(in[i] >> 21) & ((1u << FINE_BITS) - 1)], 1u);
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t run = lo;
-        for (int k = 0; k < (1 << FINE_BITS); k++) { cursor[k] = run; bs[k] = run; run += hist[k]; }
-        if (bin + 1 == gridDim.x) bs[1 << FINE_BITS] = run;          // bucket_start[nb] = total
+    for (uint32_t i = tid; i < cnt; i += 256) {
+        const uint32_t v = in[lo + i];
+        if (fits) buf_in[i] = v;
+        atomicAdd(&hist[(v >> 21) & fmask], 1u);
     }
     __syncthreads();
-    for (uint32_t i = lo + tid; i < hi; i += 256) {
-        const uint32_t v = in[i];
-        const uint32_t pos = atomicAdd(&cursor[(v >> 21) & ((1u << FINE_BITS) - 1)], 1u);
-        out[pos] = v & 0x801fffffu;
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int k = 0; k < (1 << FINE_BITS); k++) { cursor[k] = run; bs[k] = lo + run; run += hist[k]; }
+        if (bin + 1 == gridDim.x) bs[1 << FINE_BITS] = lo + run;          // bucket_start[nb] = total
+    }
+    __syncthreads();
+    if (fits) {
+        for (uint32_t i = tid; i < cnt; i += 256) {
+            const uint32_t v = buf_in[i];
+            buf_out[atomicAdd(&cursor[(v >> 21) & fmask], 1u)] = v & 0x801fffffu;
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < cnt; i += 256) out[lo + i] = buf_out[i];
+    } else {
+        for (uint32_t i = tid; i < cnt; i += 256) {
+            const uint32_t v = in[lo + i];
+            out[lo + atomicAdd(&cursor[(v >> 21) & fmask], 1u)] = v & 0x801fffffu;
+        }
     }
 }
 
