@@ -597,8 +597,11 @@ static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, M
                            sc.gen_val.p, n, c, W, sc.bucket_start.p, sc.entries.p, max_entries);
     }
     // lanes per instance for the accumulate kernel: ~2048 entries per lane at the worst case (all scalars wide)
-    // (2048 entries per thread measured best among 512..4096)
-    uint32_t nlanes = (uint32_t)((max_entries + 2047) / 2048);
+    // 2048 entries per thread measured best at B = 1024 (among 512..4096); small batches (a single Prove() call) cut the
+    // list finer so that the launch still has ~256k threads
+    size_t piece = 2048;
+    while (piece > 64 && (max_entries * B) / piece < 262144) piece >>= 1;
+    uint32_t nlanes = (uint32_t)((max_entries + piece - 1) / piece);
     if (nlanes < 1) nlanes = 1;
     XYZZ<F> *sums = SumsSel<F>::get(sc);
     if (SumsSel<F>::cap(sc) < B * (size_t)nb) throw ZkError("msm bucket-sum scratch too small");
