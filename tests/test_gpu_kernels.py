@@ -143,3 +143,29 @@ def test_msm_dense_all_equal_scalars_overflows_lds_bins(zk, oracle):
     got = np.zeros((batch, 64), np.uint8)
     assert zk.lib.zkp_msm_g1_dense(n, batch, pts.ctypes.data, sc.ctypes.data, got.ctypes.data, 16) == 0
     assert np.array_equal(got, exp)
+
+
+def test_full_size_ntt_round_trip_and_linearity(zk):
+    """N = 2^16 (the ChaCha domain), batch 64: inverse(forward(x)) == x through both kernel families, and the transform is
+    linear -- size-independent properties at a size the CPU oracle would take minutes for"""
+    rng = np.random.default_rng(11)
+    logn, batch = 16, 64
+    n = 1 << logn
+    x = rng.integers(0, 256, size=(batch, n, 32), dtype=np.uint8)
+    x[:, :, 31] &= 0x1F                                  # < 2^253 < r
+    y = x.copy()
+    assert zk.lib.zkp_ntt(logn, batch, y.ctypes.data, 0) == 0        # forward, DIF kernels
+    z = y.copy()
+    assert zk.lib.zkp_ntt(logn, batch, z.ctypes.data, 3) == 0        # inverse, DIT kernels
+    assert np.array_equal(z, x)
+    # linearity on two instances: NTT(a) + NTT(b) == NTT(a + b)  (mod r)
+    a = [int.from_bytes(x[0, i].tobytes(), "little") for i in range(0, n, 997)]
+    s = x[:2].copy()
+    tot = np.zeros((1, n, 32), np.uint8)
+    for i in range(n):
+        v = (int.from_bytes(x[0, i].tobytes(), "little") + int.from_bytes(x[1, i].tobytes(), "little")) % R
+        tot[0, i] = np.frombuffer(v.to_bytes(32, "little"), np.uint8)
+    assert zk.lib.zkp_ntt(logn, 1, tot.ctypes.data, 0) == 0
+    for i in range(0, n, 1231):
+        lhs = (int.from_bytes(y[0, i].tobytes(), "little") + int.from_bytes(y[1, i].tobytes(), "little")) % R
+        assert lhs == int.from_bytes(tot[0, i].tobytes(), "little")

@@ -186,6 +186,7 @@ def test_unsatisfiable_witness_is_flagged_per_instance(zk, oracle, algs):
 def test_reference_full_test_prove_then_verify_through_both_abis(zk, alg):
     """gnark/libraries/test_helpers.go:292-411 RunFullTest with the product on both sides: keys from ZkpSetup,
     prover.Prove(json) then verifier.Verify(json) must be true; js/src/tests/lib.test.ts:124-158: tampered -> false"""
+    zk.lib.ZkpAllowUnpinnedKeys(1)
     r1cs = zk.synth.r1cs_bytes(alg)
     pk, vk = zk.setup(r1cs, zk.synth.toxic_from_seed(7), raw=True)
     zk.lib.ZkpReset()
@@ -256,3 +257,39 @@ def test_extreme_inputs(zk, oracle, algs, alg):
 
 
 R_TEST = rf.R_MOD
+
+
+def test_full_size_batch_every_proof_verifies(zk, oracle):
+    """BASELINE config[1] at full size (ChaCha20, batch 1024): every proof of the batch passes the product's verifier
+    (itself cross-checked against the oracle's independent pairing in tests/test_verifier.py), a tampered one fails, and
+    sampled proofs are bit-identical to the oracle's."""
+    from concurrent.futures import ThreadPoolExecutor
+    zk.lib.ZkpAllowUnpinnedKeys(1)
+    alg, B = 0, 1024
+    r1cs = zk.synth.r1cs_bytes(alg)
+    pk, vk = zk.setup(r1cs, zk.synth.toxic_from_seed(1), raw=True)
+    zk.lib.ZkpReset()
+    assert zk.init_algorithm(alg, pk, r1cs) and zk.init_verifier(alg, vk)
+    rng = H.SplitMix64(0x5EED0000 + 1)
+    insts = [H.make_instance(alg, rng) for _ in range(B)]
+    wits, outs = [], []
+    for inst in insts:
+        _, w, out = zk.request_witness(H.request_json(alg, inst))
+        wits.append(w); outs.append(out)
+    rb = zk.ResidentBatch(alg, np.array(wits, np.uint32), [i["r"] for i in insts], [i["s"] for i in insts], [0] * B)
+    rb.steps(2)
+    proofs, errs = rb.fetch()
+    assert not errs.any()
+    ser = [zk.proof_serialize(proofs[k], False) for k in range(B)]
+    assert len(set(ser)) == B
+
+    def check(k):
+        return zk.verify(H.CIPHER[alg], ser[k], outs[k], list(zip(insts[k]["nonces"], insts[k]["counters"])), insts[k]["data"])
+    with ThreadPoolExecutor(max_workers=16) as ex:
+        ok = list(ex.map(check, range(B)))
+    assert all(ok), "instances failing verification: %s" % [k for k, v in enumerate(ok) if not v][:10]
+    assert not zk.verify(H.CIPHER[alg], ser[0], outs[1], list(zip(insts[0]["nonces"], insts[0]["counters"])), insts[0]["data"])
+    for k in (0, 511, 1023):
+        exp, out, *_ = H.oracle_proof_bytes(alg, dict(insts[k], randomize=0))
+        assert ser[k] == exp and outs[k] == out
+    zk.lib.ZkpReset()
