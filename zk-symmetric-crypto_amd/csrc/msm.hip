@@ -459,17 +459,39 @@ __global__ __launch_bounds__(256) void k_msm_ones(const Affine<F> *__restrict__ 
     const size_t j0 = chunk * ONES_CHUNK;
     const size_t j1 = j0 + ONES_CHUNK < n ? j0 + ONES_CHUNK : n;
     const Fr one = Fr::one(), mone = fr_minus_one();
-    uint32_t pos[4] = {0, 0, 0, 0}, neg[4] = {0, 0, 0, 0};
-    for (size_t j = j0; j < j1; j++) {
-        const Fr s = scalars[(size_t)rows[j] * B + b];
-        if (s.is_zero()) continue;
-        const uint32_t k = (uint32_t)(j - j0);
-        if (s == one) pos[k >> 5] |= 1u << (k & 31);
-        else if (s == mone) neg[k >> 5] |= 1u << (k & 31);
-        else {
+    uint32_t pos[4] = {0, 0, 0, 0}, neg[4] = {0, 0, 0, 0}, gen[4] = {0, 0, 0, 0};
+    // eight scalar rows are loaded together (unconditional loads, tail clamped) so that the scan is not 128 dependent
+    // memory round trips
+    for (size_t jb = j0; jb < j1; jb += 8) {
+        Fr sv[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const size_t j = jb + q < j1 ? jb + q : j1 - 1;
+            sv[q] = scalars[(size_t)rows[j] * B + b];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            if (jb + q >= j1) break;
+            const Fr &s = sv[q];
+            if (s.is_zero()) continue;
+            const uint32_t k = (uint32_t)(jb + q - j0);
+            if (s == one) pos[k >> 5] |= 1u << (k & 31);
+            else if (s == mone) neg[k >> 5] |= 1u << (k & 31);
+            else gen[k >> 5] |= 1u << (k & 31);
+        }
+    }
+    // wide scalars (6 % of the AES wires) are only MARKED above: appending them inside the scan would make every wavefront
+    // pay an atomic + a Montgomery conversion in almost all of its 128 iterations; here each lane walks just its own few
+#pragma unroll
+    for (int wd = 0; wd < 4; wd++) {
+        uint32_t m = gen[wd];
+        while (m) {
+            const int bit = __ffs((int)m) - 1;
+            m &= m - 1;
+            const size_t j = j0 + wd * 32 + bit;
             const uint32_t q = atomicAdd(&gen_count[b], 1u);
             gen_idx[b * n + q] = (uint32_t)j;
-            gen_val[b * n + q] = s.from_mont();
+            gen_val[b * n + q] = scalars[(size_t)rows[j] * B + b].from_mont();
         }
     }
     XYZZ<F> acc = XYZZ<F>::inf();
