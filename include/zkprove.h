@@ -84,8 +84,9 @@ int zkp_bench_step(int algorithmID, float *times7);
  * times8: phase times of the last pass, [6] = whole call / nsteps */
 int zkp_bench_steps(int algorithmID, int nsteps, float *times8);
 int zkp_bench_fetch(int algorithmID, uint8_t *proofs, uint32_t *errs);
-/* after a step: copy out the solved wire vectors [batch][n_wires][32] and quotient coefficients
- * [batch][N][32] (canonical LE, natural order) -- parity tests only */
+/* after a step: copy out the solved wire vectors [batch][n_wires][32] and the quotient-stage products
+ * f_i = A(g w^i) * B(g w^i) [batch][N][32] (canonical LE, natural order; the scalars of the folded quotient MSM, see
+ * csrc/keyfold.hip) -- parity tests only */
 int zkp_debug_fetch(int algorithmID, uint8_t *wires, uint8_t *h);
 /* request -> witness assignment (host logic only, no GPU): fills inputs[n_inputs], output bytes; returns
  * 0, or -1 with the reference's panic text in zkp_last_error() */
@@ -108,6 +109,10 @@ int zkp_msm_g1(long n, long batch, const uint8_t *points, const uint8_t *scalars
 int zkp_msm_g2(long n, long batch, const uint8_t *points, const uint8_t *scalars, uint8_t *out, int c);
 /* same as zkp_msm_g1 through the dense (quotient-MSM) sort path: no 0/+-1 fast path, two-level sort when c >= 9 */
 int zkp_msm_g1_dense(long n, long batch, const uint8_t *points, const uint8_t *scalars, uint8_t *out, int c);
+/* Key folding done at InitAlgorithm (csrc/keyfold.hip): pk.G1.Z (2^logn - 1 points, 64 B canonical LE x|y each) ->
+ * ze[i] = 1/(N D) sum_k w^-ik g^-k Z_k (2^logn points) and zc[j] = -1/(N D) sum_k w^-jk Z_k (ncons points), D = g^N - 1;
+ * replaces the last four transforms of gnark's computeH (backend/groth16/bn254/prove.go) per proof. */
+int zkp_fold_quotient_bases(int logn, long ncons, const uint8_t *z, uint8_t *ze, uint8_t *zc);
 /* kind 0: Fp mul (2/iter) 1: G1 mixed add 2: G2 mixed add; returns milliseconds */
 double zkp_microbench(int kind, long threads, int iters);
 

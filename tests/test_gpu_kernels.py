@@ -145,6 +145,28 @@ def test_msm_dense_all_equal_scalars_overflows_lds_bins(zk, oracle):
     assert np.array_equal(got, exp)
 
 
+@pytest.mark.parametrize("logn,ncons", [(1, 2), (3, 5), (6, 64), (9, 300)])
+def test_fold_quotient_bases_matches_definition(zk, oracle, logn, ncons):
+    """InitAlgorithm's key folding (csrc/keyfold.hip): with Z_k = z_k * G the folded bases are known multiples of G:
+    Ze_i = [1/(N D) sum_{k<N-1} w^-ik g^-k z_k] G,  Zc_j = [-1/(N D) sum_{k<N-1} w^-jk z_k] G"""
+    rng = np.random.default_rng(31 + logn)
+    N = 1 << logn
+    zs = _rand_fr(rng, N - 1)
+    if N > 4:
+        zs[2] = 0                                            # a point at infinity inside the key
+    z = oracle.le32_to_ints(zs)
+    pts = oracle.g1_fixed_base(zs)
+    w = pow(5, (R - 1) // N, R)
+    winv, ginv = pow(w, -1, R), pow(5, -1, R)
+    nd_inv = pow(N * (pow(5, N, R) - 1), -1, R)
+    ze_s = [nd_inv * sum(pow(winv, i * k, R) * pow(ginv, k, R) * z[k] for k in range(N - 1)) % R for i in range(N)]
+    zc_s = [-nd_inv * sum(pow(winv, j * k, R) * z[k] for k in range(N - 1)) % R for j in range(ncons)]
+    ze, zc = np.zeros((N, 64), np.uint8), np.zeros((ncons, 64), np.uint8)
+    assert zk.lib.zkp_fold_quotient_bases(logn, ncons, pts.ctypes.data, ze.ctypes.data, zc.ctypes.data) == 0, zk.last_error()
+    assert np.array_equal(ze, oracle.g1_fixed_base(oracle.ints_to_le32(ze_s)))
+    assert np.array_equal(zc, oracle.g1_fixed_base(oracle.ints_to_le32(zc_s)))
+
+
 def test_full_size_ntt_round_trip_and_linearity(zk):
     """N = 2^16 (the ChaCha domain), batch 64: inverse(forward(x)) == x through both kernel families, and the transform is
     linear -- size-independent properties at a size the CPU oracle would take minutes for"""

@@ -111,6 +111,17 @@ ZK_HD XYZZ<F> scalar_mul(const Affine<F> &p, const uint32_t *k, int nbits = 254)
     return acc;
 }
 
+// same with a projective base point (key folding at InitAlgorithm, keyfold.hip)
+template <class F>
+ZK_HD XYZZ<F> scalar_mul_x(const XYZZ<F> &p, const uint32_t *k, int nbits = 254) {
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (int i = nbits - 1; i >= 0; i--) {
+        acc = acc.dbl();
+        if ((k[i >> 5] >> (i & 31)) & 1) acc.add(p);
+    }
+    return acc;
+}
+
 using G1Affine = Affine<Fp>;
 using G2Affine = Affine<Fp2>;
 using G1XYZZ = XYZZ<Fp>;

@@ -16,6 +16,8 @@ struct NttDomain {
     void dif(Fr *data, size_t B, bool inverse, const Fr *postmul, hipStream_t s) const;
     void dit(Fr *data, size_t B, bool inverse, const Fr *premul, hipStream_t s) const;
     void compute_h(Fr *a, Fr *b, Fr *c, size_t B, hipStream_t s) const;
+    // a, b (per-constraint values) -> evaluations of their interpolants on the coset g<w>, natural order
+    void to_coset(Fr *a, Fr *b, size_t B, hipStream_t s) const;
     void scale_ninv(Fr *a, size_t B, hipStream_t s) const;
 };
 void fr_to_mont(Fr *a, size_t total, hipStream_t s);
@@ -70,6 +72,20 @@ void msm_batch(const MsmBasesG2 &mb, const Fr *scalars, size_t B, MsmScratch &sc
 
 // instance-major copy: out[b * stride + i] = in[i * B + b]
 void fr_transpose(const Fr *in, Fr *out, size_t rows, size_t B, size_t stride, hipStream_t s);
+// out[b * stride + i] = x[i * B + b] * y[i * B + b]
+void fr_transpose_mul(const Fr *x, const Fr *y, Fr *out, size_t rows, size_t B, size_t stride, hipStream_t s);
+
+// ------------------------------------------------------------------------------- key folding (keyfold.hip)
+// Unscaled inverse DFT over G1: out[i] = sum_k w^{-ik} * data[k] for i < n_out (natural order; data is destroyed)
+void g1_point_idft(G1XYZZ *data, const NttDomain &dom, size_t n_out, G1Affine *out, hipStream_t s);
+// pk.G1.Z (N-1 points, Montgomery affine) -> evaluation-form bases Ze (N points) and the constraint-value bases Zc
+void fold_quotient_bases(const G1Affine *d_z, const NttDomain &dom, size_t n_constraints, G1Affine *d_zeval, G1Affine *d_zc, hipStream_t s);
+// one non-zero of the R1CS output matrix: constraint `cons` has the term coeffs[coeff] * wire
+struct OutputTerm { uint32_t wire, cons, coeff; };
+// K'_w = K_w + sum over the terms of wire w of coeffs[coeff] * Zc[cons].  d_k: pk.G1.K points of the wires rows_k (ascending).
+// out_rows (ascending) = rows_k united with the wires of the terms; out_points[i] = K'_{out_rows[i]}.  d_coeffs: Montgomery.
+void fold_output_matrix(const G1Affine *d_zc, const G1Affine *d_k, const std::vector<uint32_t> &rows_k, std::vector<OutputTerm> terms,
+                        const Fr *d_coeffs, DevBuf<G1Affine> &out_points, std::vector<uint32_t> &out_rows, hipStream_t s);
 
 // number of XYZZ partial slots per instance that msm_batch needs in MsmScratch::part*
 size_t msm_part_stride(size_t n, int c);

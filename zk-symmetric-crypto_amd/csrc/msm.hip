@@ -538,6 +538,29 @@ __global__ __launch_bounds__(256) void k_transpose_fr(const Fr *__restrict__ in,
 void fr_transpose(const Fr *in, Fr *out, size_t rows, size_t B, size_t stride, hipStream_t s) {
     hipLaunchKernelGGL(k_transpose_fr, dim3(ceil_div(rows, 32), ceil_div(B, 32)), dim3(256), 0, s, in, out, rows, B, stride);
 }
+// same, of the element-wise product: out[b * stride + i] = x[i * B + b] * y[i * B + b]   (quotient stage: f = A*B on the coset)
+__global__ __launch_bounds__(256) void k_transpose_mul_fr(const Fr *__restrict__ x, const Fr *__restrict__ y, Fr *__restrict__ out, size_t rows, size_t B, size_t stride) {
+    __shared__ uint4 tile[2][32][33];
+    const size_t i0 = (size_t)blockIdx.x * 32, b0 = (size_t)blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+    uint4 *dst = (uint4 *)out;
+    for (int r = ty; r < 32; r += 8) {
+        const size_t i = i0 + r, b = b0 + tx;
+        if (i < rows && b < B) {
+            const Fr p = x[i * B + b] * y[i * B + b];
+            tile[0][r][tx] = make_uint4(p.l[0], p.l[1], p.l[2], p.l[3]);
+            tile[1][r][tx] = make_uint4(p.l[4], p.l[5], p.l[6], p.l[7]);
+        }
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const size_t b = b0 + r, i = i0 + tx;
+        if (i < rows && b < B) { dst[(b * stride + i) * 2] = tile[0][tx][r]; dst[(b * stride + i) * 2 + 1] = tile[1][tx][r]; }
+    }
+}
+void fr_transpose_mul(const Fr *x, const Fr *y, Fr *out, size_t rows, size_t B, size_t stride, hipStream_t s) {
+    hipLaunchKernelGGL(k_transpose_mul_fr, dim3(ceil_div(rows, 32), ceil_div(B, 32)), dim3(256), 0, s, x, y, out, rows, B, stride);
+}
 
 // out[b*out_stride + g] = sum_{i < group} in[b*in_stride + g*group + i]   (i bounded by count)
 template <class F>
@@ -597,7 +620,7 @@ static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, M
     if (mb.dense) {
         // scalars = instance-major [B][dense_stride] copy; no +-1 fast path (every quotient coefficient is wide)
         ZK_HIP(hipMemsetAsync(part, 0, B * stride * sizeof(XYZZ<F>), s));
-        if (c - 1 > FINE_BITS && c - 1 - FINE_BITS <= 8 && W <= 24 && n * (size_t)W < (1u << 21) && sc.entries2.n >= B * max_entries + 1) {
+        if (c - 1 > FINE_BITS && c - 1 - FINE_BITS <= 8 && W <= 24 && n * (size_t)W <= (1u << 21) && sc.entries2.n >= B * max_entries + 1) {
             static bool attr2 = false;
             const size_t lds2 = (size_t)(PART_THREADS / 64 * MAX_COARSE + (MAX_COARSE + 1) + 3 * MAX_COARSE + 2 * PART_THREADS * (size_t)W) * sizeof(uint32_t);
             if (!attr2) { ZK_HIP(hipFuncSetAttribute((const void *)k_msm_partition, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)); attr2 = true; }

@@ -421,6 +421,16 @@ void NttDomain::compute_h(Fr *a, Fr *b, Fr *c, size_t B, hipStream_t s) const {
     ZK_HIP(hipGetLastError());
 }
 
+// The prover's quotient stage (see keyfold.hip): only a and b are transformed; the remaining linear maps of computeH
+// live in the folded bases.
+void NttDomain::to_coset(Fr *a, Fr *b, size_t B, hipStream_t s) const {
+    dif(a, B, true, nullptr, s);
+    dif(b, B, true, nullptr, s);
+    dit(a, B, false, coset_pre.p, s);
+    dit(b, B, false, coset_pre.p, s);
+    ZK_HIP(hipGetLastError());
+}
+
 // plain scaling by 1/n (used by the stand-alone inverse transform entry point)
 __global__ void k_scale_ninv(Fr *a, const Fr *consts, size_t total) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -18,7 +18,7 @@ struct ProvingKeyDev {
     DevBuf<G2Affine> g2_misc;   // beta, delta
     DevBuf<G1Affine> delta_tab; // fixed-base table of delta (8-bit windows)
     DevBuf<G2Affine> delta2_tab;
-    MsmBasesG1 A, B1, K, Z, ped, ped_sigma;
+    MsmBasesG1 A, B1, K, Z, ped, ped_sigma;   // Z and K hold pk.G1.Z / pk.G1.K in the folded form of keyfold.hip
     MsmBasesG2 B2;
     size_t n_ped = 0;
 };

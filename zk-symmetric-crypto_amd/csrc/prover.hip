@@ -191,16 +191,28 @@ void Algorithm::load(const uint8_t *pkb, size_t pk_len, const uint8_t *r1cs_byte
     hipLaunchKernelGGL(k_fixed_table<Fp2>, dim3(ceil_div(32 * 255, 64)), dim3(64), 0, st, pk.g2_misc.p + 1, pk.delta2_tab.p);
     upload_g1(pkb, sA, pts, st); msm_bases_build(pk.A, pts.p, sA.n, rowsA.data(), C_WIRE, st);
     upload_g1(pkb, sB, pts, st); msm_bases_build(pk.B1, pts.p, sB.n, rowsB.data(), C_WIRE, st);
-    upload_g1(pkb, sK, pts, st); msm_bases_build(pk.K, pts.p, sK.n, rowsK.data(), C_WIRE, st);
-    {   // H comes out of computeH in bit-reversed coefficient order: store the Z bases in that order so that the
-        // (dense, instance-major) scalar vector is consumed linearly.  bitrev(N-1) = N-1, so positions 0..N-2 cover Z_0..Z_{N-2}.
+    {   // quotient bases in evaluation form (keyfold.hip): Z becomes one base per coset point (dense MSM over A*B on the coset),
+        // and the part of the quotient that is linear in the wires (through c = O w) moves into the bases of K.
         upload_g1(pkb, sZ, pts, st);
-        std::vector<G1Affine> hz(sZ.n), hp(sZ.n);
-        ZK_HIP(hipMemcpy(hz.data(), pts.p, sZ.n * sizeof(G1Affine), hipMemcpyDeviceToHost));
-        for (size_t i = 0; i + 1 < N; i++) hp[i] = hz[bitrev32((uint32_t)i, logn)];
-        ZK_HIP(hipMemcpy(pts.p, hp.data(), sZ.n * sizeof(G1Affine), hipMemcpyHostToDevice));
-        msm_bases_build(pk.Z, pts.p, sZ.n, nullptr, C_H, st);
+        const size_t ncons = cs.nb_constraints;
+        DevBuf<G1Affine> ze(N), zc(ncons);
+        fold_quotient_bases(pts.p, dom, ncons, ze.p, zc.p, st);
+        msm_bases_build(pk.Z, ze.p, N, nullptr, C_H, st);
         pk.Z.dense_stride = N;
+        std::vector<OutputTerm> terms;
+        for (size_t i = 0; i < cs.nb_instructions(); i++) {
+            if (cs.bp_kind[cs.blueprint_id[i]] != BP_R1C) continue;
+            const uint32_t *cd = cs.calldata.data() + cs.start_calldata[i];
+            const uint32_t *p = cd + 4 + 2 * (size_t)(cd[1] + cd[2]);
+            for (uint32_t k = 0; k < cd[3]; k++, p += 2) terms.push_back(OutputTerm{p[1] == WIRE_CONST ? 0u : p[1], cs.constraint_offset[i], p[0]});
+        }
+        DevBuf<Fr> coeffs(cs.coeffs.size() + 1);
+        ZK_HIP(hipMemcpy(coeffs.p, cs.coeffs.data(), cs.coeffs.size() * sizeof(Fr), hipMemcpyHostToDevice));
+        upload_g1(pkb, sK, pts, st);
+        DevBuf<G1Affine> kf;
+        std::vector<uint32_t> rowsKf;
+        fold_output_matrix(zc.p, pts.p, rowsK, std::move(terms), coeffs.p, kf, rowsKf, st);
+        msm_bases_build(pk.K, kf.p, rowsKf.size(), rowsKf.data(), C_WIRE, st);
     }
     pk.n_ped = 0;
     if (has_commit) {
@@ -402,13 +414,16 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st) {
     Resident &R = *res;
     const size_t B = R.B;
     ZK_HIP(hipEventRecord(R.ev[3], st));
-    dom.compute_h(S.sb.a.p, S.sb.b.p, S.sb.c.p, B, st);
+    const size_t N = (size_t)1 << prog.log_domain;
+    dom.to_coset(S.sb.a.p, S.sb.b.p, B, st);
     ZK_HIP(hipEventRecord(R.ev[4], st));
     msm_batch(pk.A, S.sb.wires.p, B, R.ms, R.m_ar.p, st);
     msm_batch(pk.B1, S.sb.wires.p, B, R.ms, R.m_bs1.p, st);
     msm_batch(pk.K, S.sb.wires.p, B, R.ms, R.m_k.p, st);
-    fr_transpose(S.sb.a.p, S.sb.b.p, (size_t)1 << prog.log_domain, B, (size_t)1 << prog.log_domain, st);   // b is free after computeH
-    msm_batch(pk.Z, S.sb.b.p, B, R.ms, R.m_z.p, st, &R.ev[8]);
+    // sum_k h_k Z_k = sum_i (a_i b_i) Ze_i + (a part linear in the wires that sits in K); c only serves as the buffer of the
+    // instance-major products
+    fr_transpose_mul(S.sb.a.p, S.sb.b.p, S.sb.c.p, N, B, N, st);
+    msm_batch(pk.Z, S.sb.c.p, B, R.ms, R.m_z.p, st, &R.ev[8]);
     ZK_HIP(hipEventRecord(R.ev[5], st));
     msm_batch(pk.B2, S.sb.wires.p, B, R.ms, R.m_bs2.p, st);
     ZK_HIP(hipEventRecord(R.ev[6], st));
@@ -507,11 +522,11 @@ void Algorithm::prove_batch(size_t batch, const uint32_t *inputs, const U256 *r,
     if (times) *times = tot;
 }
 
-// parity-test hook: solved wires and quotient coefficients of the last resident batch, canonical form
+// parity-test hook: solved wires and quotient-stage products (A*B on the coset g<w>, natural order) of the last resident
+// batch, canonical form
 void Algorithm::debug_fetch(uint8_t *wires_out, uint8_t *h_out) {
     Resident &R = *res;
     const size_t B = R.B, nw = prog.n_wires, N = (size_t)1 << prog.log_domain;
-    const int logn = prog.log_domain;
     std::vector<Fr> tmp;
     auto fetch = [&](const Fr *src, size_t rows) {
         DevBuf<Fr> d(rows * B);
@@ -525,10 +540,11 @@ void Algorithm::debug_fetch(uint8_t *wires_out, uint8_t *h_out) {
         for (size_t b = 0; b < B; b++)
             for (size_t w = 0; w < nw; w++) memcpy(wires_out + (b * nw + w) * 32, &tmp[w * B + b], 32);
     }
-    if (h_out) {
-        fetch(R.set[0].sb.a.p, N);
-        for (size_t b = 0; b < B; b++)
-            for (size_t k = 0; k < N; k++) memcpy(h_out + (b * N + k) * 32, &tmp[(size_t)bitrev32((uint32_t)k, logn) * B + b], 32);
+    if (h_out) {   // instance-major products f = A*B on the coset, as left in c by enqueue_main
+        DevBuf<Fr> d(N * B);
+        ZK_HIP(hipMemcpy(d.p, R.set[0].sb.c.p, N * B * sizeof(Fr), hipMemcpyDeviceToDevice));
+        fr_from_mont(d.p, N * B, 0);
+        ZK_HIP(hipMemcpy(h_out, d.p, N * B * sizeof(Fr), hipMemcpyDeviceToHost));
     }
 }
 

@@ -164,6 +164,31 @@ void fp_to_mont_dev(void *p, size_t count, hipStream_t s) {
     if (count) hipLaunchKernelGGL(zk::k_fp_to_mont, dim3(ceil_div(count, 256)), dim3(256), 0, s, (Fp *)p, count);
 }
 
+namespace zk {
+__global__ void k_fp_from_mont(Fp *a, size_t total) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) a[i] = a[i].from_mont();
+}
+}
+// key folding (keyfold.hip): z = pk.G1.Z, (2^logn - 1) * 64 canonical LE (x|y) -> ze: 2^logn * 64, zc: ncons * 64
+extern "C" int zkp_fold_quotient_bases(int logn, long ncons, const uint8_t *z, uint8_t *ze, uint8_t *zc) {
+    ZKP_TRY
+    const size_t N = (size_t)1 << logn, nc = (size_t)ncons;
+    if (nc > N || nc == 0) throw ZkError("zkp_fold_quotient_bases: bad constraint count");
+    NttDomain dom;
+    dom.init(logn, 0);
+    DevBuf<G1Affine> dz(N), dze(N), dzc(nc);
+    ZK_HIP(hipMemcpy(dz.p, z, (N - 1) * 64, hipMemcpyHostToDevice));
+    fp_to_mont_dev(dz.p, (N - 1) * 2, 0);
+    fold_quotient_bases(dz.p, dom, nc, dze.p, dzc.p, 0);
+    hipLaunchKernelGGL(zk::k_fp_from_mont, dim3(ceil_div(N * 2, 256)), dim3(256), 0, 0, (Fp *)dze.p, N * 2);
+    hipLaunchKernelGGL(zk::k_fp_from_mont, dim3(ceil_div(nc * 2, 256)), dim3(256), 0, 0, (Fp *)dzc.p, nc * 2);
+    ZK_HIP(hipMemcpy(ze, dze.p, N * 64, hipMemcpyDeviceToHost));
+    ZK_HIP(hipMemcpy(zc, dzc.p, nc * 64, hipMemcpyDeviceToHost));
+    return 0;
+    ZKP_CATCH(-1)
+}
+
 // -------- micro-benchmarks: raw field-multiplication / point-addition throughput on the device
 namespace zk {
 template <class F>
