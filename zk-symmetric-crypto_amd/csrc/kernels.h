@@ -33,7 +33,7 @@ struct MsmBases {
     int c = 0;             // window bits (signed digits, 2^(c-1) buckets)
     int W = 0;             // windows
     DevBuf<Affine<F>> table;
-    DevBuf<Affine<F>> base;        // the n base points themselves, contiguous (conditional-sum path)
+    DevBuf<Affine<F>> tern;        // conditional-sum path: signed subset sums of every group of 6 bases (msm.hip, TERN_*)
     DevBuf<uint32_t> scalar_row;   // row index of the scalar of point j in the [row][B] scalar matrix
     bool dense = false;            // quotient MSM: all scalars wide, read from an instance-major copy [B][dense_stride]
     size_t dense_stride = 0;

@@ -26,7 +26,14 @@
 namespace zk {
 
 static constexpr int SEG_LOG = 6;            // L = 64 buckets per segment
-static constexpr int ONES_CHUNK = 128;       // base points per conditional-sum thread
+// Conditional-sum path (scalars 0 / +1 / -1): bases are taken TERN_G at a time and every signed subset sum of a group is
+// precomputed, so a group costs one mixed addition whatever its +-1 pattern is.  Index of a pattern: sum (t_i + 1) 3^i,
+// t_i in {-1, 0, +1}; the patterns above the centre (all zero) are stored, the ones below are their negatives.
+static constexpr int TERN_G = 6;
+static constexpr int TERN_CENTER = 364;                    // (3^6 - 1) / 2
+static constexpr int TERN_ENTRIES = 364;                   // patterns 365 .. 728
+static constexpr int ONES_GROUPS = 20;                     // groups per conditional-sum thread
+static constexpr int ONES_CHUNK = TERN_G * ONES_GROUPS;    // base points per conditional-sum thread
 static constexpr int SORT_THREADS = 1024;
 
 // ------------------------------------------------------------------------------ table precompute
@@ -48,6 +55,25 @@ __global__ __launch_bounds__(256) void k_xyzz_to_affine(const XYZZ<F> *__restric
     out[i] = in[i].to_affine();
 }
 
+// tern[g * TERN_ENTRIES + e] = sum_i t_i * P_{6g+i} for the pattern e + TERN_CENTER + 1
+template <class F>
+__global__ __launch_bounds__(256) void k_ternary_table(const Affine<F> *__restrict__ pts, size_t n, size_t ngroups, Affine<F> *__restrict__ out) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ngroups * TERN_ENTRIES) return;
+    const size_t g = t / TERN_ENTRIES;
+    uint32_t pat = (uint32_t)(t % TERN_ENTRIES) + TERN_CENTER + 1;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (int i = 0; i < TERN_G; i++, pat /= 3) {
+        const uint32_t d = pat % 3;
+        const size_t j = g * TERN_G + i;
+        if (d == 1 || j >= n) continue;
+        Affine<F> p = pts[j];
+        if (d == 0) p.y = p.y.neg();
+        acc.madd(p);
+    }
+    out[t] = acc.to_affine();
+}
+
 template <class F>
 static void bases_build(MsmBases<F> &mb, const Affine<F> *d_points, size_t n, const uint32_t *h_rows, int c, hipStream_t s) {
     mb.n = n; mb.c = c; mb.W = (254 + c - 1) / c;
@@ -56,9 +82,10 @@ static void bases_build(MsmBases<F> &mb, const Affine<F> *d_points, size_t n, co
     if (n && h_rows) ZK_HIP(hipMemcpyAsync(mb.scalar_row.p, h_rows, n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
     size_t tot = n * mb.W;
     mb.table.alloc(tot ? tot : 1);
-    mb.base.alloc(n ? n : 1);
+    const size_t ngroups = mb.dense ? 0 : (n + TERN_G - 1) / TERN_G;
+    mb.tern.alloc(ngroups ? ngroups * TERN_ENTRIES : 1);
     if (!n) return;
-    ZK_HIP(hipMemcpyAsync(mb.base.p, d_points, n * sizeof(Affine<F>), hipMemcpyDeviceToDevice, s));
+    if (ngroups) hipLaunchKernelGGL(k_ternary_table<F>, dim3(ceil_div(ngroups * TERN_ENTRIES, 256)), dim3(256), 0, s, d_points, n, ngroups, mb.tern.p);
     // chunked to bound the XYZZ temp
     const size_t CH = 1 << 16;
     DevBuf<XYZZ<F>> tmp(CH * mb.W);
@@ -443,15 +470,15 @@ __global__ __launch_bounds__(64) void k_msm_bucket_reduce(const XYZZ<F> *__restr
 
 // thread (chunk, b): lanes = consecutive instances.  Scalars +-1 are summed here; scalars that are neither 0 nor
 // +-1 are appended (index + canonical value) to the instance's compact list for the bucket pipeline.
-// Two phases per thread: (1) classify the chunk's 128 scalars into +1 / -1 bit masks (coalesced row reads),
-// (2) walk the set bits only -- a wavefront then runs max-over-lanes(popcount) ~ 77 mixed additions instead of
-// 128 predicated ones (49 % of the ChaCha wire scalars are +-1).
+// Two phases per thread: (1) classify the chunk's 120 scalars, one group of 6 (coalesced row reads) at a time, into the
+// group's pattern index, (2) one mixed addition per non-empty group with the group's precomputed signed subset sum --
+// 20 additions per wavefront and chunk where adding the +-1 bases one by one took ~77 (49 % of the ChaCha wire scalars
+// are +-1, and a wavefront runs the maximum over its lanes).
 template <class F>
-__global__ __launch_bounds__(256) void k_msm_ones(const Affine<F> *__restrict__ base, const Fr *__restrict__ scalars, size_t B,
+__global__ __launch_bounds__(256) void k_msm_ones(const Affine<F> *__restrict__ tern, const Fr *__restrict__ scalars, size_t B,
                                                   const uint32_t *__restrict__ rows, size_t n, XYZZ<F> *__restrict__ part,
                                                   size_t part_stride, size_t part_off, uint32_t *__restrict__ gen_count,
                                                   uint32_t *__restrict__ gen_idx, Fr *__restrict__ gen_val) {
-    static_assert(ONES_CHUNK == 128, "mask layout");
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t nchunks = (n + ONES_CHUNK - 1) / ONES_CHUNK;
     if (t >= nchunks * B) return;
@@ -459,29 +486,35 @@ __global__ __launch_bounds__(256) void k_msm_ones(const Affine<F> *__restrict__ 
     const size_t j0 = chunk * ONES_CHUNK;
     const size_t j1 = j0 + ONES_CHUNK < n ? j0 + ONES_CHUNK : n;
     const Fr one = Fr::one(), mone = fr_minus_one();
-    uint32_t pos[4] = {0, 0, 0, 0}, neg[4] = {0, 0, 0, 0}, gen[4] = {0, 0, 0, 0};
-    // eight scalar rows are loaded together (unconditional loads, tail clamped) so that the scan is not 128 dependent
-    // memory round trips
-    for (size_t jb = j0; jb < j1; jb += 8) {
-        Fr sv[8];
+    uint32_t pat[ONES_GROUPS];                 // pattern index per group (fully unrolled: stays in registers)
+    uint32_t gen[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const size_t j = jb + q < j1 ? jb + q : j1 - 1;
-            sv[q] = scalars[(size_t)rows[j] * B + b];
-        }
+    for (int g = 0; g < ONES_GROUPS; g++) {
+        const size_t jb = j0 + (size_t)g * TERN_G;
+        uint32_t idx = TERN_CENTER;
+        if (jb < j1) {
+            // the six scalar rows of a group are loaded together (unconditional loads, tail clamped)
+            Fr sv[TERN_G];
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-            if (jb + q >= j1) break;
-            const Fr &s = sv[q];
-            if (s.is_zero()) continue;
-            const uint32_t k = (uint32_t)(jb + q - j0);
-            if (s == one) pos[k >> 5] |= 1u << (k & 31);
-            else if (s == mone) neg[k >> 5] |= 1u << (k & 31);
-            else gen[k >> 5] |= 1u << (k & 31);
+            for (int q = 0; q < TERN_G; q++) {
+                const size_t j = jb + q < j1 ? jb + q : j1 - 1;
+                sv[q] = scalars[(size_t)rows[j] * B + b];
+            }
+            uint32_t p3 = 1;
+#pragma unroll
+            for (int q = 0; q < TERN_G; q++, p3 *= 3) {
+                if (jb + q >= j1) break;
+                const Fr &s = sv[q];
+                if (s.is_zero()) continue;
+                if (s == one) idx += p3;
+                else if (s == mone) idx -= p3;
+                else { const uint32_t k = (uint32_t)(g * TERN_G + q); gen[k >> 5] |= 1u << (k & 31); }
+            }
         }
+        pat[g] = idx;
     }
     // wide scalars (6 % of the AES wires) are only MARKED above: appending them inside the scan would make every wavefront
-    // pay an atomic + a Montgomery conversion in almost all of its 128 iterations; here each lane walks just its own few
+    // pay an atomic + a Montgomery conversion in almost all of its iterations; here each lane walks just its own few
 #pragma unroll
     for (int wd = 0; wd < 4; wd++) {
         uint32_t m = gen[wd];
@@ -495,25 +528,23 @@ __global__ __launch_bounds__(256) void k_msm_ones(const Affine<F> *__restrict__ 
         }
     }
     XYZZ<F> acc = XYZZ<F>::inf();
-    // walk the set bits with the next base point prefetched under the current mixed addition
-    uint64_t mlo = (uint64_t)(pos[0] | neg[0]) | ((uint64_t)(pos[1] | neg[1]) << 32);
-    uint64_t mhi = (uint64_t)(pos[2] | neg[2]) | ((uint64_t)(pos[3] | neg[3]) << 32);
-    const uint64_t nlo = (uint64_t)neg[0] | ((uint64_t)neg[1] << 32), nhi = (uint64_t)neg[2] | ((uint64_t)neg[3] << 32);
-    auto next_bit = [&]() -> int {          // index in [0,128) of the lowest remaining bit, -1 when done
-        if (mlo) { const int k = __ffsll((long long)mlo) - 1; mlo &= mlo - 1; return k; }
-        if (mhi) { const int k = __ffsll((long long)mhi) - 1; mhi &= mhi - 1; return 64 + k; }
-        return -1;
+    const Affine<F> *tg = tern + chunk * ONES_GROUPS * (size_t)TERN_ENTRIES;
+    // group g's addend: entry |pat - centre| - 1, negated when pat < centre; the next group's is loaded under the addition
+    auto fetch = [&](int g, uint32_t pt) -> Affine<F> {
+        const uint32_t e = pt > TERN_CENTER ? pt - TERN_CENTER - 1 : TERN_CENTER - 1 - pt;
+        return tg[(size_t)g * TERN_ENTRIES + e];
     };
-    int k = next_bit();
-    Affine<F> p = base[j0 + (k < 0 ? 0 : k)];
-    while (k >= 0) {
-        const int kn = next_bit();
-        Affine<F> pn = p;
-        if (kn >= 0) pn = base[j0 + kn];
-        const bool ng = k < 64 ? ((nlo >> k) & 1) : ((nhi >> (k - 64)) & 1);
-        if (ng) p.y = p.y.neg();
-        acc.madd(p);
-        k = kn; p = pn;
+    Affine<F> p = Affine<F>::inf();
+    if (pat[0] != TERN_CENTER) p = fetch(0, pat[0]);
+#pragma unroll
+    for (int g = 0; g < ONES_GROUPS; g++) {
+        Affine<F> pn = Affine<F>::inf();
+        if (g + 1 < ONES_GROUPS && pat[g + 1] != TERN_CENTER) pn = fetch(g + 1, pat[g + 1]);
+        if (pat[g] != TERN_CENTER) {
+            if (pat[g] < TERN_CENTER) p.y = p.y.neg();
+            acc.madd(p);
+        }
+        p = pn;
     }
     part[b * part_stride + part_off + chunk] = acc;
 }
@@ -636,7 +667,7 @@ static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, M
     } else {
         if (sc.gen_count.n < B || sc.gen_idx.n < B * n || sc.gen_val.n < B * n) throw ZkError("msm compact-list scratch too small");
         ZK_HIP(hipMemsetAsync(sc.gen_count.p, 0, B * sizeof(uint32_t), s));
-        hipLaunchKernelGGL(k_msm_ones<F>, dim3(ceil_div(nchunks * B, 256)), dim3(256), 0, s, mb.base.p, scalars, B, mb.scalar_row.p, n, part,
+        hipLaunchKernelGGL(k_msm_ones<F>, dim3(ceil_div(nchunks * B, 256)), dim3(256), 0, s, mb.tern.p, scalars, B, mb.scalar_row.p, n, part,
                            stride, (size_t)0, sc.gen_count.p, sc.gen_idx.p, sc.gen_val.p);
         hipLaunchKernelGGL(k_msm_sort<false>, dim3((unsigned)B), dim3(SORT_THREADS), lds, s, (const Fr *)nullptr, (size_t)0, sc.gen_count.p, sc.gen_idx.p,
                            sc.gen_val.p, n, c, W, sc.bucket_start.p, sc.entries.p, max_entries);
