@@ -55,7 +55,8 @@ class Algorithm {
     // device-resident variant for the benchmark: inputs already in HBM as [n_inputs][B] (see bench.py)
     struct Resident;
     void enqueue_solve(struct SolveSet &S, MsmScratch &commit_scratch, hipStream_t st);
-    void enqueue_main(struct SolveSet &S, hipStream_t st);
+    void enqueue_main(struct SolveSet &S, hipStream_t st, hipEvent_t before_msm = nullptr);
+    void enqueue_finalize(struct SolveSet &S, hipStream_t st);
     void collect_times(struct SolveSet &S, PhaseTimes *times);
     std::unique_ptr<Resident> res;
     void resident_reserve(size_t B);

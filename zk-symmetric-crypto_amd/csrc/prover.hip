@@ -120,8 +120,8 @@ struct Algorithm::Resident {
     DevBuf<G1Affine> ar_aff, bs1_aff;
     DevBuf<G1XYZZ> f_t, f_u, f_v;
     DevBuf<ProofPoints> out;
-    hipStream_t stream = nullptr, stream2 = nullptr;
-    hipEvent_t ev[10] = {};
+    hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr;
+    hipEvent_t ev[12] = {};     // [10] MSM sums of the current batch complete  [11] tail of the previous batch done
 };
 
 Algorithm::Algorithm() {}
@@ -131,6 +131,7 @@ Algorithm::~Algorithm() {
         for (auto &st : res->set) for (hipEvent_t e : {st.solved, st.consumed, st.t0, st.t1, st.t2, st.t3}) if (e) (void)hipEventDestroy(e);
         if (res->stream) (void)hipStreamDestroy(res->stream);
         if (res->stream2) (void)hipStreamDestroy(res->stream2);
+        if (res->stream3) (void)hipStreamDestroy(res->stream3);
     }
 }
 
@@ -326,6 +327,7 @@ void Algorithm::resident_reserve(size_t B) {
         res.reset(new Resident());
         ZK_HIP(hipStreamCreate(&res->stream));
         ZK_HIP(hipStreamCreate(&res->stream2));
+        ZK_HIP(hipStreamCreate(&res->stream3));
         for (auto &e : res->ev) ZK_HIP(hipEventCreate(&e));
     }
     Resident &R = *res;
@@ -409,14 +411,16 @@ void Algorithm::enqueue_solve(SolveSet &S, MsmScratch &commit_scratch, hipStream
     ZK_HIP(hipEventRecord(S.t3, st));
 }
 
-// NTT + MSM + tail of one solved batch on stream st.  R.ev[3..9] bracket the phases.
-void Algorithm::enqueue_main(SolveSet &S, hipStream_t st) {
+// NTT + MSM of one solved batch on stream st.  R.ev[3..9] bracket the phases.  before_msm (optional): an event the MSMs must
+// wait for -- they overwrite the per-batch sums that the previous batch's tail (on another stream) still reads.
+void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm) {
     Resident &R = *res;
     const size_t B = R.B;
     ZK_HIP(hipEventRecord(R.ev[3], st));
     const size_t N = (size_t)1 << prog.log_domain;
     dom.to_coset(S.sb.a.p, S.sb.b.p, B, st);
     ZK_HIP(hipEventRecord(R.ev[4], st));
+    if (before_msm) ZK_HIP(hipStreamWaitEvent(st, before_msm, 0));
     msm_batch(pk.A, S.sb.wires.p, B, R.ms, R.m_ar.p, st);
     msm_batch(pk.B1, S.sb.wires.p, B, R.ms, R.m_bs1.p, st);
     msm_batch(pk.K, S.sb.wires.p, B, R.ms, R.m_k.p, st);
@@ -427,6 +431,13 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st) {
     ZK_HIP(hipEventRecord(R.ev[5], st));
     msm_batch(pk.B2, S.sb.wires.p, B, R.ms, R.m_bs2.p, st);
     ZK_HIP(hipEventRecord(R.ev[6], st));
+}
+
+// Tail of one batch: blinding terms, Krs, canonical outputs.  1024-thread kernels with long dependent chains (two variable-base
+// scalar multiplications per proof): latency-bound, so the pipelined driver runs it on its own stream under the next batch.
+void Algorithm::enqueue_finalize(SolveSet &S, hipStream_t st) {
+    Resident &R = *res;
+    const size_t B = R.B;
     hipLaunchKernelGGL(k_finalize_stage1, dim3(ceil_div(B, 64), 3), dim3(64), 0, st, R.m_ar.p, R.m_bs1.p, pk.g1_misc.p, pk.delta_tab.p, R.r.p, R.s.p,
                        R.ar_aff.p, R.bs1_aff.p, R.f_t.p, B);
     hipLaunchKernelGGL(k_finalize_g2, dim3(ceil_div(B, 64)), dim3(64), 0, st, R.m_bs2.p, pk.g2_misc.p, pk.delta2_tab.p, R.s.p, R.out.p, B);
@@ -452,6 +463,7 @@ void Algorithm::resident_prove(PhaseTimes *times) {
     hipStream_t st = R.stream;
     enqueue_solve(R.set[0], R.ms, st);
     enqueue_main(R.set[0], st);
+    enqueue_finalize(R.set[0], st);
     ZK_HIP(hipStreamSynchronize(st));
     if (times) {
         collect_times(R.set[0], times);
@@ -475,16 +487,21 @@ void Algorithm::resident_prove_pipelined(int nsteps, PhaseTimes *times) {
             R.ms2.reserve_sums(R.cap, (size_t)1 << (pk.ped.c - 1), 1);
         }
     }
-    hipStream_t M = R.stream, S = R.stream2;
+    hipStream_t M = R.stream, S = R.stream2, F = R.stream3;
     ZK_HIP(hipEventRecord(R.ev[0], M));
     ZK_HIP(hipStreamWaitEvent(S, R.ev[0], 0));
+    ZK_HIP(hipStreamWaitEvent(F, R.ev[0], 0));
     enqueue_solve(R.set[0], has_commit ? R.ms2 : R.ms, S);
     ZK_HIP(hipEventRecord(R.set[0].solved, S));
     for (int k = 0; k < nsteps; k++) {
         SolveSet &cur = R.set[k & 1], &nxt = R.set[(k + 1) & 1];
         ZK_HIP(hipStreamWaitEvent(M, cur.solved, 0));
-        enqueue_main(cur, M);
-        ZK_HIP(hipEventRecord(cur.consumed, M));
+        enqueue_main(cur, M, k ? R.ev[11] : nullptr);
+        ZK_HIP(hipEventRecord(R.ev[10], M));
+        ZK_HIP(hipStreamWaitEvent(F, R.ev[10], 0));
+        enqueue_finalize(cur, F);
+        ZK_HIP(hipEventRecord(R.ev[11], F));
+        ZK_HIP(hipEventRecord(cur.consumed, F));
         if (k + 1 < nsteps) {
             if (k >= 1) ZK_HIP(hipStreamWaitEvent(S, nxt.consumed, 0));      // nxt's buffers were read by batch k-1
             enqueue_solve(nxt, has_commit ? R.ms2 : R.ms, S);
@@ -493,6 +510,7 @@ void Algorithm::resident_prove_pipelined(int nsteps, PhaseTimes *times) {
     }
     ZK_HIP(hipStreamSynchronize(S));
     ZK_HIP(hipStreamSynchronize(M));
+    ZK_HIP(hipStreamSynchronize(F));
     if (times) {
         collect_times(R.set[(nsteps - 1) & 1], times);
         float tot;
