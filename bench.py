@@ -150,6 +150,17 @@ def main():
                                  "64-byte window multiple per addition (traffic = 16 x 64 B per term by design, served mostly from MALL/HBM); "
                                  "mixed_add_peak = back-to-back G1 mixed additions measured by scripts/gpu_microbench.py; MFMA not applicable"},
         }
+        # the transforms (north_star asks for the achieved HBM fraction of MSM and NTT): algorithmic bytes = SURVEY 8(d)'s
+        # 7-transform figure of the reference (7 * N * 32 * 2 per proof); the folded pipeline executes 4 transforms in 3 HBM
+        # round trips each, timed with HIP events around the whole transform phase
+        n_dom = 1 << (16 if alg == 0 else 17)
+        ntt_model = 7 * n_dom * 32 * 2 * B
+        ntt_moved = 4 * n_dom * 32 * 2 * 3 * B
+        out["roofline_ntt"] = {"bound": "hbm", "kernel": "k_ntt_dif_lds / k_ntt_dit_lds passes of one batch (4 transforms)", "achieved": ntt_model / (mean["ntt"] * 1e-3) / 1e9,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ntt_model / (mean["ntt"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "phase_ms": mean["ntt"], "algorithmic_bytes": ntt_model, "bytes_moved_by_design": ntt_moved,
+                               "moved_GBps": ntt_moved / (mean["ntt"] * 1e-3) / 1e9,
+                               "note": "integer-ALU bound: one 254-bit Montgomery multiplication per butterfly; see DESIGN.md section 3"}
         if args.cpu_proofs != 0 and world == 1:
             # CPU baseline: scripts/cpu_baseline.py in its own interpreter (no GPU runtime): one single-threaded oracle
             # prover process per worker, forked after key generation; best of {cores/2, cores} workers

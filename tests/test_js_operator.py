@@ -107,3 +107,57 @@ def test_operator_proves_and_verifies_through_node(zk, oracle, tmp_path):
         proof = base64.b64decode(p64)
         assert len(proof) == 164
         assert pairing.groth16_verify(vkp, gf.proof_parse(proof), wit[:H.circuit(alg).r1cs.nb_public - 1])
+
+
+def test_zk_layer_chunking_and_counters(tmp_path):
+    """js/zk.js against the reference's rules (zk.ts:96-178, utils.ts:206-245): start counters, padding blocks, chunk split"""
+    script = ("const zk=require('./zk.js');"
+              "const s=zk.getPublicSignals({algorithm:'aes-128-ctr',key:Buffer.alloc(16,1),publicInput:{ciphertext:new Uint8Array(16).fill(7),iv:new Uint8Array(12),offsetBytes:240}});"
+              "const c=zk.getPublicSignals({algorithm:'chacha20',key:Buffer.from([...Array(32).keys()]),publicInput:{ciphertext:Buffer.from('Ladies and Gentlemen'),iv:Buffer.from('000000000000004a00000000','hex')}});"
+              "let err='';try{zk.getCounterForByteOffset('chacha20',5)}catch(e){err=e.message}"
+              "const r={aesCounters:s.noncesAndCounters.map(n=>n.counter),aesIn:Buffer.from(s.in).toString('hex'),aesLen:[s.in.length,s.out.length],"
+              "ccCounters:c.noncesAndCounters.map(n=>n.counter),ccOut:Buffer.from(c.out).toString('hex').slice(0,40),ccLen:c.in.length,"
+              "chunks:zk.splitToChunks('aes-128-ctr',{ciphertext:new Uint8Array(256),iv:new Uint8Array(12)}).map(c=>[c.offsetBytes,c.ciphertext.length]),err};"
+              "process.stdout.write('\\nRESULT '+JSON.stringify(r)+'\\n')")
+    r = _run_node(["-e", script])
+    assert r["aesCounters"] == [17, 18, 19, 20, 21]                       # AES-GCM payload starts at counter 2 (config.ts:35,50); offset 240 = block 15
+    assert r["aesIn"] == "07" * 16 + "00" * 64 and r["aesLen"] == [80, 80]
+    assert r["ccCounters"] == [1, 2] and r["ccLen"] == 128
+    assert r["ccOut"] == "6e2e359a2568f98041ba0728dd0d6981e97e7aec"          # RFC 8439 2.4.2 keystream, as chacha_test.go:123-152
+    assert r["chunks"] == [[0, 80], [80, 80], [160, 80], [240, 16]]
+    assert r["err"] == "offset(5) must be a multiple of block size(64)"
+
+
+@pytest.mark.gpu
+def test_config5_aes128_16_block_items_through_node(zk, oracle, tmp_path):
+    """BASELINE config 5 at full size: 256 records of 16 AES-128 blocks -> 4 chunk proofs each = 1024 proofs in one ProveBatch call
+    from Node; every 8th proof (and the last) is verified, a tampered plaintext is rejected, the plaintexts match the oracle's cipher"""
+    _addon()
+    alg = 1
+    d = str(tmp_path)
+    r1cs = zk.synth.r1cs_bytes(alg)
+    pk, vk = zk.setup(r1cs, zk.synth.toxic_from_seed(1), raw=True)
+    for name, data in (("pk.aes128", pk), ("r1cs.aes128", r1cs), ("vk.aes128", vk)):
+        with open(os.path.join(d, name), "wb") as f:
+            f.write(data)
+    rng = H.SplitMix64(0x5EED0000 + 4)
+    b64 = lambda b: base64.b64encode(bytes(b)).decode()
+    items = []
+    for _ in range(256):
+        items.append({"key": rng.bytes(16), "iv": rng.bytes(12), "ciphertext": rng.bytes(256)})
+    with open(os.path.join(d, "items.json"), "w") as f:
+        json.dump({"algorithm": "aes-128-ctr", "verifyStride": 8, "items": [{k: b64(v) for k, v in it.items()} for it in items]}, f)
+    r = _run_node([os.path.join("test", "run_items.js"), d], timeout=900)
+    assert "error" not in r, r.get("error")
+    assert r["items"] == 256 and r["proofs"] == 1024 and r["verified"] == 129 and r["rejected"] is True
+    assert r["proofBytes"] == 196
+    assert r["lastChunk"]["offsetBytes"] == 240 and r["lastChunk"]["bytes"] == 16
+    # plaintext of the first chunk = the oracle's AES-CTR keystream XOR (counters 2..6), of the last = block 17 then the keystream of 4 empty blocks
+    from oracle import witness as W
+    it = items[0]
+    _, out = W.aes_witness(it["key"], [it["iv"]] * 5, [2, 3, 4, 5, 6], it["ciphertext"][:80])
+    assert base64.b64decode(r["firstPlaintext"]) == bytes(out)
+    it = items[-1]
+    _, out = W.aes_witness(it["key"], [it["iv"]] * 5, [17, 18, 19, 20, 21], it["ciphertext"][240:] + bytes(64))
+    assert base64.b64decode(r["lastChunk"]["plaintext"]) == bytes(out)
+    print("config 5 through Node: %.1f items/s, %.1f proofs/s (prove %d ms, verify %d ms)" % (r["itemsPerS"], r["proofsPerS"], r["proveMs"], r["verifyMs"]))
