@@ -380,9 +380,9 @@ __global__ __launch_bounds__(256) void k_msm_binsort(const uint32_t *__restrict_
 // the reduce kernel reads emptiness from bucket_start).
 // DENSE only names the instantiation (quotient MSM vs. wire MSMs) so that profiler summaries keep the dominant launch apart.
 template <class F, bool DENSE>
-__global__ __launch_bounds__(64) void k_msm_accumulate(const Affine<F> *__restrict__ table, const uint32_t *__restrict__ bucket_start,
-                                                       const uint32_t *__restrict__ entries, size_t max_entries, int c, size_t B,
-                                                       uint32_t nlanes, XYZZ<F> *__restrict__ sums) {
+__device__ __forceinline__ void accumulate_body(const Affine<F> *__restrict__ table, const uint32_t *__restrict__ bucket_start,
+                                                const uint32_t *__restrict__ entries, size_t max_entries, int c, size_t B,
+                                                uint32_t nlanes, XYZZ<F> *__restrict__ sums) {
     const uint32_t nb = 1u << (c - 1);
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (size_t)nlanes * B) return;
@@ -433,6 +433,24 @@ __global__ __launch_bounds__(64) void k_msm_accumulate(const Affine<F> *__restri
     }
     out[cur] = acc;
 }
+template <class F, bool DENSE>
+__global__ __launch_bounds__(64) void k_msm_accumulate(const Affine<F> *__restrict__ table, const uint32_t *__restrict__ bucket_start,
+                                                       const uint32_t *__restrict__ entries, size_t max_entries, int c, size_t B,
+                                                       uint32_t nlanes, XYZZ<F> *__restrict__ sums) {
+    accumulate_body<F, DENSE>(table, bucket_start, entries, max_entries, c, B, nlanes, sums);
+}
+// G1: 3 wavefronts per SIMD (168 VGPRs, 64 B of scratch) hide the multiplier's dependent chains better than 2 at 190 VGPRs
+// (measured 111 vs 115 ms for the quotient MSM; 4 wavefronts at 128 VGPRs spill too much: 120 ms).  G2 needs all 256.
+#define ZK_ACC_G1(DENSE)                                                                                                                  \
+    template <>                                                                                                                           \
+    __global__ __launch_bounds__(64, 3) void k_msm_accumulate<Fp, DENSE>(const Affine<Fp> *__restrict__ table, const uint32_t *__restrict__ bucket_start, \
+                                                                         const uint32_t *__restrict__ entries, size_t max_entries, int c, size_t B,       \
+                                                                         uint32_t nlanes, XYZZ<Fp> *__restrict__ sums) {                                  \
+        accumulate_body<Fp, DENSE>(table, bucket_start, entries, max_entries, c, B, nlanes, sums);                                       \
+    }
+ZK_ACC_G1(true)
+ZK_ACC_G1(false)
+#undef ZK_ACC_G1
 
 // thread (b, seg): running-sum reduction of buckets [seg*L, seg*L + L) of instance b
 template <class F>

@@ -325,9 +325,13 @@ __global__ void k_store_commit(const G1Affine *com, const G1Affine *pok, ProofPo
 void Algorithm::resident_reserve(size_t B) {
     if (!res) {
         res.reset(new Resident());
-        ZK_HIP(hipStreamCreate(&res->stream));
-        ZK_HIP(hipStreamCreate(&res->stream2));
-        ZK_HIP(hipStreamCreate(&res->stream3));
+        // the solve stage and the proof tail are chains of small latency-bound kernels: on high-priority streams they slip in
+        // between the wavefronts of the large NTT / MSM kernels instead of queueing behind them
+        int prio_lo = 0, prio_hi = 0;
+        ZK_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        ZK_HIP(hipStreamCreateWithPriority(&res->stream, hipStreamDefault, prio_lo));
+        ZK_HIP(hipStreamCreateWithPriority(&res->stream2, hipStreamDefault, prio_hi));
+        ZK_HIP(hipStreamCreateWithPriority(&res->stream3, hipStreamDefault, prio_hi));
         for (auto &e : res->ev) ZK_HIP(hipEventCreate(&e));
     }
     Resident &R = *res;
