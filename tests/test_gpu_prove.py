@@ -304,3 +304,68 @@ def test_full_size_batch_every_proof_verifies(zk, oracle):
         exp, out, *_ = H.oracle_proof_bytes(alg, dict(insts[k], randomize=0))
         assert ser[k] == exp and outs[k] == out
     zk.lib.ZkpReset()
+
+
+def _pk_offsets(pk: bytes):
+    """byte offsets of the first point of each slice of an uncompressed proving key (SURVEY App. C layout)"""
+    u32 = lambda o: int.from_bytes(pk[o:o + 4], "big")
+    pos = 8 + 5 * 32 + 1
+    off = {"alpha": pos}
+    pos += 3 * 64
+    for name in ("A", "B", "Z", "K"):
+        n = u32(pos)
+        off[name] = pos + 4
+        pos += 4 + 64 * n
+    off["beta2"] = pos
+    pos += 2 * 128
+    off["B2"] = pos + 4
+    return off
+
+
+def test_init_rejects_invalid_key_points(zk, oracle):
+    """ProvingKey.ReadFrom semantics (impl/library.go:104-108: error -> InitAlgorithm false): a point off the curve, a non-reduced
+    coordinate, and a G2 point on the twist but outside the order-r subgroup are all refused; the intact key still loads"""
+    zk.lib.ZkpAllowUnpinnedKeys(1)
+    zk.lib.ZkpReset()
+    pk = bytearray(H.pk_file_bytes(0, raw=True))
+    r1cs = rf.load_r1cs_bytes("chacha20")
+    off = _pk_offsets(pk)
+    P = gf.P
+
+    def refused(mutated):
+        ok = zk.init_algorithm(0, bytes(mutated), r1cs)
+        zk.lib.ZkpReset()
+        return not ok
+
+    bad = bytearray(pk); bad[off["A"] + 63] ^= 1                                   # y of A[0] off the curve
+    assert refused(bad)
+    bad = bytearray(pk); bad[off["K"] + 5 * 64 + 40] ^= 0x10                       # K[5]
+    assert refused(bad)
+    (x, y), _ = gf.g1_decode(bytes(pk), off["Z"])
+    bad = bytearray(pk); bad[off["Z"]:off["Z"] + 32] = (x + P).to_bytes(32, "big")   # same point, x not reduced (x + p < 2^256)
+    assert refused(bad)
+    # a twist point outside the subgroup: the twist has cofactor 2p - r, so a random point on it is (almost surely) not in G2
+    xx = 1
+    while True:
+        comp = bytearray((0).to_bytes(32, "big") + xx.to_bytes(32, "big")); comp[0] |= 0x80
+        try:
+            pt, _ = gf.g2_decode(bytes(comp))
+            break
+        except ValueError:
+            xx += 1
+    assert gf.g2_on_curve(pt)
+    bad = bytearray(pk); bad[off["B2"]:off["B2"] + 128] = gf.g2_raw(pt)
+    assert refused(bad)
+    bad = bytearray(pk); bad[off["beta2"] + 127] ^= 1                               # beta2 off the twist
+    assert refused(bad)
+    # the compressed form goes through the same checks
+    pkc = bytearray(H.pk_file_bytes(0, raw=False))
+    u32 = lambda o: int.from_bytes(pkc[o:o + 4], "big")
+    pos = 8 + 5 * 32 + 1 + 3 * 32
+    for _ in range(4):
+        pos += 4 + 32 * u32(pos)
+    pos += 2 * 64 + 4                                                               # first compressed B2 point
+    bad = bytearray(pkc); bad[pos:pos + 64] = gf.g2_compress(pt)
+    assert refused(bad)
+    assert zk.init_algorithm(0, bytes(pk), r1cs)                                     # untouched key loads
+    zk.lib.ZkpReset()

@@ -96,6 +96,10 @@ void g2_from_be_bytes(G2Affine *d_out, const uint8_t *d_in /* n*128: X.A1|X.A0|Y
 // compressed forms (gnark-crypto marshal): returns via d_ok[i] = 0 on invalid point
 void g1_decompress(G1Affine *d_out, const uint8_t *d_in /* n*32 */, size_t n, uint32_t *d_bad, hipStream_t s);
 void g2_decompress(G2Affine *d_out, const uint8_t *d_in /* n*64 */, size_t n, uint32_t *d_bad, hipStream_t s);
+// key-slice validation (gnark-crypto decoder semantics): reduced coordinates (d_raw = uncompressed source bytes or nullptr),
+// on-curve, G2 subgroup membership; every failing point increments *d_bad
+void g1_validate(const G1Affine *d_pts, const uint8_t *d_raw, size_t n, uint32_t *d_bad, hipStream_t s);
+void g2_validate(const G2Affine *d_pts, const uint8_t *d_raw, size_t n, uint32_t *d_bad, hipStream_t s);
 // XYZZ -> canonical (non-Montgomery) affine, little-endian limbs; infinity -> zeros
 void g1_to_affine_canonical(const G1XYZZ *d_in, G1Affine *d_out, size_t n, hipStream_t s);
 void g2_to_affine_canonical(const G2XYZZ *d_in, G2Affine *d_out, size_t n, hipStream_t s);

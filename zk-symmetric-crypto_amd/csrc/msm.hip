@@ -792,7 +792,9 @@ __global__ void k_g1_decompress(G1Affine *out, const uint8_t *in, size_t n, uint
     const uint32_t flag = p[0] >> 6;
     if (flag == 1) { out[i] = G1Affine::inf(); return; }
     if (flag == 0) { atomicAdd(bad, 1u); out[i] = G1Affine::inf(); return; }
-    Fp x = fp_from_be(p, true).to_mont();
+    const Fp xc = fp_from_be(p, true);
+    if (Fp::geq_mod(xc.l)) { atomicAdd(bad, 1u); out[i] = G1Affine::inf(); return; }       // non-reduced coordinate
+    Fp x = xc.to_mont();
     Fp y;
     if (!fp_sqrt(x.sqr() * x + Fp::from_u32(3), y)) { atomicAdd(bad, 1u); out[i] = G1Affine::inf(); return; }
     if (fp_lex_largest(y) != (flag == 3)) y = y.neg();
@@ -805,7 +807,9 @@ __global__ void k_g2_decompress(G2Affine *out, const uint8_t *in, size_t n, uint
     const uint32_t flag = p[0] >> 6;
     if (flag == 1) { out[i] = G2Affine::inf(); return; }
     if (flag == 0) { atomicAdd(bad, 1u); out[i] = G2Affine::inf(); return; }
-    Fp2 x{fp_from_be(p + 32, false).to_mont(), fp_from_be(p, true).to_mont()};
+    const Fp x0c = fp_from_be(p + 32, false), x1c = fp_from_be(p, true);
+    if (Fp::geq_mod(x0c.l) || Fp::geq_mod(x1c.l)) { atomicAdd(bad, 1u); out[i] = G2Affine::inf(); return; }
+    Fp2 x{x0c.to_mont(), x1c.to_mont()};
     // twist coefficient b' = 3/(9+u)
     const Fp2 xi{Fp::from_u32(9), Fp::one()};
     const Fp2 bt = Fp2{Fp::from_u32(3), Fp::zero()} * xi.inv();
@@ -826,6 +830,47 @@ __global__ void k_g2_to_affine_canon(const G2XYZZ *in, G2Affine *out, size_t n) 
     if (i >= n) return;
     G2Affine a = in[i].to_affine();
     out[i] = G2Affine{a.x.from_mont(), a.y.from_mont()};
+}
+// Point validation of a decoded key slice, as gnark-crypto's decoder does in ProvingKey.ReadFrom (impl/library.go:104-108):
+// coordinates reduced, point on the curve, and for G2 (cofactor != 1) membership of the order-r subgroup ([r]P = O).
+// d_raw (optional): the big-endian source coordinates of an uncompressed slice, to reject non-reduced encodings.
+__device__ __forceinline__ bool be_reduced(const uint8_t *p) {
+    const Fp v = fp_from_be(p, false);
+    return !Fp::geq_mod(v.l);
+}
+__global__ void k_g1_validate(const G1Affine *pts, const uint8_t *raw, size_t n, uint32_t *bad) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const G1Affine p = pts[i];
+    bool ok = true;
+    if (raw) ok = be_reduced(raw + 64 * i) && be_reduced(raw + 64 * i + 32);
+    if (ok && !p.is_inf()) ok = p.y.sqr() == p.x.sqr() * p.x + Fp::from_u32(3);
+    if (!ok) atomicAdd(bad, 1u);
+}
+__global__ __launch_bounds__(64) void k_g2_validate(const G2Affine *pts, const uint8_t *raw, size_t n, uint32_t *bad) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const G2Affine p = pts[i];
+    bool ok = true;
+    if (raw)
+        for (int k = 0; k < 4; k++) ok = ok && be_reduced(raw + 128 * i + 32 * k);
+    if (ok && !p.is_inf()) {
+        const Fp2 xi{Fp::from_u32(9), Fp::one()};
+        const Fp2 bt = Fp2{Fp::from_u32(3), Fp::zero()} * xi.inv();
+        ok = p.y.sqr() == p.x.sqr() * p.x + bt;
+        if (ok) {
+            // r = the Fr modulus
+            const uint32_t r[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+            ok = scalar_mul(p, r, 254).is_inf();
+        }
+    }
+    if (!ok) atomicAdd(bad, 1u);
+}
+void g1_validate(const G1Affine *d_pts, const uint8_t *d_raw, size_t n, uint32_t *d_bad, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_g1_validate, dim3(ceil_div(n, 128)), dim3(128), 0, s, d_pts, d_raw, n, d_bad);
+}
+void g2_validate(const G2Affine *d_pts, const uint8_t *d_raw, size_t n, uint32_t *d_bad, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_g2_validate, dim3(ceil_div(n, 64)), dim3(64), 0, s, d_pts, d_raw, n, d_bad);
 }
 void g1_from_be_bytes(G1Affine *o, const uint8_t *in, size_t n, hipStream_t s) { if (n) hipLaunchKernelGGL(k_g1_from_be, dim3(ceil_div(n, 256)), dim3(256), 0, s, o, in, n); }
 void g2_from_be_bytes(G2Affine *o, const uint8_t *in, size_t n, hipStream_t s) { if (n) hipLaunchKernelGGL(k_g2_from_be, dim3(ceil_div(n, 256)), dim3(256), 0, s, o, in, n); }

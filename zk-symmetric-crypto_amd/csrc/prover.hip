@@ -42,32 +42,28 @@ static void upload_g1(const uint8_t *base, const Slice &s, DevBuf<G1Affine> &out
     if (!s.n) return;
     const size_t bytes = s.n * (s.raw ? 64 : 32);
     DevBuf<uint8_t> raw(bytes);
+    DevBuf<uint32_t> bad(1); bad.zero(st);
     ZK_HIP(hipMemcpyAsync(raw.p, base + s.off, bytes, hipMemcpyHostToDevice, st));
     if (s.raw) g1_from_be_bytes(out.p, raw.p, s.n, st);
-    else {
-        DevBuf<uint32_t> bad(1); bad.zero(st);
-        g1_decompress(out.p, raw.p, s.n, bad.p, st);
-        uint32_t nb = 0; bad.download(&nb, 1, st);
-        ZK_HIP(hipStreamSynchronize(st));
-        if (nb) throw ZkError("proving key: invalid compressed G1 point");
-    }
+    else g1_decompress(out.p, raw.p, s.n, bad.p, st);
+    g1_validate(out.p, s.raw ? raw.p : nullptr, s.n, bad.p, st);
+    uint32_t nb = 0; bad.download(&nb, 1, st);
     ZK_HIP(hipStreamSynchronize(st));
+    if (nb) throw ZkError("proving key: invalid G1 point");
 }
 static void upload_g2(const uint8_t *base, const Slice &s, DevBuf<G2Affine> &out, hipStream_t st) {
     out.alloc(s.n ? s.n : 1);
     if (!s.n) return;
     const size_t bytes = s.n * (s.raw ? 128 : 64);
     DevBuf<uint8_t> raw(bytes);
+    DevBuf<uint32_t> bad(1); bad.zero(st);
     ZK_HIP(hipMemcpyAsync(raw.p, base + s.off, bytes, hipMemcpyHostToDevice, st));
     if (s.raw) g2_from_be_bytes(out.p, raw.p, s.n, st);
-    else {
-        DevBuf<uint32_t> bad(1); bad.zero(st);
-        g2_decompress(out.p, raw.p, s.n, bad.p, st);
-        uint32_t nb = 0; bad.download(&nb, 1, st);
-        ZK_HIP(hipStreamSynchronize(st));
-        if (nb) throw ZkError("proving key: invalid compressed G2 point");
-    }
+    else g2_decompress(out.p, raw.p, s.n, bad.p, st);
+    g2_validate(out.p, s.raw ? raw.p : nullptr, s.n, bad.p, st);
+    uint32_t nb = 0; bad.download(&nb, 1, st);
     ZK_HIP(hipStreamSynchronize(st));
+    if (nb) throw ZkError("proving key: invalid G2 point (not on the curve or not in the subgroup)");
 }
 static std::vector<uint8_t> take_bools(PkCursor &c) {
     // gnark-crypto encoder []bool: u32 length, bits packed LSB-first  [gnark-mem, unpinned: SURVEY App. C]
