@@ -4,6 +4,8 @@
 #include <string.h>
 #include <memory>
 #include <mutex>
+#include <thread>
+#include <atomic>
 #include "../../include/zkprove.h"
 #include "prover.h"
 
@@ -194,33 +196,70 @@ std::string response_json(const std::vector<uint8_t> &proof, const std::vector<u
     return "{\"proof\":\"" + base64_encode(proof.data(), proof.size()) + "\",\"ciphertext\":\"" + base64_encode(ct.data(), ct.size()) + "\"}";
 }
 
-// Prove a list of decoded requests of ONE algorithm as one GPU batch.
-std::vector<std::string> prove_requests(int alg_id, const std::vector<Request> &rqs, const U256 *r_fix, const U256 *s_fix, const U256 *rnd_fix) {
+// host-side parallel loop (request decoding, witness packing, proof serialisation are independent per request)
+template <class Fn>
+void parallel_for(size_t n, Fn fn) {
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt > 16) nt = 16;
+    if (n < 64 || nt <= 1) { for (size_t i = 0; i < n; i++) fn(i); return; }
+    std::atomic<size_t> next{0};
+    auto worker = [&] {
+        for (;;) {
+            const size_t i0 = next.fetch_add(32);
+            if (i0 >= n) return;
+            const size_t i1 = i0 + 32 < n ? i0 + 32 : n;
+            for (size_t i = i0; i < i1; i++) fn(i);
+        }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(worker);
+    worker();
+    for (auto &t : th) t.join();
+}
+
+// one decoded request with its witness assignment and cipher output (or the panic value it produced)
+struct Prepared {
+    Request rq;
+    std::vector<uint32_t> w;
+    std::vector<uint8_t> out;
+    std::string panic;
+    bool ok = false;
+};
+void prepare(const Json &j, Prepared &p) {
+    try {
+        p.rq = decode_request(j);
+        // impl.Prove checks initDone before the prover validates the request (library.go:143-145, then provers.go:120-133)
+        if (!get_alg(p.rq.alg)) panic_str(std::string("proving params are not initialized for cipher: ") + ALGS[p.rq.alg].name);
+        build_witness(p.rq, p.w, p.out);
+        p.ok = true;
+    } catch (const Panic &e) {
+        p.panic = e.json;
+    }
+}
+
+// Prove prepared requests of ONE algorithm as one GPU batch (chunked and pipelined inside Algorithm::prove_batch).
+std::vector<std::string> prove_prepared(int alg_id, const std::vector<const Prepared *> &items, const U256 *r_fix, const U256 *s_fix, const U256 *rnd_fix) {
     Algorithm *alg = get_alg(alg_id);
     if (!alg) panic_str(std::string("proving params are not initialized for cipher: ") + ALGS[alg_id].name);   // library.go:143-145
-    const size_t B = rqs.size(), ni = alg->n_inputs();
+    const size_t B = items.size(), ni = alg->n_inputs();
     std::vector<uint32_t> inputs(B * ni);
-    std::vector<std::vector<uint8_t>> outs(B);
     for (size_t i = 0; i < B; i++) {
-        std::vector<uint32_t> w;
-        build_witness(rqs[i], w, outs[i]);
-        if (w.size() != ni) panic_err();
-        memcpy(&inputs[i * ni], w.data(), ni * 4);
+        if (items[i]->w.size() != ni) panic_err();
+        memcpy(&inputs[i * ni], items[i]->w.data(), ni * 4);
     }
     std::vector<U256> r(B), s(B), rnd(B);
-    for (size_t i = 0; i < B; i++) {
-        r[i] = r_fix ? r_fix[i] : fr_random();
-        s[i] = s_fix ? s_fix[i] : fr_random();
-        rnd[i] = rnd_fix ? rnd_fix[i] : fr_random();
-    }
+    if (r_fix) { for (size_t i = 0; i < B; i++) r[i] = r_fix[i]; } else fr_random_fill(r.data(), B);
+    if (s_fix) { for (size_t i = 0; i < B; i++) s[i] = s_fix[i]; } else fr_random_fill(s.data(), B);
+    if (rnd_fix) { for (size_t i = 0; i < B; i++) rnd[i] = rnd_fix[i]; } else fr_random_fill(rnd.data(), B);
     std::vector<ProofPoints> pp(B);
     std::vector<uint32_t> errs(B);
     alg->prove_batch(B, inputs.data(), r.data(), s.data(), rnd.data(), pp.data(), errs.data());
     std::vector<std::string> res(B);
-    for (size_t i = 0; i < B; i++) {
-        if (errs[i]) { res[i] = "{}"; continue; }       // groth16.Prove returned an error -> panic(err) -> {}
-        res[i] = response_json(proof_serialize(pp[i], alg->has_commit), outs[i]);
-    }
+    const bool has_commit = alg->has_commit;
+    parallel_for(B, [&](size_t i) {
+        if (errs[i]) { res[i] = "{}"; return; }       // groth16.Prove returned an error -> panic(err) -> {}
+        res[i] = response_json(proof_serialize(pp[i], has_commit), items[i]->out);
+    });
     return res;
 }
 
@@ -231,9 +270,10 @@ ProveReturn prove_one(GoSlice params, const U256 *r, const U256 *s, const U256 *
         Json j;
         std::string err;
         if (!json_parse((const char *)params.data, (size_t)params.len, j, err)) panic_err();   // *json.SyntaxError -> {"Offset":n}; offsets are not reproduced
-        Request rq = decode_request(j);
-        std::vector<Request> v{rq};
-        result = prove_requests(rq.alg, v, r, s, rnd)[0];
+        Prepared p;
+        prepare(j, p);
+        if (!p.ok) throw Panic{p.panic};
+        result = prove_prepared(p.rq.alg, {&p}, r, s, rnd)[0];
     } catch (const Panic &p) {
         result = p.json;
     } catch (const std::exception &e) {
@@ -322,27 +362,22 @@ ProveReturn ProveBatch(GoSlice params) {
         if (!json_parse((const char *)params.data, (size_t)params.len, j, err) || j.t != Json::ARR) panic_err();
         const size_t n = j.a.size();
         std::vector<std::string> res(n);
-        std::vector<Request> rqs;
+        std::vector<Prepared> prep(n);
+        parallel_for(n, [&](size_t i) { prepare(j.a[i], prep[i]); });
+        std::vector<const Prepared *> items;
         std::vector<size_t> idx;
         int alg = -1;
         for (size_t i = 0; i < n; i++) {
-            try {
-                Request rq = decode_request(j.a[i]);
-                if (alg < 0) alg = rq.alg;
-                if (rq.alg != alg) panic_str("ProveBatch: all requests must use the same cipher");
-                // validate now so that one bad request does not poison the batch
-                std::vector<uint32_t> w; std::vector<uint8_t> o;
-                build_witness(rq, w, o);
-                rqs.push_back(std::move(rq));
-                idx.push_back(i);
-            } catch (const Panic &p) {
-                res[i] = p.json;
-            }
+            if (!prep[i].ok) { res[i] = prep[i].panic; continue; }      // one bad request does not poison the batch
+            if (alg < 0) alg = prep[i].rq.alg;
+            if (prep[i].rq.alg != alg) { res[i] = json_quote("ProveBatch: all requests must use the same cipher"); continue; }
+            items.push_back(&prep[i]);
+            idx.push_back(i);
         }
-        if (!rqs.empty()) {
+        if (!items.empty()) {
             try {
-                auto out = prove_requests(alg, rqs, nullptr, nullptr, nullptr);
-                for (size_t k = 0; k < idx.size(); k++) res[idx[k]] = out[k];
+                auto out = prove_prepared(alg, items, nullptr, nullptr, nullptr);
+                for (size_t k = 0; k < idx.size(); k++) res[idx[k]] = std::move(out[k]);
             } catch (const Panic &p) {
                 for (size_t k = 0; k < idx.size(); k++) res[idx[k]] = p.json;
             }

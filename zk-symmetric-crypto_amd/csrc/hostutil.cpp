@@ -368,12 +368,22 @@ void u256_to_be(const U256 &v, uint8_t out[32]) {
         out[4 * i] = w >> 24; out[4 * i + 1] = w >> 16; out[4 * i + 2] = w >> 8; out[4 * i + 3] = w;
     }
 }
-U256 fr_random() {
-    uint8_t buf[48];
+// uniform scalars from the OS entropy source: 48 random bytes reduced mod r each (bias 2^-130), ONE read for the whole batch
+void fr_random_fill(U256 *out, size_t n) {
+    if (!n) return;
+    std::vector<uint8_t> buf(48 * n);
     FILE *f = fopen("/dev/urandom", "rb");
-    if (!f || fread(buf, 1, sizeof(buf), f) != sizeof(buf)) { if (f) fclose(f); throw ZkError("cannot read /dev/urandom"); }
+    if (!f) throw ZkError("cannot read /dev/urandom");
+    setvbuf(f, nullptr, _IONBF, 0);
+    const bool ok = fread(buf.data(), 1, buf.size(), f) == buf.size();
     fclose(f);
-    return u256_from_be_mod(buf, sizeof(buf), FR_MODULUS);
+    if (!ok) throw ZkError("cannot read /dev/urandom");
+    for (size_t i = 0; i < n; i++) out[i] = u256_from_be_mod(buf.data() + 48 * i, 48, FR_MODULUS);
+}
+U256 fr_random() {
+    U256 v;
+    fr_random_fill(&v, 1);
+    return v;
 }
 U256 hash_to_fr(const uint8_t *msg, size_t len, const char *dst) {
     const size_t dlen = strlen(dst), L = 48;

@@ -47,6 +47,7 @@ U256 u256_from_be_mod(const uint8_t *p, size_t n, const U256 &m);
 void u256_to_be(const U256 &v, uint8_t out[32]);
 // uniformly random element of [0, r) from the OS entropy source (fr.Element.SetRandom)
 U256 fr_random();
+void fr_random_fill(U256 *out, size_t n);
 // RFC 9380 expand_message_xmd(SHA-256) -> one Fr element (gnark-crypto fr.Hash(msg, dst, 1)), canonical
 U256 hash_to_fr(const uint8_t *msg, size_t len, const char *dst);
 

@@ -90,16 +90,19 @@ struct SolveSet {
     DevBuf<G1XYZZ> m_com, m_pok;
     DevBuf<G1Affine> com_aff, pok_aff;
     DevBuf<U256> chal;
+    DevBuf<U256> r, s, rnd;            // blinding scalars and the Randomize hint value of this batch (canonical)
+    DevBuf<ProofPoints> out;           // proofs of this batch
     std::vector<G1Affine> h_com;
     std::vector<U256> h_chal;
-    hipEvent_t solved = nullptr, consumed = nullptr, t0 = nullptr, t1 = nullptr, t2 = nullptr, t3 = nullptr;
+    hipEvent_t solved = nullptr, consumed = nullptr, uploaded = nullptr, t0 = nullptr, t1 = nullptr, t2 = nullptr, t3 = nullptr;
     bool ready = false;
     void reserve(const SolverProgram &prog, size_t B) {
         sb.reserve(prog, B);
         m_com.ensure(B); m_pok.ensure(B); com_aff.ensure(B); pok_aff.ensure(B); chal.ensure(B);
+        r.ensure(B); s.ensure(B); rnd.ensure(B); out.ensure(B);
         h_com.resize(B); h_chal.resize(B);
         if (!solved) {
-            ZK_HIP(hipEventCreate(&solved)); ZK_HIP(hipEventCreate(&consumed));
+            ZK_HIP(hipEventCreate(&solved)); ZK_HIP(hipEventCreate(&consumed)); ZK_HIP(hipEventCreate(&uploaded));
             ZK_HIP(hipEventCreate(&t0)); ZK_HIP(hipEventCreate(&t1)); ZK_HIP(hipEventCreate(&t2)); ZK_HIP(hipEventCreate(&t3));
         }
         ready = true;
@@ -112,11 +115,10 @@ struct Algorithm::Resident {
     MsmScratch ms, ms2;             // ms2: the commitment MSMs of the solve stage when it runs on the second stream
     DevBuf<G1XYZZ> m_ar, m_bs1, m_k, m_z;
     DevBuf<G2XYZZ> m_bs2;
-    DevBuf<U256> r, s, rnd;
     DevBuf<G1Affine> ar_aff, bs1_aff;
     DevBuf<G1XYZZ> f_t, f_u, f_v;
-    DevBuf<ProofPoints> out;
-    hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr;
+    int last_set = 0;               // the set that holds the most recent batch
+    hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr, copy_stream = nullptr;
     hipEvent_t ev[12] = {};     // [10] MSM sums of the current batch complete  [11] tail of the previous batch done
 };
 
@@ -124,10 +126,11 @@ Algorithm::Algorithm() {}
 Algorithm::~Algorithm() {
     if (res) {
         for (auto &e : res->ev) if (e) (void)hipEventDestroy(e);
-        for (auto &st : res->set) for (hipEvent_t e : {st.solved, st.consumed, st.t0, st.t1, st.t2, st.t3}) if (e) (void)hipEventDestroy(e);
+        for (auto &st : res->set) for (hipEvent_t e : {st.solved, st.consumed, st.uploaded, st.t0, st.t1, st.t2, st.t3}) if (e) (void)hipEventDestroy(e);
         if (res->stream) (void)hipStreamDestroy(res->stream);
         if (res->stream2) (void)hipStreamDestroy(res->stream2);
         if (res->stream3) (void)hipStreamDestroy(res->stream3);
+        if (res->copy_stream) (void)hipStreamDestroy(res->copy_stream);
     }
 }
 
@@ -325,9 +328,11 @@ void Algorithm::resident_reserve(size_t B) {
         // between the wavefronts of the large NTT / MSM kernels instead of queueing behind them
         int prio_lo = 0, prio_hi = 0;
         ZK_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        ZK_HIP(hipStreamCreateWithPriority(&res->stream, hipStreamDefault, prio_lo));
-        ZK_HIP(hipStreamCreateWithPriority(&res->stream2, hipStreamDefault, prio_hi));
-        ZK_HIP(hipStreamCreateWithPriority(&res->stream3, hipStreamDefault, prio_hi));
+        // non-blocking: a synchronous copy on the null stream must not drain the pipeline
+        ZK_HIP(hipStreamCreateWithPriority(&res->stream, hipStreamNonBlocking, prio_lo));
+        ZK_HIP(hipStreamCreateWithPriority(&res->stream2, hipStreamNonBlocking, prio_hi));
+        ZK_HIP(hipStreamCreateWithPriority(&res->stream3, hipStreamNonBlocking, prio_hi));
+        ZK_HIP(hipStreamCreateWithPriority(&res->copy_stream, hipStreamNonBlocking, prio_hi));
         for (auto &e : res->ev) ZK_HIP(hipEventCreate(&e));
     }
     Resident &R = *res;
@@ -353,24 +358,23 @@ void Algorithm::resident_reserve(size_t B) {
         R.ms.reserve_sums(B, nb1, (size_t)1 << (pk.B2.c - 1));
     }
     R.m_ar.alloc(B); R.m_bs1.alloc(B); R.m_k.alloc(B); R.m_z.alloc(B); R.m_bs2.alloc(B);
-    R.r.alloc(B); R.s.alloc(B); R.rnd.alloc(B);
-    R.out.alloc(B);
     R.ar_aff.alloc(B); R.bs1_aff.alloc(B); R.f_t.alloc(B); R.f_u.alloc(B); R.f_v.alloc(B);
+}
+
+// inputs [B][n_inputs] (instance-major, as the host builds them), r / s / randomize [B] canonical -> set S, on stream st
+void Algorithm::upload_set(SolveSet &S, size_t B, const uint32_t *inputs, const U256 *r, const U256 *s, const U256 *randomize, hipStream_t st) {
+    ZK_HIP(hipMemcpyAsync(S.sb.inputs.p, inputs, prog.n_inputs * B * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    ZK_HIP(hipMemcpyAsync(S.r.p, r, B * sizeof(U256), hipMemcpyHostToDevice, st));
+    ZK_HIP(hipMemcpyAsync(S.s.p, s, B * sizeof(U256), hipMemcpyHostToDevice, st));
+    if (randomize) ZK_HIP(hipMemcpyAsync(S.rnd.p, randomize, B * sizeof(U256), hipMemcpyHostToDevice, st));
+    else ZK_HIP(hipMemsetAsync(S.rnd.p, 0, B * sizeof(U256), st));
 }
 
 void Algorithm::resident_upload(size_t B, const uint32_t *inputs, const U256 *r, const U256 *s, const U256 *randomize) {
     resident_reserve(B);
     Resident &R = *res;
-    const size_t ni = prog.n_inputs;
-    std::vector<uint32_t> tr(ni * B);
-    for (size_t b = 0; b < B; b++)
-        for (size_t i = 0; i < ni; i++) tr[i * B + b] = inputs[b * ni + i];
-    ZK_HIP(hipMemcpyAsync(R.set[0].sb.inputs.p, tr.data(), tr.size() * 4, hipMemcpyHostToDevice, R.stream));
-    if (R.set[1].ready) ZK_HIP(hipMemcpyAsync(R.set[1].sb.inputs.p, tr.data(), tr.size() * 4, hipMemcpyHostToDevice, R.stream));
-    ZK_HIP(hipMemcpyAsync(R.r.p, r, B * sizeof(U256), hipMemcpyHostToDevice, R.stream));
-    ZK_HIP(hipMemcpyAsync(R.s.p, s, B * sizeof(U256), hipMemcpyHostToDevice, R.stream));
-    if (randomize) ZK_HIP(hipMemcpyAsync(R.rnd.p, randomize, B * sizeof(U256), hipMemcpyHostToDevice, R.stream));
-    else ZK_HIP(hipMemsetAsync(R.rnd.p, 0, B * sizeof(U256), R.stream));
+    for (auto &S : R.set)
+        if (S.ready) upload_set(S, B, inputs, r, s, randomize, R.stream);
     ZK_HIP(hipStreamSynchronize(R.stream));
 }
 
@@ -380,7 +384,7 @@ void Algorithm::enqueue_solve(SolveSet &S, MsmScratch &commit_scratch, hipStream
     Resident &R = *res;
     const size_t B = R.B;
     ZK_HIP(hipEventRecord(S.t0, st));
-    hipLaunchKernelGGL(k_u256_to_mont, dim3(ceil_div(B, 64)), dim3(64), 0, st, R.rnd.p, S.sb.randomize.p, B);
+    hipLaunchKernelGGL(k_u256_to_mont, dim3(ceil_div(B, 64)), dim3(64), 0, st, S.rnd.p, S.sb.randomize.p, B);
     solver_begin(prog, S.sb, st);
     if (has_commit) {
         solver_run_levels(prog, S.sb, 0, commit_level, st);
@@ -438,12 +442,12 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm)
 void Algorithm::enqueue_finalize(SolveSet &S, hipStream_t st) {
     Resident &R = *res;
     const size_t B = R.B;
-    hipLaunchKernelGGL(k_finalize_stage1, dim3(ceil_div(B, 64), 3), dim3(64), 0, st, R.m_ar.p, R.m_bs1.p, pk.g1_misc.p, pk.delta_tab.p, R.r.p, R.s.p,
+    hipLaunchKernelGGL(k_finalize_stage1, dim3(ceil_div(B, 64), 3), dim3(64), 0, st, R.m_ar.p, R.m_bs1.p, pk.g1_misc.p, pk.delta_tab.p, S.r.p, S.s.p,
                        R.ar_aff.p, R.bs1_aff.p, R.f_t.p, B);
-    hipLaunchKernelGGL(k_finalize_g2, dim3(ceil_div(B, 64)), dim3(64), 0, st, R.m_bs2.p, pk.g2_misc.p, pk.delta2_tab.p, R.s.p, R.out.p, B);
-    hipLaunchKernelGGL(k_finalize_stage2, dim3(ceil_div(B, 64), 2), dim3(64), 0, st, R.ar_aff.p, R.bs1_aff.p, R.r.p, R.s.p, R.f_u.p, R.f_v.p, B);
-    hipLaunchKernelGGL(k_finalize_stage3, dim3(ceil_div(B, 64)), dim3(64), 0, st, R.m_k.p, R.m_z.p, R.f_t.p, R.f_u.p, R.f_v.p, R.ar_aff.p, R.out.p, B);
-    hipLaunchKernelGGL(k_store_commit, dim3(ceil_div(B, 64)), dim3(64), 0, st, S.com_aff.p, S.pok_aff.p, R.out.p, B, has_commit ? 1 : 0);
+    hipLaunchKernelGGL(k_finalize_g2, dim3(ceil_div(B, 64)), dim3(64), 0, st, R.m_bs2.p, pk.g2_misc.p, pk.delta2_tab.p, S.s.p, S.out.p, B);
+    hipLaunchKernelGGL(k_finalize_stage2, dim3(ceil_div(B, 64), 2), dim3(64), 0, st, R.ar_aff.p, R.bs1_aff.p, S.r.p, S.s.p, R.f_u.p, R.f_v.p, B);
+    hipLaunchKernelGGL(k_finalize_stage3, dim3(ceil_div(B, 64)), dim3(64), 0, st, R.m_k.p, R.m_z.p, R.f_t.p, R.f_u.p, R.f_v.p, R.ar_aff.p, S.out.p, B);
+    hipLaunchKernelGGL(k_store_commit, dim3(ceil_div(B, 64)), dim3(64), 0, st, S.com_aff.p, S.pok_aff.p, S.out.p, B, has_commit ? 1 : 0);
     ZK_HIP(hipGetLastError());
     ZK_HIP(hipEventRecord(R.ev[7], st));
 }
@@ -461,6 +465,7 @@ void Algorithm::collect_times(SolveSet &S, PhaseTimes *times) {
 void Algorithm::resident_prove(PhaseTimes *times) {
     Resident &R = *res;
     hipStream_t st = R.stream;
+    R.last_set = 0;
     enqueue_solve(R.set[0], R.ms, st);
     enqueue_main(R.set[0], st);
     enqueue_finalize(R.set[0], st);
@@ -471,22 +476,31 @@ void Algorithm::resident_prove(PhaseTimes *times) {
     }
 }
 
+// the second working set (and the separate scratch of its commitment MSMs) exists only once a pipelined entry is used
+void Algorithm::ensure_second_set() {
+    Resident &R = *res;
+    if (R.set[1].ready) return;
+    R.set[1].reserve(prog, R.cap);
+    R.set[1].sb.B = R.B;
+    SolveSet &a = R.set[0], &b = R.set[1];
+    ZK_HIP(hipMemcpy(b.sb.inputs.p, a.sb.inputs.p, prog.n_inputs * R.B * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+    ZK_HIP(hipMemcpy(b.r.p, a.r.p, R.B * sizeof(U256), hipMemcpyDeviceToDevice));
+    ZK_HIP(hipMemcpy(b.s.p, a.s.p, R.B * sizeof(U256), hipMemcpyDeviceToDevice));
+    ZK_HIP(hipMemcpy(b.rnd.p, a.rnd.p, R.B * sizeof(U256), hipMemcpyDeviceToDevice));
+    if (has_commit) {
+        R.ms2.reserve(R.cap, pk.ped.n * (size_t)pk.ped.W, (size_t)1 << (pk.ped.c - 1), msm_part_stride(pk.ped.n, pk.ped.c));
+        R.ms2.reserve_compact(R.cap, pk.ped.n);
+        R.ms2.reserve_sums(R.cap, (size_t)1 << (pk.ped.c - 1), 1);
+    }
+}
+
 // nsteps batches back to back (the same resident inputs are re-proved each time), the SOLVE stage of batch k+1 overlapped
 // with the NTT + MSM stage of batch k.  times (optional) = phase times of the LAST batch; total = whole call / nsteps.
 void Algorithm::resident_prove_pipelined(int nsteps, PhaseTimes *times) {
     Resident &R = *res;
     if (nsteps <= 0) return;
-    if (!R.set[1].ready) {
-        R.set[1].reserve(prog, R.cap);
-        R.set[1].sb.B = R.B;
-        ZK_HIP(hipMemcpy(R.set[1].sb.inputs.p, R.set[0].sb.inputs.p, prog.n_inputs * R.B * sizeof(uint32_t), hipMemcpyDeviceToDevice));
-        // the commitment MSMs of the overlapped solve stage need their own scratch
-        if (has_commit) {
-            R.ms2.reserve(R.cap, pk.ped.n * (size_t)pk.ped.W, (size_t)1 << (pk.ped.c - 1), msm_part_stride(pk.ped.n, pk.ped.c));
-            R.ms2.reserve_compact(R.cap, pk.ped.n);
-            R.ms2.reserve_sums(R.cap, (size_t)1 << (pk.ped.c - 1), 1);
-        }
-    }
+    ensure_second_set();
+    R.last_set = (nsteps - 1) & 1;
     hipStream_t M = R.stream, S = R.stream2, F = R.stream3;
     ZK_HIP(hipEventRecord(R.ev[0], M));
     ZK_HIP(hipStreamWaitEvent(S, R.ev[0], 0));
@@ -521,23 +535,73 @@ void Algorithm::resident_prove_pipelined(int nsteps, PhaseTimes *times) {
 
 void Algorithm::resident_download(ProofPoints *out, uint32_t *errs) {
     Resident &R = *res;
-    ZK_HIP(hipMemcpy(out, R.out.p, R.B * sizeof(ProofPoints), hipMemcpyDeviceToHost));
-    if (errs) ZK_HIP(hipMemcpy(errs, R.set[0].sb.err.p, R.B * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    SolveSet &S = R.set[R.last_set];
+    ZK_HIP(hipMemcpy(out, S.out.p, R.B * sizeof(ProofPoints), hipMemcpyDeviceToHost));
+    if (errs) ZK_HIP(hipMemcpy(errs, S.sb.err.p, R.B * sizeof(uint32_t), hipMemcpyDeviceToHost));
 }
 
+// batch proofs, chunked to max_chunk instances per device pass.  More than one chunk: the chunks are software-pipelined exactly as
+// resident_prove_pipelined does with repeated passes (solve of chunk k+1 and tail of chunk k-1 under the NTT + MSM stage of chunk k),
+// with the uploads / downloads on a copy stream, so callers of ProveBatch see the pipelined rate.
 void Algorithm::prove_batch(size_t batch, const uint32_t *inputs, const U256 *r, const U256 *s, const U256 *randomize, ProofPoints *out,
                             uint32_t *errs, PhaseTimes *times) {
     std::lock_guard<std::mutex> lk(mu);
-    PhaseTimes tot;
-    for (size_t off = 0; off < batch; off += max_chunk) {
-        const size_t B = std::min(max_chunk, batch - off);
-        resident_upload(B, inputs + off * prog.n_inputs, r + off, s + off, randomize ? randomize + off : nullptr);
+    const size_t ni = prog.n_inputs;
+    const size_t nchunks = (batch + max_chunk - 1) / max_chunk;
+    if (nchunks <= 1) {
+        resident_upload(batch, inputs, r, s, randomize);
         PhaseTimes t;
         resident_prove(&t);
-        resident_download(out + off, errs ? errs + off : nullptr);
-        tot.solve += t.solve; tot.commit += t.commit; tot.ntt += t.ntt; tot.msm_g1 += t.msm_g1; tot.msm_g2 += t.msm_g2; tot.finalize += t.finalize; tot.total += t.total; tot.z_segments += t.z_segments;
+        resident_download(out, errs);
+        if (times) *times = t;
+        return;
     }
-    if (times) *times = tot;
+    resident_reserve(max_chunk);
+    Resident &R = *res;
+    ensure_second_set();
+    hipStream_t M = R.stream, S = R.stream2, F = R.stream3, C = R.copy_stream;
+    auto chunk_size = [&](size_t k) { return std::min(max_chunk, batch - k * max_chunk); };
+    auto download = [&](size_t k) {           // chunk k lives in set k & 1; waits for its tail, not for the whole pipeline
+        SolveSet &cur = R.set[k & 1];
+        const size_t off = k * max_chunk, Bk = chunk_size(k);
+        ZK_HIP(hipStreamWaitEvent(C, cur.consumed, 0));
+        ZK_HIP(hipMemcpyAsync(out + off, cur.out.p, Bk * sizeof(ProofPoints), hipMemcpyDeviceToHost, C));
+        if (errs) ZK_HIP(hipMemcpyAsync(errs + off, cur.sb.err.p, Bk * sizeof(uint32_t), hipMemcpyDeviceToHost, C));
+        ZK_HIP(hipStreamSynchronize(C));
+    };
+    ZK_HIP(hipEventRecord(R.ev[0], M));
+    for (size_t k = 0; k < nchunks; k++) {
+        SolveSet &cur = R.set[k & 1];
+        if (k >= 2) download(k - 2);            // also guarantees that the set is free again
+        const size_t off = k * max_chunk, Bk = chunk_size(k);
+        R.B = Bk; cur.sb.B = Bk; R.ms.B = Bk; R.ms2.B = Bk;
+        upload_set(cur, Bk, inputs + off * ni, r + off, s + off, randomize ? randomize + off : nullptr, C);
+        ZK_HIP(hipEventRecord(cur.uploaded, C));
+        ZK_HIP(hipStreamWaitEvent(S, cur.uploaded, 0));
+        enqueue_solve(cur, has_commit ? R.ms2 : R.ms, S);
+        ZK_HIP(hipEventRecord(cur.solved, S));
+        ZK_HIP(hipStreamWaitEvent(M, cur.solved, 0));
+        enqueue_main(cur, M, k ? R.ev[11] : nullptr);
+        ZK_HIP(hipEventRecord(R.ev[10], M));
+        ZK_HIP(hipStreamWaitEvent(F, R.ev[10], 0));
+        enqueue_finalize(cur, F);
+        ZK_HIP(hipEventRecord(R.ev[11], F));
+        ZK_HIP(hipEventRecord(cur.consumed, F));
+    }
+    if (nchunks >= 2) download(nchunks - 2);
+    download(nchunks - 1);
+    ZK_HIP(hipStreamSynchronize(S));
+    ZK_HIP(hipStreamSynchronize(M));
+    ZK_HIP(hipStreamSynchronize(F));
+    R.last_set = (int)((nchunks - 1) & 1);
+    if (times) {
+        PhaseTimes t;
+        collect_times(R.set[(nchunks - 1) & 1], &t);
+        float tot;
+        ZK_HIP(hipEventElapsedTime(&tot, R.ev[0], R.ev[7]));
+        t.total = tot;
+        *times = t;
+    }
 }
 
 // parity-test hook: solved wires and quotient-stage products (A*B on the coset g<w>, natural order) of the last resident

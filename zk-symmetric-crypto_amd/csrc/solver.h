@@ -40,7 +40,7 @@ struct SolverBuffers {
     size_t B = 0;
     DevBuf<Fr> wires;          // [n_wires][B]
     DevBuf<Fr> a, b, c;        // [N][B]
-    DevBuf<uint32_t> inputs;   // [n_inputs][B] small integers
+    DevBuf<uint32_t> inputs;   // [B][n_inputs] small integers (instance-major, as the host builds them)
     DevBuf<Fr> randomize;      // [B] Montgomery
     DevBuf<Fr> challenge;      // [B] Montgomery (commitment challenge)
     DevBuf<uint32_t> err;      // [B] (code | constraint<<8)

@@ -510,7 +510,7 @@ __global__ __launch_bounds__(256) void k_assign_inputs(const uint32_t *__restric
     if (t >= (n_inputs + 1) * B) return;
     const size_t row = t / B;
     if (row == 0) { wires[t] = Fr::one(); return; }
-    const uint32_t v = in[t - B];
+    const uint32_t v = in[(t % B) * n_inputs + (row - 1)];      // inputs arrive instance-major [B][n_inputs]
     wires[t] = v == 0 ? Fr::zero() : (v == 1 ? Fr::one() : Fr::from_u32(v));
 }
 
