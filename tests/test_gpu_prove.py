@@ -233,19 +233,37 @@ def test_concurrent_init_and_prove(zk, oracle):
         assert base64.b64decode(got["proof"]) == exp and base64.b64decode(got["ciphertext"]) == out
 
 
-def test_prove_batch_larger_than_one_gpu_chunk(zk, oracle, algs):
-    """ProveBatch with more requests than the 1024-instance device chunk: processed in chunks, order preserved"""
-    alg = algs(0)
-    rng = H.SplitMix64(8080)
-    insts = [H.make_instance(alg, rng) for _ in range(1030)]
-    reqs = "[" + ",".join(H.request_json(alg, i).decode() for i in insts) + "]"
-    res = json.loads(zk.prove_batch_raw(reqs.encode()))
-    assert len(res) == 1030 and all("proof" in r for r in res)
-    vk = gf.vk_from_pk(H.oracle_pk(alg))
-    for k in (0, 1023, 1024, 1029):
+@pytest.mark.parametrize("alg,n", [(0, 3100), (1, 1030)])
+def test_prove_batch_larger_than_one_gpu_chunk(zk, oracle, algs, alg, n):
+    """ProveBatch with more requests than the 1024-instance device chunk: the chunks run software-pipelined on the device (working
+    sets are reused from the third chunk on; the AES circuits add the commitment round trip); order preserved, a bad request in the
+    middle keeps its slot, every checked proof verifies against ITS request"""
+    algs(alg)
+    rng = H.SplitMix64(8080 + alg)
+    insts = [H.make_instance(alg, rng) for _ in range(n)]
+    parts = [H.request_json(alg, i).decode() for i in insts]
+    parts.insert(1500 if n > 1500 else 700, json.dumps({"cipher": H.CIPHER[alg], "key": "AAAA", "blocks": [], "input": ""}))
+    bad_at = 1500 if n > 1500 else 700
+    res = json.loads(zk.prove_batch_raw(("[" + ",".join(parts) + "]").encode()))
+    assert len(res) == n + 1
+    assert isinstance(res[bad_at], str) and res[bad_at].startswith("key length must be")
+    del res[bad_at]
+    assert all(isinstance(r, dict) and "proof" in r for r in res)
+    npub = H.circuit(alg).r1cs.nb_public - 1
+    vk_bytes = gf.vk_bytes(gf.vk_from_pk(H.oracle_pk(alg)))
+    assert zk.init_verifier(alg, vk_bytes)
+    picks = sorted(set([0, 1, 1022, 1023, 1024, 1025, n - 1] + list(range(7, n, 211))))
+    for k in picks:
         wit, out = H.oracle_witness(alg, insts[k])
         assert base64.b64decode(res[k]["ciphertext"]) == out
-        assert pairing.groth16_verify(vk, gf.proof_parse(base64.b64decode(res[k]["proof"])), wit[:2304])
+        rq = json.loads(parts[k if k < bad_at else k + 1])
+        sig = {"ciphertext": res[k]["ciphertext"], "blocks": rq["blocks"], "input": rq["input"]}
+        assert zk.verify_raw(json.dumps({"cipher": H.CIPHER[alg], "proof": res[k]["proof"], "publicSignals": sig}).encode()), "proof %d does not verify" % k
+        if k + 1 < n:       # and it is not accidentally the neighbour's proof
+            assert not zk.verify_raw(json.dumps({"cipher": H.CIPHER[alg], "proof": res[k + 1]["proof"], "publicSignals": sig}).encode())
+    vk = gf.vk_from_pk(H.oracle_pk(alg))
+    wit, _ = H.oracle_witness(alg, insts[n - 1])
+    assert pairing.groth16_verify(vk, gf.proof_parse(base64.b64decode(res[n - 1]["proof"])), wit[:npub])
 
 
 @pytest.mark.parametrize("alg", [0, 2])
