@@ -57,7 +57,8 @@ class Algorithm {
     void upload_set(struct SolveSet &S, size_t B, const uint32_t *inputs, const U256 *r, const U256 *s, const U256 *randomize, hipStream_t st);
     void ensure_second_set();
     void enqueue_solve(struct SolveSet &S, MsmScratch &commit_scratch, hipStream_t st);
-    void enqueue_main(struct SolveSet &S, hipStream_t st, hipEvent_t before_msm = nullptr);
+    void enqueue_main(struct SolveSet &S, hipStream_t st, hipEvent_t before_msm, hipStream_t tail);
+    void enqueue_tail_early(struct SolveSet &S, hipStream_t st);
     void enqueue_finalize(struct SolveSet &S, hipStream_t st);
     void collect_times(struct SolveSet &S, PhaseTimes *times);
     std::unique_ptr<Resident> res;

@@ -119,7 +119,7 @@ struct Algorithm::Resident {
     DevBuf<G1XYZZ> f_t, f_u, f_v;
     int last_set = 0;               // the set that holds the most recent batch
     hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr, copy_stream = nullptr;
-    hipEvent_t ev[12] = {};     // [10] MSM sums of the current batch complete  [11] tail of the previous batch done
+    hipEvent_t ev[13] = {};     // [10] MSM sums of the current batch complete  [11] tail of the previous batch done  [12] A and B1 sums complete
 };
 
 Algorithm::Algorithm() {}
@@ -417,7 +417,7 @@ void Algorithm::enqueue_solve(SolveSet &S, MsmScratch &commit_scratch, hipStream
 
 // NTT + MSM of one solved batch on stream st.  R.ev[3..9] bracket the phases.  before_msm (optional): an event the MSMs must
 // wait for -- they overwrite the per-batch sums that the previous batch's tail (on another stream) still reads.
-void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm) {
+void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm, hipStream_t tail) {
     Resident &R = *res;
     const size_t B = R.B;
     ZK_HIP(hipEventRecord(R.ev[3], st));
@@ -427,6 +427,11 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm)
     if (before_msm) ZK_HIP(hipStreamWaitEvent(st, before_msm, 0));
     msm_batch(pk.A, S.sb.wires.p, B, R.ms, R.m_ar.p, st);
     msm_batch(pk.B1, S.sb.wires.p, B, R.ms, R.m_bs1.p, st);
+    // Ar and Bs1 only need these two sums: their blinding and the two variable-base multiplications s*Ar, r*Bs1 (4 ms of
+    // dependent doublings whatever the batch size) start now on the tail stream, under the remaining MSMs
+    ZK_HIP(hipEventRecord(R.ev[12], st));
+    ZK_HIP(hipStreamWaitEvent(tail, R.ev[12], 0));
+    enqueue_tail_early(S, tail);
     msm_batch(pk.K, S.sb.wires.p, B, R.ms, R.m_k.p, st);
     // sum_k h_k Z_k = sum_i (a_i b_i) Ze_i + (a part linear in the wires that sits in K); c only serves as the buffer of the
     // instance-major products
@@ -437,15 +442,21 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm)
     ZK_HIP(hipEventRecord(R.ev[6], st));
 }
 
-// Tail of one batch: blinding terms, Krs, canonical outputs.  1024-thread kernels with long dependent chains (two variable-base
-// scalar multiplications per proof): latency-bound, so the pipelined driver runs it on its own stream under the next batch.
-void Algorithm::enqueue_finalize(SolveSet &S, hipStream_t st) {
+// Tail of one batch, first half: Ar, Bs1 (blinded, affine), -rs*delta, s*Ar, r*Bs1.  1024-thread kernels with long dependent
+// chains (two variable-base scalar multiplications per proof): latency-bound, so they run on their own stream.
+void Algorithm::enqueue_tail_early(SolveSet &S, hipStream_t st) {
     Resident &R = *res;
     const size_t B = R.B;
     hipLaunchKernelGGL(k_finalize_stage1, dim3(ceil_div(B, 64), 3), dim3(64), 0, st, R.m_ar.p, R.m_bs1.p, pk.g1_misc.p, pk.delta_tab.p, S.r.p, S.s.p,
                        R.ar_aff.p, R.bs1_aff.p, R.f_t.p, B);
-    hipLaunchKernelGGL(k_finalize_g2, dim3(ceil_div(B, 64)), dim3(64), 0, st, R.m_bs2.p, pk.g2_misc.p, pk.delta2_tab.p, S.s.p, S.out.p, B);
     hipLaunchKernelGGL(k_finalize_stage2, dim3(ceil_div(B, 64), 2), dim3(64), 0, st, R.ar_aff.p, R.bs1_aff.p, S.r.p, S.s.p, R.f_u.p, R.f_v.p, B);
+    ZK_HIP(hipGetLastError());
+}
+// second half, once every sum of the batch is complete: Bs, Krs, canonical outputs
+void Algorithm::enqueue_finalize(SolveSet &S, hipStream_t st) {
+    Resident &R = *res;
+    const size_t B = R.B;
+    hipLaunchKernelGGL(k_finalize_g2, dim3(ceil_div(B, 64)), dim3(64), 0, st, R.m_bs2.p, pk.g2_misc.p, pk.delta2_tab.p, S.s.p, S.out.p, B);
     hipLaunchKernelGGL(k_finalize_stage3, dim3(ceil_div(B, 64)), dim3(64), 0, st, R.m_k.p, R.m_z.p, R.f_t.p, R.f_u.p, R.f_v.p, R.ar_aff.p, S.out.p, B);
     hipLaunchKernelGGL(k_store_commit, dim3(ceil_div(B, 64)), dim3(64), 0, st, S.com_aff.p, S.pok_aff.p, S.out.p, B, has_commit ? 1 : 0);
     ZK_HIP(hipGetLastError());
@@ -467,9 +478,12 @@ void Algorithm::resident_prove(PhaseTimes *times) {
     hipStream_t st = R.stream;
     R.last_set = 0;
     enqueue_solve(R.set[0], R.ms, st);
-    enqueue_main(R.set[0], st);
-    enqueue_finalize(R.set[0], st);
+    enqueue_main(R.set[0], st, nullptr, R.stream3);
+    ZK_HIP(hipEventRecord(R.ev[10], st));
+    ZK_HIP(hipStreamWaitEvent(R.stream3, R.ev[10], 0));
+    enqueue_finalize(R.set[0], R.stream3);
     ZK_HIP(hipStreamSynchronize(st));
+    ZK_HIP(hipStreamSynchronize(R.stream3));
     if (times) {
         collect_times(R.set[0], times);
         ZK_HIP(hipEventElapsedTime(&times->total, R.set[0].t0, R.ev[7]));
@@ -510,7 +524,7 @@ void Algorithm::resident_prove_pipelined(int nsteps, PhaseTimes *times) {
     for (int k = 0; k < nsteps; k++) {
         SolveSet &cur = R.set[k & 1], &nxt = R.set[(k + 1) & 1];
         ZK_HIP(hipStreamWaitEvent(M, cur.solved, 0));
-        enqueue_main(cur, M, k ? R.ev[11] : nullptr);
+        enqueue_main(cur, M, k ? R.ev[11] : nullptr, F);
         ZK_HIP(hipEventRecord(R.ev[10], M));
         ZK_HIP(hipStreamWaitEvent(F, R.ev[10], 0));
         enqueue_finalize(cur, F);
@@ -581,7 +595,7 @@ void Algorithm::prove_batch(size_t batch, const uint32_t *inputs, const U256 *r,
         enqueue_solve(cur, has_commit ? R.ms2 : R.ms, S);
         ZK_HIP(hipEventRecord(cur.solved, S));
         ZK_HIP(hipStreamWaitEvent(M, cur.solved, 0));
-        enqueue_main(cur, M, k ? R.ev[11] : nullptr);
+        enqueue_main(cur, M, k ? R.ev[11] : nullptr, F);
         ZK_HIP(hipEventRecord(R.ev[10], M));
         ZK_HIP(hipStreamWaitEvent(F, R.ev[10], 0));
         enqueue_finalize(cur, F);
