@@ -25,7 +25,15 @@
 
 namespace zk {
 
-static constexpr int SEG_LOG = 6;            // L = 64 buckets per segment
+// buckets per bucket-reduction thread: 64 when that still gives >= 32k threads (any MSM at batch 1024), else 16 -- a small batch
+// (one Prove() call) is pure latency of dependent additions, and 4x more threads cut it 4x
+static constexpr int SEG_LOG = 6, SEG_LOG_SMALL = 4;
+static inline uint32_t seg_len(uint32_t nb, size_t B) {
+    uint32_t L = nb < (1u << SEG_LOG) ? nb : (1u << SEG_LOG);
+    if ((size_t)(nb / L) * B < 32768 && nb > (1u << SEG_LOG_SMALL)) L = 1u << SEG_LOG_SMALL;
+    return L;
+}
+static constexpr size_t FOLD_GROUP = 8;      // partial sums are folded 8 at a time, level by level
 // Conditional-sum path (scalars 0 / +1 / -1): bases are taken TERN_G at a time and every signed subset sum of a group is
 // precomputed, so a group costs one mixed addition whatever its +-1 pattern is.  Index of a pattern: sum (t_i + 1) 3^i,
 // t_i in {-1, 0, +1}; the patterns above the centre (all zero) are stored, the ones below are their negatives.
@@ -455,9 +463,8 @@ ZK_ACC_G1(false)
 // thread (b, seg): running-sum reduction of buckets [seg*L, seg*L + L) of instance b
 template <class F>
 __global__ __launch_bounds__(64) void k_msm_bucket_reduce(const XYZZ<F> *__restrict__ sums, const uint32_t *__restrict__ bucket_start, int c, size_t B,
-                                                          XYZZ<F> *__restrict__ part, size_t part_stride, size_t part_off) {
+                                                          XYZZ<F> *__restrict__ part, size_t part_stride, size_t part_off, uint32_t L) {
     const uint32_t nb = 1u << (c - 1);
-    const uint32_t L = nb < (1u << SEG_LOG) ? nb : (1u << SEG_LOG);
     const uint32_t nseg = nb / L;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (size_t)nseg * B) return;
@@ -644,14 +651,12 @@ static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, M
     const size_t n = mb.n;
     const int c = mb.c, W = mb.W;
     const uint32_t nb = 1u << (c - 1);
-    const uint32_t L = nb < (1u << SEG_LOG) ? nb : (1u << SEG_LOG);
+    const uint32_t L = seg_len(nb, B);
     const size_t nseg = nb / L;
     const size_t nchunks = (n + ONES_CHUNK - 1) / ONES_CHUNK;
     const size_t max_entries = n * W;
     const size_t npart = nchunks + nseg;
-    const size_t GROUP = 32;
-    const size_t nlvl1 = (npart + GROUP - 1) / GROUP;
-    const size_t stride = npart + nlvl1;      // level-0 partials followed by level-1 partials
+    const size_t stride = msm_part_stride(n, c);      // level-0 partials followed by the fold levels
     if (sc.entries.n < B * max_entries + 1 || sc.bucket_start.n < B * (nb + 1) || PartSel<F>::cap(sc) < B * stride + 1)
         throw ZkError("msm scratch too small");
     XYZZ<F> *part = PartSel<F>::get(sc);
@@ -707,9 +712,17 @@ static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, M
         hipLaunchKernelGGL((k_msm_accumulate<F, false>), dim3(ceil_div((size_t)nlanes * B, 64)), dim3(64), 0, s, mb.table.p, sc.bucket_start.p, sc.entries.p,
                            max_entries, c, B, nlanes, sums);
     if (seg_events) ZK_HIP(hipEventRecord(seg_events[1], s));
-    hipLaunchKernelGGL(k_msm_bucket_reduce<F>, dim3(ceil_div(nseg * B, 64)), dim3(64), 0, s, sums, sc.bucket_start.p, c, B, part, stride, nchunks);
-    hipLaunchKernelGGL(k_sum_groups<F>, dim3(ceil_div(nlvl1 * B, 64)), dim3(64), 0, s, part, stride, npart, GROUP, part + npart, stride, B);
-    hipLaunchKernelGGL(k_sum_groups<F>, dim3(ceil_div(B, 64)), dim3(64), 0, s, part + npart, stride, nlvl1, nlvl1, out, (size_t)1, B);
+    hipLaunchKernelGGL(k_msm_bucket_reduce<F>, dim3(ceil_div(nseg * B, 64)), dim3(64), 0, s, sums, sc.bucket_start.p, c, B, part, stride, nchunks, L);
+    // fold the npart partial sums of every instance, FOLD_GROUP at a time; the last level writes out[b]
+    size_t off = 0, cnt = npart;
+    do {
+        const size_t groups = (cnt + FOLD_GROUP - 1) / FOLD_GROUP;
+        const bool last = groups == 1;
+        hipLaunchKernelGGL(k_sum_groups<F>, dim3(ceil_div(groups * B, 64)), dim3(64), 0, s, part + off, stride, cnt, FOLD_GROUP,
+                           last ? out : part + off + cnt, last ? (size_t)1 : stride, B);
+        off += cnt;
+        cnt = groups;
+    } while (cnt > 1);
     ZK_HIP(hipGetLastError());
 }
 void msm_batch(const MsmBasesG1 &mb, const Fr *sc, size_t B, MsmScratch &scr, G1XYZZ *out, hipStream_t s, hipEvent_t *ev) { msm_batch_impl<Fp>(mb, sc, B, scr, out, s, ev); }
@@ -717,9 +730,10 @@ void msm_batch(const MsmBasesG2 &mb, const Fr *sc, size_t B, MsmScratch &scr, G2
 
 size_t msm_part_stride(size_t n, int c) {
     const uint32_t nb = 1u << (c - 1);
-    const uint32_t L = nb < (1u << SEG_LOG) ? nb : (1u << SEG_LOG);
-    size_t npart = (n + ONES_CHUNK - 1) / ONES_CHUNK + nb / L;
-    return npart + (npart + 31) / 32;
+    const uint32_t L = nb > (1u << SEG_LOG_SMALL) ? (1u << SEG_LOG_SMALL) : nb;     // the small-batch segment length gives the most partials
+    size_t npart = (n + ONES_CHUNK - 1) / ONES_CHUNK + nb / L, total = 0;
+    for (size_t cnt = npart; cnt > 1; cnt = (cnt + FOLD_GROUP - 1) / FOLD_GROUP) total += cnt;
+    return total + 2;
 }
 
 // ------------------------------------------------------------------------ point import / export

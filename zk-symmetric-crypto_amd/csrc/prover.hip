@@ -119,7 +119,7 @@ struct Algorithm::Resident {
     DevBuf<G1XYZZ> f_t, f_u, f_v;
     int last_set = 0;               // the set that holds the most recent batch
     hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr, copy_stream = nullptr;
-    hipEvent_t ev[13] = {};     // [10] MSM sums of the current batch complete  [11] tail of the previous batch done  [12] A and B1 sums complete
+    hipEvent_t ev[14] = {};     // [10] MSM sums of the current batch complete  [11] tail of the previous batch done  [12] A and B1 sums complete  [13] end of the G1 MSMs
 };
 
 Algorithm::Algorithm() {}
@@ -432,14 +432,19 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm,
     ZK_HIP(hipEventRecord(R.ev[12], st));
     ZK_HIP(hipStreamWaitEvent(tail, R.ev[12], 0));
     enqueue_tail_early(S, tail);
+    ZK_HIP(hipEventRecord(R.ev[5], st));
+    // the G2 sum next, so that its blinding and affine conversion also run under the two largest MSMs
+    msm_batch(pk.B2, S.sb.wires.p, B, R.ms, R.m_bs2.p, st);
+    ZK_HIP(hipEventRecord(R.ev[6], st));
+    ZK_HIP(hipStreamWaitEvent(tail, R.ev[6], 0));
+    hipLaunchKernelGGL(k_finalize_g2, dim3(ceil_div(B, 64)), dim3(64), 0, tail, R.m_bs2.p, pk.g2_misc.p, pk.delta2_tab.p, S.s.p, S.out.p, B);
     msm_batch(pk.K, S.sb.wires.p, B, R.ms, R.m_k.p, st);
     // sum_k h_k Z_k = sum_i (a_i b_i) Ze_i + (a part linear in the wires that sits in K); c only serves as the buffer of the
     // instance-major products
     fr_transpose_mul(S.sb.a.p, S.sb.b.p, S.sb.c.p, N, B, N, st);
     msm_batch(pk.Z, S.sb.c.p, B, R.ms, R.m_z.p, st, &R.ev[8]);
-    ZK_HIP(hipEventRecord(R.ev[5], st));
-    msm_batch(pk.B2, S.sb.wires.p, B, R.ms, R.m_bs2.p, st);
-    ZK_HIP(hipEventRecord(R.ev[6], st));
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipEventRecord(R.ev[13], st));
 }
 
 // Tail of one batch, first half: Ar, Bs1 (blinded, affine), -rs*delta, s*Ar, r*Bs1.  1024-thread kernels with long dependent
@@ -452,11 +457,10 @@ void Algorithm::enqueue_tail_early(SolveSet &S, hipStream_t st) {
     hipLaunchKernelGGL(k_finalize_stage2, dim3(ceil_div(B, 64), 2), dim3(64), 0, st, R.ar_aff.p, R.bs1_aff.p, S.r.p, S.s.p, R.f_u.p, R.f_v.p, B);
     ZK_HIP(hipGetLastError());
 }
-// second half, once every sum of the batch is complete: Bs, Krs, canonical outputs
+// last part, once every sum of the batch is complete: Krs, canonical outputs
 void Algorithm::enqueue_finalize(SolveSet &S, hipStream_t st) {
     Resident &R = *res;
     const size_t B = R.B;
-    hipLaunchKernelGGL(k_finalize_g2, dim3(ceil_div(B, 64)), dim3(64), 0, st, R.m_bs2.p, pk.g2_misc.p, pk.delta2_tab.p, S.s.p, S.out.p, B);
     hipLaunchKernelGGL(k_finalize_stage3, dim3(ceil_div(B, 64)), dim3(64), 0, st, R.m_k.p, R.m_z.p, R.f_t.p, R.f_u.p, R.f_v.p, R.ar_aff.p, S.out.p, B);
     hipLaunchKernelGGL(k_store_commit, dim3(ceil_div(B, 64)), dim3(64), 0, st, S.com_aff.p, S.pok_aff.p, S.out.p, B, has_commit ? 1 : 0);
     ZK_HIP(hipGetLastError());
@@ -468,7 +472,9 @@ void Algorithm::collect_times(SolveSet &S, PhaseTimes *times) {
     float t01, t12, t23, t34, t45, t56, t67;
     ZK_HIP(hipEventElapsedTime(&t01, S.t0, S.t1)); ZK_HIP(hipEventElapsedTime(&t12, S.t1, S.t2)); ZK_HIP(hipEventElapsedTime(&t23, S.t2, S.t3));
     ZK_HIP(hipEventElapsedTime(&t34, R.ev[3], R.ev[4])); ZK_HIP(hipEventElapsedTime(&t45, R.ev[4], R.ev[5]));
-    ZK_HIP(hipEventElapsedTime(&t56, R.ev[5], R.ev[6])); ZK_HIP(hipEventElapsedTime(&t67, R.ev[6], R.ev[7]));
+    float t6e;
+    ZK_HIP(hipEventElapsedTime(&t56, R.ev[5], R.ev[6])); ZK_HIP(hipEventElapsedTime(&t6e, R.ev[6], R.ev[13])); ZK_HIP(hipEventElapsedTime(&t67, R.ev[13], R.ev[7]));
+    t45 += t6e;
     ZK_HIP(hipEventElapsedTime(&times->z_segments, R.ev[8], R.ev[9]));
     times->solve = t01 + t23; times->commit = t12; times->ntt = t34; times->msm_g1 = t45; times->msm_g2 = t56; times->finalize = t67;
 }
