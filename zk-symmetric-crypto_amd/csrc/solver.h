@@ -48,6 +48,7 @@ struct SolverBuffers {
     void reserve(const SolverProgram &p, size_t B);
 };
 
+
 // inputs -> wires rows 0..n_inputs ; zero a,b,c ; clear errors
 void solver_begin(const SolverProgram &p, SolverBuffers &buf, hipStream_t s);
 // run levels [first_level, last_level)

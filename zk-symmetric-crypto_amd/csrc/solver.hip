@@ -167,9 +167,19 @@ void SolverProgram::build(const R1cs &cs, hipStream_t s) {
                     count_tab.push_back(v);
                     q += 3;
                 }
-                prg.insert(prg.end(), {OP_COUNT, ntab, ncol, nq, out_start, (uint32_t)n_count_slots, table_off});
+                const size_t hdr = prg.size();
+                prg.insert(prg.end(), {OP_COUNT, ntab, ncol, nq, out_start, (uint32_t)n_count_slots, table_off, 0u});
                 n_count_slots++;
-                for (uint32_t k = 0; k < nq * ncol; k++) push_linexp(prg, q);
+                // word 7: offset (from the first query) of a table with the start of every query row, so that the slices of a
+                // workgroup can each take every SL-th query although the rows are variable-length linear expressions
+                std::vector<uint32_t> row_start(nq);
+                const size_t q0 = prg.size();
+                for (uint32_t j = 0; j < nq; j++) {
+                    row_start[j] = (uint32_t)(prg.size() - q0);
+                    for (uint32_t col = 0; col < ncol; col++) push_linexp(prg, q);
+                }
+                prg[hdr + 7] = (uint32_t)(prg.size() - q0);
+                prg.insert(prg.end(), row_start.begin(), row_start.end());
                 if (ntab > n_count_rows) n_count_rows = ntab;
             } else if (hid == HINT_RANDOMIZE) {
                 if (out_end - out_start != 1) throw ZkError("Randomize hint with != 1 output");
@@ -328,8 +338,10 @@ __device__ __forceinline__ Fr eval_linexp(const SolveCtx &cx, const uint32_t *&p
 // Cooperative evaluation of a long linear expression by the SL "slices" of a workgroup (threadIdx.y): the add32 /
 // FromBinary constraints have ~100 terms and, evaluated by one lane, set the latency of every dependency level.
 // Must be called by all threads of the workgroup (n and p are workgroup-uniform).  Result valid in slice 0.
-static constexpr int SL = 4;
+// Workgroup shapes (instances x slices = 256 threads): 64 x 4 for real batches; 16 x 16 and 8 x 32 for the small batches of
+// single Prove() calls, where spare lanes are better spent on the terms of an expression than on instances that do not exist.
 static constexpr int COOP_MIN_TERMS = 16;
+template <int LX, int SL>
 __device__ __forceinline__ Fr eval_terms_coop(const SolveCtx &cx, const uint32_t *&p, uint32_t n, size_t b, Fr *red) {
     const int slice = threadIdx.y, lane = threadIdx.x;
     if (n < COOP_MIN_TERMS) {
@@ -342,19 +354,20 @@ __device__ __forceinline__ Fr eval_terms_coop(const SolveCtx &cx, const uint32_t
     const uint32_t *q = p + 2 * lo;
     Fr part = lo < hi ? eval_terms(cx, q, hi - lo, b) : Fr::zero();
     p += 2 * n;
-    red[slice * 64 + lane] = part;
+    red[slice * LX + lane] = part;
     __syncthreads();
     Fr acc = Fr::zero();
     if (slice == 0) {
-#pragma unroll
-        for (int k = 0; k < SL; k++) acc = acc + red[k * 64 + lane];
+#pragma unroll 4
+        for (int k = 0; k < SL; k++) acc = acc + red[k * LX + lane];
     }
     __syncthreads();
     return acc;
 }
+template <int LX, int SL>
 __device__ __forceinline__ Fr eval_linexp_coop(const SolveCtx &cx, const uint32_t *&p, size_t b, Fr *red) {
     uint32_t n = *p++;
-    return eval_terms_coop(cx, p, n, b, red);
+    return eval_terms_coop<LX, SL>(cx, p, n, b, red);
 }
 __device__ __forceinline__ void report(const SolveCtx &cx, size_t b, uint32_t code, uint32_t detail) {
     atomicCAS(&cx.err[b], 0u, code | (detail << 8));
@@ -368,14 +381,16 @@ __device__ __forceinline__ bool small_index(const Fr &v_mont, uint32_t bound, ui
     return hi == 0 && idx < bound;
 }
 
+template <int LX, int SL>
 __global__ __launch_bounds__(256) void k_solve_level(SolveCtx cx, const uint32_t *__restrict__ instr_off, const uint32_t *__restrict__ level_instr,
                                                      uint32_t count) {
-    // grid = (ceil(B / 64), instructions of the level), block = (64 instances, SL slices): the instruction is uniform per
+    // grid = (ceil(B / LX), instructions of the level), block = (LX instances, SL slices): the instruction is uniform per
     // workgroup, so the program words are scalar loads and all control flow on them is wave-uniform; the slices share
-    // the evaluation of long linear expressions, slice 0 finishes the instruction
-    __shared__ Fr red[SL * 64];
+    // the evaluation of long linear expressions (and the queries of a countHint), slice 0 finishes the instruction
+    static_assert(LX * SL == 256, "workgroup shape");
+    __shared__ Fr red[SL * LX];
     const size_t B = cx.B;
-    const size_t b_raw = (size_t)blockIdx.x * 64 + threadIdx.x;
+    const size_t b_raw = (size_t)blockIdx.x * LX + threadIdx.x;
     const bool live = b_raw < B;
     const size_t b = live ? b_raw : B - 1;            // dead lanes shadow the last instance (no early exit before barriers)
     const bool lead = threadIdx.y == 0 && live;
@@ -386,9 +401,9 @@ __global__ __launch_bounds__(256) void k_solve_level(SolveCtx cx, const uint32_t
     if (op == OP_R1C) {
         const uint32_t cons = p[1], nL = p[2], nR = p[3], nO = p[4], loc = p[5], sw = p[6], sc = p[7];
         p += 8;
-        Fr vL = eval_terms_coop(cx, p, nL, b, red);
-        Fr vR = eval_terms_coop(cx, p, nR, b, red);
-        Fr vO = eval_terms_coop(cx, p, nO, b, red);
+        Fr vL = eval_terms_coop<LX, SL>(cx, p, nL, b, red);
+        Fr vR = eval_terms_coop<LX, SL>(cx, p, nR, b, red);
+        Fr vO = eval_terms_coop<LX, SL>(cx, p, nO, b, red);
         if (!lead) return;
         if (loc == 0) {
             if (mul_fast(vL, vR) != vO) report(cx, b, SERR_UNSATISFIED, cons);
@@ -416,7 +431,7 @@ __global__ __launch_bounds__(256) void k_solve_level(SolveCtx cx, const uint32_t
     } else if (op == OP_NBITS) {
         const uint32_t nout = p[1], out0 = p[2];
         p += 3;
-        Fr v = eval_linexp_coop(cx, p, b, red);
+        Fr v = eval_linexp_coop<LX, SL>(cx, p, b, red);
         if (!lead) return;
         v = v.from_mont();
         const Fr one = Fr::one(), zero = Fr::zero();
@@ -424,6 +439,36 @@ __global__ __launch_bounds__(256) void k_solve_level(SolveCtx cx, const uint32_t
             const bool bit = k < 256 && ((v.l[k >> 5] >> (k & 31)) & 1);
             cx.wires[(size_t)(out0 + k) * B + b] = bit ? one : zero;
         }
+    } else if (op == OP_COUNT) {
+        // countHint of a log-derivative lookup: multiplicity of every table row among nq (~3 600 for the AES S-box) queries.
+        // The slices take every SL-th query (one lane used to walk all of them: the three longest levels of the AES circuits,
+        // 3-4 ms each); counters live in global memory, hence atomics.
+        const uint32_t ntab = p[1], ncol = p[2], nq = p[3], out0 = p[4], slot = p[5], toff = p[6];
+        const uint32_t *row_start = p + 8 + p[7];
+        p += 8;
+        const uint32_t slice = threadIdx.y;
+        uint32_t *cnt = cx.count_scratch + (size_t)slot * cx.count_rows * B;
+        if (live)
+            for (uint32_t r = slice; r < ntab; r += SL) cnt[(size_t)r * B + b] = 0;
+        __syncthreads();
+        const Fr *tab = cx.count_tables + toff;
+        for (uint32_t j = slice; j < nq; j += SL) {
+            const uint32_t *pq = p + row_start[j];
+            // first column of a logderivlookup table row is the row index: O(1) candidate, then full-row compare
+            uint32_t row = 0;
+            bool ok = true;
+            for (uint32_t col = 0; col < ncol; col++) {
+                const Fr qv = eval_linexp(cx, pq, b);
+                if (col == 0) ok = small_index(qv, ntab, row);
+                if (ok && tab[(size_t)row * ncol + col] != qv) ok = false;
+            }
+            if (!live) continue;
+            if (ok) atomicAdd(&cnt[(size_t)row * B + b], 1u);
+            else report(cx, b, SERR_COUNT_QUERY, instr);
+        }
+        __syncthreads();
+        if (live)
+            for (uint32_t r = slice; r < ntab; r += SL) cx.wires[(size_t)(out0 + r) * B + b] = Fr::from_u32(cnt[(size_t)r * B + b]);
     } else if (!lead) {
         return;                                   // the remaining ops have short expressions: slice 0 alone
     } else if (op == OP_LOOKUP) {
@@ -435,25 +480,6 @@ __global__ __launch_bounds__(256) void k_solve_level(SolveCtx cx, const uint32_t
             if (!small_index(v, nent, idx)) { report(cx, b, SERR_LOOKUP_RANGE, instr); idx = 0; }
             cx.wires[(size_t)(w0 + q) * B + b] = cx.tables[(size_t)tb * nent + idx];
         }
-    } else if (op == OP_COUNT) {
-        const uint32_t ntab = p[1], ncol = p[2], nq = p[3], out0 = p[4], slot = p[5], toff = p[6];
-        p += 7;
-        uint32_t *cnt = cx.count_scratch + (size_t)slot * cx.count_rows * B;
-        for (uint32_t r = 0; r < ntab; r++) cnt[(size_t)r * B + b] = 0;
-        const Fr *tab = cx.count_tables + toff;
-        for (uint32_t j = 0; j < nq; j++) {
-            // first column of a logderivlookup table row is the row index: O(1) candidate, then full-row compare
-            uint32_t row = 0;
-            bool ok = true;
-            for (uint32_t col = 0; col < ncol; col++) {
-                const Fr qv = eval_linexp(cx, p, b);
-                if (col == 0) ok = small_index(qv, ntab, row);
-                if (ok && tab[(size_t)row * ncol + col] != qv) ok = false;
-            }
-            if (ok) cnt[(size_t)row * B + b] += 1;
-            else report(cx, b, SERR_COUNT_QUERY, instr);
-        }
-        for (uint32_t r = 0; r < ntab; r++) cx.wires[(size_t)(out0 + r) * B + b] = Fr::from_u32(cnt[(size_t)r * B + b]);
     } else if (op == OP_RANDOMIZE) {
         cx.wires[(size_t)p[1] * B + b] = cx.randomize[b];
     } else if (op == OP_BSB22) {
@@ -532,7 +558,12 @@ void solver_run_levels(const SolverProgram &p, SolverBuffers &buf, size_t first_
         if (!lv.count) continue;
         for (uint32_t off = 0; off < lv.count; off += 65535) {       // grid.y limit
             const uint32_t cnt = lv.count - off < 65535 ? lv.count - off : 65535;
-            hipLaunchKernelGGL(k_solve_level, dim3(ceil_div(buf.B, 64), cnt), dim3(64, SL), 0, s, cx, p.instr_off.p, p.level_instr.p + lv.first + off, cnt);
+            if (buf.B <= 8)
+                hipLaunchKernelGGL((k_solve_level<8, 32>), dim3(ceil_div(buf.B, 8), cnt), dim3(8, 32), 0, s, cx, p.instr_off.p, p.level_instr.p + lv.first + off, cnt);
+            else if (buf.B <= 16)
+                hipLaunchKernelGGL((k_solve_level<16, 16>), dim3(ceil_div(buf.B, 16), cnt), dim3(16, 16), 0, s, cx, p.instr_off.p, p.level_instr.p + lv.first + off, cnt);
+            else
+                hipLaunchKernelGGL((k_solve_level<64, 4>), dim3(ceil_div(buf.B, 64), cnt), dim3(64, 4), 0, s, cx, p.instr_off.p, p.level_instr.p + lv.first + off, cnt);
         }
         if (lv.div_count)
             hipLaunchKernelGGL(k_solve_divisions, dim3(ceil_div(buf.B, 256), ceil_div(lv.div_count, DIV_GROUP)), dim3(256), 0, s, cx,
