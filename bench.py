@@ -87,8 +87,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # K steps = K passes over the resident batch.  Default: consecutive passes are software-pipelined on two HIP streams
-    # (witness solve of pass k+1 under the NTT + MSM stage of pass k); every pass does the full work.
+    # K steps = K passes over the resident batch.  Default: consecutive passes are software-pipelined on three HIP streams
+    # (witness solve of pass k+1 and proof tail of pass k-1 under the NTT + MSM stage of pass k); every pass does the full work.
     if args.no_pipeline:
         for _ in range(args.warmup):
             rb.step()
@@ -140,7 +140,7 @@ def main():
                                    % (H.CIPHER[alg], 2 if alg == 0 else 5, B),
                        "algorithm_id": alg, "batch_per_gpu": B, "pipelined_steps": not args.no_pipeline, "parallelism": "dp%d (independent proofs, no collective)" % world,
                        "blocks_per_s": value * (2 if alg == 0 else 5)},
-            "phases_ms": mean, "phases_note": ("pipelined: 'solve' (+'commit') ran on a second stream UNDER the previous pass's ntt/msm and is not additive; total = whole call / steps" if not args.no_pipeline else "single stream: phases are additive"), "solver_ok": ok, "init_s": t_init, "setup_s": t_setup,
+            "phases_ms": mean, "phases_note": ("pipelined: 'solve' (+'commit') and 'finalize' ran on their own streams UNDER the neighbouring passes' ntt/msm and are not additive; total = whole call / steps" if not args.no_pipeline else "single stream: phases are additive"), "solver_ok": ok, "init_s": t_init, "setup_s": t_setup,
             "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate<Fp, dense> (bucket accumulation of the quotient MSM over G1.Z)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launch_ms": zdur_ms, "algorithmic_bytes_per_launch": zbytes,

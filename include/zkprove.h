@@ -75,12 +75,13 @@ int ZkpSetup(GoSlice r1cs, const uint8_t *toxic192, int raw, void **pk_out, long
  * (public inputs without the constant one, then secret), r/s/randomize: [batch][32] canonical LE.
  * zkp_bench_step = one pass of the whole proving path over the resident batch; times7 (ms, HIP events):
  * solve, commit, ntt, msm_g1, msm_g2, finalize, total, z_segments (times7 has room for 8 floats;
- * z_segments = the dominant kernel k_msm_segments<Fp> of the quotient MSM alone).  proofs: [batch][384] canonical LE affine
+ * z_segments = the dominant kernel k_msm_accumulate<Fp, true> of the quotient MSM alone).  proofs: [batch][384] canonical LE affine
  * coordinates Ar(64) Bs(128: x.a0 x.a1 y.a0 y.a1) Krs(64) commitment(64) pok(64). */
 long zkp_n_inputs(int algorithmID);
 int zkp_bench_upload(int algorithmID, long batch, const uint32_t *inputs, const uint8_t *r, const uint8_t *s, const uint8_t *randomize);
 int zkp_bench_step(int algorithmID, float *times7);
-/* nsteps passes back to back; the witness solve of pass k+1 runs on a second stream under the NTT + MSM stage of pass k.
+/* nsteps passes back to back; the witness solve of pass k+1 and the proof tail of pass k-1 run on their own streams under the
+ * NTT + MSM stage of pass k.
  * times8: phase times of the last pass, [6] = whole call / nsteps */
 int zkp_bench_steps(int algorithmID, int nsteps, float *times8);
 int zkp_bench_fetch(int algorithmID, uint8_t *proofs, uint32_t *errs);

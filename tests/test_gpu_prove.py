@@ -1,5 +1,5 @@
 """GPU parity of the whole proving path through the C ABI (InitAlgorithm / Prove / batch API) against
-the CPU oracle: solved wires, quotient coefficients and final proof bytes are bit-identical for the same
+the CPU oracle: solved wires, the quotient stage and final proof bytes are bit-identical for the same
 (witness, r, s, randomize); proofs verify under the independent pairing check; tampering is rejected."""
 import base64
 import json

@@ -66,12 +66,10 @@ struct MsmScratch {
 
 // out[b] (+)= sum_j scalars[row_j][b] * P_j for b in [0,B).  scalars: [rows][B] Fr Montgomery.
 // If accumulate is false out[b] is overwritten.
-// seg_events (optional): two events recorded around the bucket kernel (k_msm_segments) for the roofline line
+// seg_events (optional): two events recorded around the bucket-accumulation kernel (k_msm_accumulate) for the roofline line
 void msm_batch(const MsmBasesG1 &mb, const Fr *scalars, size_t B, MsmScratch &sc, G1XYZZ *out, hipStream_t s, hipEvent_t *seg_events = nullptr);
 void msm_batch(const MsmBasesG2 &mb, const Fr *scalars, size_t B, MsmScratch &sc, G2XYZZ *out, hipStream_t s);
 
-// instance-major copy: out[b * stride + i] = in[i * B + b]
-void fr_transpose(const Fr *in, Fr *out, size_t rows, size_t B, size_t stride, hipStream_t s);
 // out[b * stride + i] = x[i * B + b] * y[i * B + b]
 void fr_transpose_mul(const Fr *x, const Fr *y, Fr *out, size_t rows, size_t B, size_t stride, hipStream_t s);
 

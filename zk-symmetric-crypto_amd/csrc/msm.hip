@@ -574,27 +574,8 @@ __global__ __launch_bounds__(256) void k_msm_ones(const Affine<F> *__restrict__ 
     part[b * part_stride + part_off + chunk] = acc;
 }
 
-// instance-major copy of a [rows][B] matrix: out[b * stride + i] = in[i * B + b]  (tiled through LDS)
-__global__ __launch_bounds__(256) void k_transpose_fr(const Fr *__restrict__ in, Fr *__restrict__ out, size_t rows, size_t B, size_t stride) {
-    __shared__ uint4 tile[2][32][33];
-    const size_t i0 = (size_t)blockIdx.x * 32, b0 = (size_t)blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
-    const uint4 *src = (const uint4 *)in;
-    uint4 *dst = (uint4 *)out;
-    for (int r = ty; r < 32; r += 8) {
-        const size_t i = i0 + r, b = b0 + tx;
-        if (i < rows && b < B) { tile[0][r][tx] = src[(i * B + b) * 2]; tile[1][r][tx] = src[(i * B + b) * 2 + 1]; }
-    }
-    __syncthreads();
-    for (int r = ty; r < 32; r += 8) {
-        const size_t b = b0 + r, i = i0 + tx;
-        if (i < rows && b < B) { dst[(b * stride + i) * 2] = tile[0][tx][r]; dst[(b * stride + i) * 2 + 1] = tile[1][tx][r]; }
-    }
-}
-void fr_transpose(const Fr *in, Fr *out, size_t rows, size_t B, size_t stride, hipStream_t s) {
-    hipLaunchKernelGGL(k_transpose_fr, dim3(ceil_div(rows, 32), ceil_div(B, 32)), dim3(256), 0, s, in, out, rows, B, stride);
-}
-// same, of the element-wise product: out[b * stride + i] = x[i * B + b] * y[i * B + b]   (quotient stage: f = A*B on the coset)
+// instance-major copy of the element-wise product of two [rows][B] matrices (tiled through LDS):
+// out[b * stride + i] = x[i * B + b] * y[i * B + b]   (quotient stage: f = A*B on the coset)
 __global__ __launch_bounds__(256) void k_transpose_mul_fr(const Fr *__restrict__ x, const Fr *__restrict__ y, Fr *__restrict__ out, size_t rows, size_t B, size_t stride) {
     __shared__ uint4 tile[2][32][33];
     const size_t i0 = (size_t)blockIdx.x * 32, b0 = (size_t)blockIdx.y * 32;

@@ -11,8 +11,9 @@
 // elements in VGPRs and performs K butterfly stages per HBM round trip.
 //
 // Like gnark we never run a bit-reversal pass: inverse transforms are DIF (natural in, bit-reversed
-// out), forward transforms are DIT (bit-reversed in, natural out); the quotient H comes out in
-// bit-reversed coefficient order and the G1.Z bases are stored bit-reversed to match.
+// out), forward transforms are DIT (bit-reversed in, natural out).  The prover only runs the pair
+// inverse + coset-forward on a and b (to_coset); the rest of computeH lives in the folded key (keyfold.hip).
+// compute_h (all 7 transforms) is kept as the kernel-level entry point zkp_compute_h for parity tests.
 #include "kernels.h"
 
 namespace zk {

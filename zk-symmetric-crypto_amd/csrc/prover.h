@@ -30,7 +30,7 @@ struct ProofPoints {
 
 struct PhaseTimes {   // milliseconds, device time measured with HIP events on the prover's stream
     float solve = 0, commit = 0, ntt = 0, msm_g1 = 0, msm_g2 = 0, finalize = 0, total = 0;
-    float z_segments = 0;   // the dominant kernel alone: k_msm_segments<Fp> of the quotient MSM
+    float z_segments = 0;   // the dominant kernel alone: k_msm_accumulate<Fp, true> of the quotient MSM
 };
 
 class Algorithm {
