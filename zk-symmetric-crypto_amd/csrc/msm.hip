@@ -429,15 +429,14 @@ __device__ __forceinline__ void accumulate_body(const Affine<F> *__restrict__ ta
             next_b = next_b2;
             next_b2 = bs[(cur + 2 <= nb) ? cur + 2 : nb];
         }
-        // prefetch the next entry's base point before the long dependent chain of the mixed addition
+        // only the next entry WORD is fetched ahead; at 3 wavefronts per SIMD the base point itself is loaded just in time
         const uint32_t e_next = e + 1;
         uint32_t v_next = 0;
-        Affine<F> p_next = p;
-        if (e_next < e_end) { v_next = ent[e_next]; p_next = table[v_next & 0x7fffffffu]; }
+        if (e_next < e_end) v_next = ent[e_next];
         if (v >> 31) p.y = p.y.neg();
         acc.madd(p);
         if (e_next >= e_end) break;
-        e = e_next; v = v_next; p = p_next;
+        e = e_next; v = v_next; p = table[v & 0x7fffffffu];
     }
     out[cur] = acc;
 }
