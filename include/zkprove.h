@@ -30,6 +30,8 @@ unsigned char InitAlgorithm(unsigned char algorithmID, GoSlice provingKey, GoSli
  * returns a malloc'd JSON document {"proof":b64,"ciphertext":b64}; on failure the JSON encoding of the
  * reference's panic value (a JSON string, or {} for error objects) -- libprove.go:34-44.
  * The caller releases r0 with Free (utils.ts:223). */
+/* Thread-safe.  Calls that arrive while the device is busy with another Prove of the same algorithm are proved together in the
+ * next device batch (each caller still gets its own response), so N caller threads approach ProveBatch throughput. */
 ProveReturn Prove(GoSlice params);
 /* libprove.go:26-29 */
 void Free(void *pointer);

@@ -233,6 +233,53 @@ def test_concurrent_init_and_prove(zk, oracle):
         assert base64.b64decode(got["proof"]) == exp and base64.b64decode(got["ciphertext"]) == out
 
 
+@pytest.mark.parametrize("alg", [0, 2])
+def test_concurrent_prove_calls_are_coalesced(zk, oracle, algs, alg):
+    """Prove() from many threads at once (a Go server's goroutines, Node's libuv pool): calls that arrive while the device is busy are
+    proved together in the next batch.  Every caller gets the proof of ITS request (checked against its public inputs), a bad request
+    among them gets its own panic, and the wall time shows the calls did not queue one by one"""
+    import threading
+    import time
+    algs(alg)
+    vkb = gf.vk_bytes(gf.vk_from_pk(H.oracle_pk(alg)))
+    assert zk.init_verifier(alg, vkb)
+    rng = H.SplitMix64(31337 + alg)
+    nthreads, per = 24, 4
+    insts = [[H.make_instance(alg, rng) for _ in range(per)] for _ in range(nthreads)]
+    reqs = [[H.request_json(alg, i) for i in row] for row in insts]
+    zk.prove_raw(reqs[0][0])                                           # warm-up (allocations)
+    t0 = time.perf_counter(); zk.prove_raw(reqs[0][0]); one = time.perf_counter() - t0
+    out = [[None] * per for _ in range(nthreads)]
+    bad = [None]
+
+    def worker(t):
+        for k in range(per):
+            out[t][k] = zk.prove_raw(reqs[t][k])
+        if t == 3:
+            bad[0] = zk.prove_raw(json.dumps({"cipher": H.CIPHER[alg], "key": "AAAA", "blocks": [], "input": ""}).encode())
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(nthreads)]
+    t0 = time.perf_counter()
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    wall = time.perf_counter() - t0
+    assert json.loads(bad[0]).startswith("key length must be")
+    for t in range(nthreads):
+        for k in range(per):
+            res = json.loads(out[t][k])
+            rq = json.loads(reqs[t][k])
+            _, exp_out = H.oracle_witness(alg, insts[t][k])
+            assert base64.b64decode(res["ciphertext"]) == exp_out
+            if (t * per + k) % 5 == 0:
+                sig = {"ciphertext": res["ciphertext"], "blocks": rq["blocks"], "input": rq["input"]}
+                assert zk.verify_raw(json.dumps({"cipher": H.CIPHER[alg], "proof": res["proof"], "publicSignals": sig}).encode())
+    # 96 calls one by one would take 96 * `one`; coalesced batches must do clearly better
+    assert wall < 0.5 * nthreads * per * one, "concurrent calls were not batched: %.3f s vs %.3f s serial" % (wall, nthreads * per * one)
+    print("coalescing: %d concurrent Prove() calls in %.3f s (%.1f proofs/s; one call alone %.1f ms)" % (nthreads * per, wall, nthreads * per / wall, one * 1e3))
+
+
 @pytest.mark.parametrize("alg,n", [(0, 3100), (1, 1030)])
 def test_prove_batch_larger_than_one_gpu_chunk(zk, oracle, algs, alg, n):
     """ProveBatch with more requests than the 1024-instance device chunk: the chunks run software-pipelined on the device (working

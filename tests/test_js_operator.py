@@ -24,8 +24,8 @@ def _addon():
     return os.path.join(JS, "zkprove_napi.node")
 
 
-def _run_node(args, timeout=600):
-    p = subprocess.run([NODE] + args, cwd=JS, capture_output=True, text=True, timeout=timeout)
+def _run_node(args, timeout=600, env=None):
+    p = subprocess.run([NODE] + args, cwd=JS, capture_output=True, text=True, timeout=timeout, env=dict(os.environ, **(env or {})))
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")]
     assert lines, "no result from node:\n%s\n%s" % (p.stdout[-2000:], p.stderr[-2000:])
     return json.loads(lines[-1][len("RESULT "):])
@@ -93,11 +93,13 @@ def test_operator_proves_and_verifies_through_node(zk, oracle, tmp_path):
         with open(os.path.join(d, name), "wb") as f:
             f.write(data)
     rng = H.SplitMix64(4711)
-    insts = [H.make_instance(alg, rng) for _ in range(5)]
+    insts = [H.make_instance(alg, rng) for _ in range(16)]
     _instances_file(d, alg, insts)
-    r = _run_node([os.path.join("test", "run_operator.js"), "prove", d])
+    r = _run_node([os.path.join("test", "run_operator.js"), "prove", d], env={"UV_THREADPOOL_SIZE": "16"})
     assert "error" not in r, r.get("error")
-    assert r["okSingle"] is True and r["okBatch"] == [True] * 5 and r["okTampered"] is False
+    assert r["okSingle"] is True and r["okBatch"] == [True] * 16 and r["okTampered"] is False
+    assert r["okConcurrent"] == [True] * 16          # Promise.all over groth16Prove: coalesced into device batches by the library
+    print("node: single %d ms, batch of 16 %d ms, Promise.all of 16 single calls %d ms (libuv pool %s)" % (r["msSingle"], r["msBatch"], r["msConcurrent"], r["poolSize"]))
     assert r["badErr"] == 'Failed to create gnark proof: "key length must be 32: 3"'       # operator.ts:26-30 over provers.go:120-133
     # the proofs Node got verify under the independent pairing of the oracle as well
     vkp = gf.vk_parse(vk)

@@ -6,6 +6,8 @@
 #include <mutex>
 #include <thread>
 #include <atomic>
+#include <condition_variable>
+#include <deque>
 #include "../../include/zkprove.h"
 #include "prover.h"
 
@@ -263,6 +265,61 @@ std::vector<std::string> prove_prepared(int alg_id, const std::vector<const Prep
     return res;
 }
 
+// Concurrent Prove() calls of one algorithm are coalesced into ONE device batch (leader / follower): the reference's Prove is
+// re-entrant and uses every core per call (SURVEY 8b "Threading"); here a call occupies the GPU for ~12 ms whatever the batch size
+// up to a few dozen, so callers that arrive while a batch is running are proved together in the next one.  A single-threaded
+// caller sees exactly the old behaviour (batches of one).
+struct Waiter {
+    const Prepared *prep;
+    std::string result;
+    bool done = false;
+};
+struct Coalescer {
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<Waiter *> queue;
+    bool leader_active = false;
+};
+Coalescer g_coalesce[3];
+static constexpr size_t COALESCE_MAX = 1024;
+
+std::string prove_coalesced(const Prepared &p) {
+    Coalescer &c = g_coalesce[p.rq.alg];
+    Waiter me{&p};
+    std::unique_lock<std::mutex> lk(c.m);
+    c.queue.push_back(&me);
+    if (c.leader_active) {
+        c.cv.wait(lk, [&] { return me.done || !c.leader_active; });
+        if (me.done) return me.result;
+        // the leader left before it saw this request: take over
+    }
+    c.leader_active = true;
+    while (!c.queue.empty()) {
+        std::vector<Waiter *> batch;
+        while (!c.queue.empty() && batch.size() < COALESCE_MAX) { batch.push_back(c.queue.front()); c.queue.pop_front(); }
+        lk.unlock();
+        std::vector<const Prepared *> items;
+        for (Waiter *w : batch) items.push_back(w->prep);
+        std::vector<std::string> out;
+        std::string fail;
+        try {
+            out = prove_prepared(p.rq.alg, items, nullptr, nullptr, nullptr);
+        } catch (const Panic &e) {
+            fail = e.json;
+        } catch (const std::exception &e) {
+            fprintf(stderr, "zkprove: %s\n", e.what());
+            fail = "{}";
+        }
+        lk.lock();
+        for (size_t i = 0; i < batch.size(); i++) { batch[i]->result = fail.empty() ? std::move(out[i]) : fail; batch[i]->done = true; }
+        c.cv.notify_all();
+        if (me.done) break;           // hand leadership to whoever is still waiting (they wake up and see !leader_active)
+    }
+    c.leader_active = false;
+    c.cv.notify_all();
+    return me.result;
+}
+
 ProveReturn prove_one(GoSlice params, const U256 *r, const U256 *s, const U256 *rnd) {
     std::string result;
     try {
@@ -273,7 +330,7 @@ ProveReturn prove_one(GoSlice params, const U256 *r, const U256 *s, const U256 *
         Prepared p;
         prepare(j, p);
         if (!p.ok) throw Panic{p.panic};
-        result = prove_prepared(p.rq.alg, {&p}, r, s, rnd)[0];
+        result = (r || s || rnd) ? prove_prepared(p.rq.alg, {&p}, r, s, rnd)[0] : prove_coalesced(p);
     } catch (const Panic &p) {
         result = p.json;
     } catch (const std::exception &e) {
