@@ -8,6 +8,7 @@ namespace zk {
 
 static constexpr int C_WIRE = 13;   // window bits for the wire-scalar MSMs (few wide scalars)
 static constexpr int C_H = 16;      // window bits for the quotient MSM (all scalars full width)
+static constexpr size_t SIDE_G2_MAX_B = 64;   // up to this batch size the G2 MSM runs beside the G1 MSMs (kernels are latency-bound)
 
 // ------------------------------------------------------------------------------- pk parsing
 namespace {
@@ -112,7 +113,8 @@ struct SolveSet {
 struct Algorithm::Resident {
     size_t B = 0, cap = 0;
     SolveSet set[2];
-    MsmScratch ms, ms2;             // ms2: the commitment MSMs of the solve stage when it runs on the second stream
+    MsmScratch ms, ms2, ms_g2;      // ms2: the commitment MSMs of the solve stage when it runs on the second stream; ms_g2: the G2 MSM of
+                                    // SMALL batches, which runs on its own stream beside the latency-bound G1 MSMs
     DevBuf<G1XYZZ> m_ar, m_bs1, m_k, m_z;
     DevBuf<G2XYZZ> m_bs2;
     DevBuf<G1Affine> ar_aff, bs1_aff;
@@ -332,6 +334,8 @@ void Algorithm::resident_reserve(size_t B) {
         ZK_HIP(hipStreamCreateWithPriority(&res->stream, hipStreamNonBlocking, prio_lo));
         ZK_HIP(hipStreamCreateWithPriority(&res->stream2, hipStreamNonBlocking, prio_hi));
         ZK_HIP(hipStreamCreateWithPriority(&res->stream3, hipStreamNonBlocking, prio_hi));
+        // exactly four streams: a fifth one no longer gets a hardware queue of its own (HIP multiplexes streams over 4 queues) and
+        // doubled the latency of the 160-460 dependent solver launches.  The copy stream doubles as the side stream of small batches.
         ZK_HIP(hipStreamCreateWithPriority(&res->copy_stream, hipStreamNonBlocking, prio_hi));
         for (auto &e : res->ev) ZK_HIP(hipEventCreate(&e));
     }
@@ -353,6 +357,12 @@ void Algorithm::resident_reserve(size_t B) {
     R.ms.reserve(B, max_entries, max_nb, max_part);
     R.ms.reserve_dense(B, pk.Z.n * (size_t)pk.Z.W);
     R.ms.reserve_compact(B, std::max({pk.A.n, pk.B1.n, pk.K.n, pk.B2.n, has_commit ? pk.ped.n : (size_t)1}));
+    {
+        const size_t Bs = std::min(B, SIDE_G2_MAX_B);
+        R.ms_g2.reserve(Bs, pk.B2.n * (size_t)pk.B2.W, (size_t)1 << (pk.B2.c - 1), msm_part_stride(pk.B2.n, pk.B2.c));
+        R.ms_g2.reserve_compact(Bs, pk.B2.n);
+        R.ms_g2.reserve_sums(Bs, 1, (size_t)1 << (pk.B2.c - 1));
+    }
     {
         size_t nb1 = (size_t)1 << (std::max({pk.A.c, pk.B1.c, pk.K.c, pk.Z.c, has_commit ? pk.ped.c : 1}) - 1);
         R.ms.reserve_sums(B, nb1, (size_t)1 << (pk.B2.c - 1));
@@ -433,9 +443,13 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm,
     ZK_HIP(hipStreamWaitEvent(tail, R.ev[12], 0));
     enqueue_tail_early(S, tail);
     ZK_HIP(hipEventRecord(R.ev[5], st));
-    // the G2 sum next, so that its blinding and affine conversion also run under the two largest MSMs
-    msm_batch(pk.B2, S.sb.wires.p, B, R.ms, R.m_bs2.p, st);
-    ZK_HIP(hipEventRecord(R.ev[6], st));
+    // the G2 sum next, so that its blinding and affine conversion also run under the two largest MSMs.  A small batch is a chain of
+    // latency-bound kernels: there the G2 chain gets its own stream and scratch and runs beside the K / Z chains
+    const bool side = B <= SIDE_G2_MAX_B;
+    hipStream_t g2 = side ? R.copy_stream : st;      // the copy stream is idle in single-chunk calls
+    if (side) ZK_HIP(hipStreamWaitEvent(g2, R.ev[5], 0));
+    msm_batch(pk.B2, S.sb.wires.p, B, side ? R.ms_g2 : R.ms, R.m_bs2.p, g2);
+    ZK_HIP(hipEventRecord(R.ev[6], g2));
     ZK_HIP(hipStreamWaitEvent(tail, R.ev[6], 0));
     hipLaunchKernelGGL(k_finalize_g2, dim3(ceil_div(B, 64)), dim3(64), 0, tail, R.m_bs2.p, pk.g2_misc.p, pk.delta2_tab.p, S.s.p, S.out.p, B);
     msm_batch(pk.K, S.sb.wires.p, B, R.ms, R.m_k.p, st);
@@ -444,6 +458,7 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm,
     fr_transpose_mul(S.sb.a.p, S.sb.b.p, S.sb.c.p, N, B, N, st);
     msm_batch(pk.Z, S.sb.c.p, B, R.ms, R.m_z.p, st, &R.ev[8]);
     ZK_HIP(hipGetLastError());
+    if (side) ZK_HIP(hipStreamWaitEvent(st, R.ev[6], 0));       // the batch's sums are complete only when the G2 stream is done too
     ZK_HIP(hipEventRecord(R.ev[13], st));
 }
 
