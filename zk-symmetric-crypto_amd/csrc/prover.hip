@@ -121,7 +121,7 @@ struct Algorithm::Resident {
     DevBuf<G1XYZZ> f_t, f_u, f_v;
     int last_set = 0;               // the set that holds the most recent batch
     hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr, copy_stream = nullptr;
-    hipEvent_t ev[14] = {};     // [10] MSM sums of the current batch complete  [11] tail of the previous batch done  [12] A and B1 sums complete  [13] end of the G1 MSMs
+    hipEvent_t ev[15] = {};     // [10] MSM sums of the current batch complete  [11] tail of the previous batch done  [12] A and B1 sums complete  [13] end of the G1 MSMs
 };
 
 Algorithm::Algorithm() {}
@@ -359,9 +359,12 @@ void Algorithm::resident_reserve(size_t B) {
     R.ms.reserve_compact(B, std::max({pk.A.n, pk.B1.n, pk.K.n, pk.B2.n, has_commit ? pk.ped.n : (size_t)1}));
     {
         const size_t Bs = std::min(B, SIDE_G2_MAX_B);
-        R.ms_g2.reserve(Bs, pk.B2.n * (size_t)pk.B2.W, (size_t)1 << (pk.B2.c - 1), msm_part_stride(pk.B2.n, pk.B2.c));
-        R.ms_g2.reserve_compact(Bs, pk.B2.n);
-        R.ms_g2.reserve_sums(Bs, 1, (size_t)1 << (pk.B2.c - 1));
+        const size_t n_side = std::max(pk.B2.n, has_commit ? pk.ped_sigma.n : (size_t)1);
+        const int c_side = std::max(pk.B2.c, has_commit ? pk.ped_sigma.c : 1);
+        R.ms_g2.reserve(Bs, n_side * (size_t)std::max(pk.B2.W, has_commit ? pk.ped_sigma.W : 1), (size_t)1 << (c_side - 1),
+                        std::max(msm_part_stride(pk.B2.n, pk.B2.c), has_commit ? msm_part_stride(pk.ped_sigma.n, pk.ped_sigma.c) : (size_t)1));
+        R.ms_g2.reserve_compact(Bs, n_side);
+        R.ms_g2.reserve_sums(Bs, has_commit ? (size_t)1 << (pk.ped_sigma.c - 1) : 1, (size_t)1 << (pk.B2.c - 1));
     }
     {
         size_t nb1 = (size_t)1 << (std::max({pk.A.c, pk.B1.c, pk.K.c, pk.Z.c, has_commit ? pk.ped.c : 1}) - 1);
@@ -400,10 +403,23 @@ void Algorithm::enqueue_solve(SolveSet &S, MsmScratch &commit_scratch, hipStream
         solver_run_levels(prog, S.sb, 0, commit_level, st);
         ZK_HIP(hipEventRecord(S.t1, st));
         // BSB22 commitment: C = sum v_i * Basis_i ; challenge = H2F(C.Marshal(), "bsb22-commitment") ; PoK = sum v_i * BasisExpSigma_i
-        msm_batch(pk.ped, S.sb.wires.p, B, commit_scratch, S.m_com.p, st);
-        msm_batch(pk.ped_sigma, S.sb.wires.p, B, commit_scratch, S.m_pok.p, st);
-        g1_to_affine_canonical(S.m_com.p, S.com_aff.p, B, st);
-        g1_to_affine_canonical(S.m_pok.p, S.pok_aff.p, B, st);
+        if (B <= SIDE_G2_MAX_B) {
+            // small batch: the two Pedersen MSMs are latency-bound chains -- the proof-of-knowledge one runs on the side stream
+            // (scratch of the side G2 MSM, idle until the MSM stage) beside the commitment
+            ZK_HIP(hipEventRecord(R.ev[14], st));
+            ZK_HIP(hipStreamWaitEvent(R.copy_stream, R.ev[14], 0));
+            msm_batch(pk.ped_sigma, S.sb.wires.p, B, R.ms_g2, S.m_pok.p, R.copy_stream);
+            g1_to_affine_canonical(S.m_pok.p, S.pok_aff.p, B, R.copy_stream);
+            ZK_HIP(hipEventRecord(R.ev[14], R.copy_stream));
+            msm_batch(pk.ped, S.sb.wires.p, B, commit_scratch, S.m_com.p, st);
+            g1_to_affine_canonical(S.m_com.p, S.com_aff.p, B, st);
+            ZK_HIP(hipStreamWaitEvent(st, R.ev[14], 0));
+        } else {
+            msm_batch(pk.ped, S.sb.wires.p, B, commit_scratch, S.m_com.p, st);
+            msm_batch(pk.ped_sigma, S.sb.wires.p, B, commit_scratch, S.m_pok.p, st);
+            g1_to_affine_canonical(S.m_com.p, S.com_aff.p, B, st);
+            g1_to_affine_canonical(S.m_pok.p, S.pok_aff.p, B, st);
+        }
         ZK_HIP(hipMemcpyAsync(S.h_com.data(), S.com_aff.p, B * sizeof(G1Affine), hipMemcpyDeviceToHost, st));
         ZK_HIP(hipStreamSynchronize(st));
         for (size_t b = 0; b < B; b++) {
