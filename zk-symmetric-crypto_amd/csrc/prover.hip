@@ -113,15 +113,15 @@ struct SolveSet {
 struct Algorithm::Resident {
     size_t B = 0, cap = 0;
     SolveSet set[2];
-    MsmScratch ms, ms2, ms_g2;      // ms2: the commitment MSMs of the solve stage when it runs on the second stream; ms_g2: the G2 MSM of
-                                    // SMALL batches, which runs on its own stream beside the latency-bound G1 MSMs
+    MsmScratch ms, ms2, ms_g2, ms_k, ms_a;      // ms2: the commitment MSMs of the solve stage when it runs on the second stream; ms_g2: the G2 MSM of
+                                    // SMALL batches, which runs on its own stream beside the latency-bound G1 MSMs; ms_k, ms_a: likewise the K and the A / B1 MSMs
     DevBuf<G1XYZZ> m_ar, m_bs1, m_k, m_z;
     DevBuf<G2XYZZ> m_bs2;
     DevBuf<G1Affine> ar_aff, bs1_aff;
     DevBuf<G1XYZZ> f_t, f_u, f_v;
     int last_set = 0;               // the set that holds the most recent batch
     hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr, copy_stream = nullptr;
-    hipEvent_t ev[15] = {};     // [10] MSM sums of the current batch complete  [11] tail of the previous batch done  [12] A and B1 sums complete  [13] end of the G1 MSMs
+    hipEvent_t ev[17] = {};     // [10] MSM sums of the current batch complete  [11] tail of the previous batch done  [12] A and B1 sums complete  [13] end of the G1 MSMs
 };
 
 Algorithm::Algorithm() {}
@@ -363,6 +363,15 @@ void Algorithm::resident_reserve(size_t B) {
         const int c_side = std::max(pk.B2.c, has_commit ? pk.ped_sigma.c : 1);
         R.ms_g2.reserve(Bs, n_side * (size_t)std::max(pk.B2.W, has_commit ? pk.ped_sigma.W : 1), (size_t)1 << (c_side - 1),
                         std::max(msm_part_stride(pk.B2.n, pk.B2.c), has_commit ? msm_part_stride(pk.ped_sigma.n, pk.ped_sigma.c) : (size_t)1));
+        {
+            const size_t na = std::max(pk.A.n, pk.B1.n);
+            R.ms_a.reserve(Bs, na * (size_t)pk.A.W, (size_t)1 << (pk.A.c - 1), std::max(msm_part_stride(pk.A.n, pk.A.c), msm_part_stride(pk.B1.n, pk.B1.c)));
+            R.ms_a.reserve_compact(Bs, na);
+            R.ms_a.reserve_sums(Bs, (size_t)1 << (pk.A.c - 1), 1);
+        }
+        R.ms_k.reserve(Bs, pk.K.n * (size_t)pk.K.W, (size_t)1 << (pk.K.c - 1), msm_part_stride(pk.K.n, pk.K.c));
+        R.ms_k.reserve_compact(Bs, pk.K.n);
+        R.ms_k.reserve_sums(Bs, (size_t)1 << (pk.K.c - 1), 1);
         R.ms_g2.reserve_compact(Bs, n_side);
         R.ms_g2.reserve_sums(Bs, has_commit ? (size_t)1 << (pk.ped_sigma.c - 1) : 1, (size_t)1 << (pk.B2.c - 1));
     }
@@ -448,33 +457,63 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm,
     const size_t B = R.B;
     ZK_HIP(hipEventRecord(R.ev[3], st));
     const size_t N = (size_t)1 << prog.log_domain;
-    dom.to_coset(S.sb.a.p, S.sb.b.p, B, st);
+    // A small batch is a set of latency-bound kernel chains: independent chains go to the otherwise idle streams (the transforms of b
+    // and the K MSM to the solve stream, the G2 MSM to the copy stream) -- never to new ones, see resident_reserve
+    const bool side = B <= SIDE_G2_MAX_B;
+    hipStream_t sk = R.stream2;
+    if (side) {
+        ZK_HIP(hipStreamWaitEvent(sk, R.ev[3], 0));
+        dom.dif(S.sb.b.p, B, true, nullptr, sk);
+        dom.dit(S.sb.b.p, B, false, dom.coset_pre.p, sk);
+        ZK_HIP(hipEventRecord(R.ev[15], sk));
+        if (before_msm) ZK_HIP(hipStreamWaitEvent(sk, before_msm, 0));
+        msm_batch(pk.K, S.sb.wires.p, B, R.ms_k, R.m_k.p, sk);
+        ZK_HIP(hipEventRecord(R.ev[16], sk));
+        // Ar and Bs1 need the wires only: their MSMs and the 4 ms of dependent doublings of s*Ar, r*Bs1 start on the tail stream
+        // at once, beside the transforms
+        ZK_HIP(hipStreamWaitEvent(tail, R.ev[3], 0));
+        msm_batch(pk.A, S.sb.wires.p, B, R.ms_a, R.m_ar.p, tail);
+        msm_batch(pk.B1, S.sb.wires.p, B, R.ms_a, R.m_bs1.p, tail);
+        enqueue_tail_early(S, tail);
+        dom.dif(S.sb.a.p, B, true, nullptr, st);
+        dom.dit(S.sb.a.p, B, false, dom.coset_pre.p, st);
+    } else {
+        dom.to_coset(S.sb.a.p, S.sb.b.p, B, st);
+    }
     ZK_HIP(hipEventRecord(R.ev[4], st));
     if (before_msm) ZK_HIP(hipStreamWaitEvent(st, before_msm, 0));
-    msm_batch(pk.A, S.sb.wires.p, B, R.ms, R.m_ar.p, st);
-    msm_batch(pk.B1, S.sb.wires.p, B, R.ms, R.m_bs1.p, st);
-    // Ar and Bs1 only need these two sums: their blinding and the two variable-base multiplications s*Ar, r*Bs1 (4 ms of
-    // dependent doublings whatever the batch size) start now on the tail stream, under the remaining MSMs
-    ZK_HIP(hipEventRecord(R.ev[12], st));
-    ZK_HIP(hipStreamWaitEvent(tail, R.ev[12], 0));
-    enqueue_tail_early(S, tail);
+    if (!side) {
+        msm_batch(pk.A, S.sb.wires.p, B, R.ms, R.m_ar.p, st);
+        msm_batch(pk.B1, S.sb.wires.p, B, R.ms, R.m_bs1.p, st);
+        // Ar and Bs1 only need these two sums: their blinding and the two variable-base multiplications s*Ar, r*Bs1 (4 ms of
+        // dependent doublings whatever the batch size) start now on the tail stream, under the remaining MSMs
+        ZK_HIP(hipEventRecord(R.ev[12], st));
+        ZK_HIP(hipStreamWaitEvent(tail, R.ev[12], 0));
+        enqueue_tail_early(S, tail);
+    }
     ZK_HIP(hipEventRecord(R.ev[5], st));
     // the G2 sum next, so that its blinding and affine conversion also run under the two largest MSMs.  A small batch is a chain of
     // latency-bound kernels: there the G2 chain gets its own stream and scratch and runs beside the K / Z chains
-    const bool side = B <= SIDE_G2_MAX_B;
     hipStream_t g2 = side ? R.copy_stream : st;      // the copy stream is idle in single-chunk calls
-    if (side) ZK_HIP(hipStreamWaitEvent(g2, R.ev[5], 0));
+    if (side) {          // wires only: may start with the transforms
+        ZK_HIP(hipStreamWaitEvent(g2, R.ev[3], 0));
+        if (before_msm) ZK_HIP(hipStreamWaitEvent(g2, before_msm, 0));
+    }
     msm_batch(pk.B2, S.sb.wires.p, B, side ? R.ms_g2 : R.ms, R.m_bs2.p, g2);
     ZK_HIP(hipEventRecord(R.ev[6], g2));
     ZK_HIP(hipStreamWaitEvent(tail, R.ev[6], 0));
     hipLaunchKernelGGL(k_finalize_g2, dim3(ceil_div(B, 64)), dim3(64), 0, tail, R.m_bs2.p, pk.g2_misc.p, pk.delta2_tab.p, S.s.p, S.out.p, B);
-    msm_batch(pk.K, S.sb.wires.p, B, R.ms, R.m_k.p, st);
+    if (!side) msm_batch(pk.K, S.sb.wires.p, B, R.ms, R.m_k.p, st);
     // sum_k h_k Z_k = sum_i (a_i b_i) Ze_i + (a part linear in the wires that sits in K); c only serves as the buffer of the
     // instance-major products
+    if (side) ZK_HIP(hipStreamWaitEvent(st, R.ev[15], 0));      // b on the coset comes from the side stream
     fr_transpose_mul(S.sb.a.p, S.sb.b.p, S.sb.c.p, N, B, N, st);
     msm_batch(pk.Z, S.sb.c.p, B, R.ms, R.m_z.p, st, &R.ev[8]);
     ZK_HIP(hipGetLastError());
-    if (side) ZK_HIP(hipStreamWaitEvent(st, R.ev[6], 0));       // the batch's sums are complete only when the G2 stream is done too
+    if (side) {                                                  // the batch's sums are complete only when the side streams are done too
+        ZK_HIP(hipStreamWaitEvent(st, R.ev[6], 0));
+        ZK_HIP(hipStreamWaitEvent(st, R.ev[16], 0));
+    }
     ZK_HIP(hipEventRecord(R.ev[13], st));
 }
 
