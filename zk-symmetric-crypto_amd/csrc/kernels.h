@@ -61,6 +61,7 @@ struct MsmScratch {
     DevBuf<Fr> gen_val;
     void reserve_compact(size_t B, size_t max_sparse_n);
     DevBuf<uint32_t> entries2, coarse_base;   // dense two-level sort: partitioned entries, per-instance coarse bin offsets
+    DevBuf<G1XYZZ> vout1;                     // results of the virtual instances of a split small-batch dense MSM
     void reserve_dense(size_t B, size_t max_dense_entries);
 };
 

@@ -108,9 +108,14 @@ static void bases_build(MsmBases<F> &mb, const Affine<F> *d_points, size_t n, co
 void msm_bases_build(MsmBasesG1 &mb, const G1Affine *p, size_t n, const uint32_t *rows, int c, hipStream_t s) { bases_build<Fp>(mb, p, n, rows, c, s); }
 void msm_bases_build(MsmBasesG2 &mb, const G2Affine *p, size_t n, const uint32_t *rows, int c, hipStream_t s) { bases_build<Fp2>(mb, p, n, rows, c, s); }
 
+// A small batch splits every instance of the dense MSM into up to DENSE_SPLIT_MAX "virtual instances" (a slice of the scalars
+// each, own buckets) so that its sort / accumulate / reduce chain has workgroups to spread over; the per-instance arrays are
+// therefore sized for at least VIRT_MIN instances.
+static constexpr size_t VIRT_MIN = 64, DENSE_SPLIT_MAX = 16;
 void MsmScratch::reserve_dense(size_t B_, size_t max_dense_entries) {
     entries2.ensure(B_ * max_dense_entries + 1);
-    coarse_base.ensure(B_ * 257);
+    coarse_base.ensure((B_ > VIRT_MIN ? B_ : VIRT_MIN) * 257);
+    vout1.ensure(VIRT_MIN + 1);
 }
 void MsmScratch::reserve_compact(size_t B_, size_t max_sparse_n) {
     gen_count.ensure(B_ + 1);
@@ -118,14 +123,15 @@ void MsmScratch::reserve_compact(size_t B_, size_t max_sparse_n) {
     gen_val.ensure(B_ * max_sparse_n + 1);
 }
 void MsmScratch::reserve_sums(size_t B_, size_t nb_g1, size_t nb_g2) {
-    sums1.ensure(B_ * nb_g1 + 1);
+    sums1.ensure((B_ > VIRT_MIN ? B_ : VIRT_MIN) * nb_g1 + 1);
     sums2.ensure(B_ * nb_g2 + 1);
 }
 void MsmScratch::reserve(size_t B_, size_t max_entries, size_t max_nb, size_t max_part) {
     B = B_;
     entries.ensure(B * max_entries + 1);
-    bucket_start.ensure(B * (max_nb + 1));
-    part1.ensure(B * max_part + 1);
+    const size_t Bm = B > VIRT_MIN ? B : VIRT_MIN;
+    bucket_start.ensure(Bm * (max_nb + 1));
+    part1.ensure(Bm * max_part + 1);
     part2.ensure(B * max_part + 1);
 }
 
@@ -239,7 +245,9 @@ static constexpr int MAX_COARSE = 256;
 
 __global__ __launch_bounds__(PART_THREADS) void k_msm_partition(const Fr *__restrict__ dense, size_t dense_stride, size_t n, int c, int W,
                                                                 uint32_t *__restrict__ coarse_base, uint32_t *__restrict__ part_entries,
-                                                                size_t max_entries) {
+                                                                size_t max_entries, uint32_t split) {
+    // workgroup = virtual instance blockIdx.x = instance * split + slice; it sorts scalars [slice * n, slice * n + n) of the instance
+    // (n = scalars per slice) and emits GLOBAL table indices
     extern __shared__ uint32_t lds[];
     const int cb = c - 1 - FINE_BITS;                 // coarse bits
     const uint32_t nbin = 1u << cb;
@@ -253,7 +261,8 @@ __global__ __launch_bounds__(PART_THREADS) void k_msm_partition(const Fr *__rest
     uint32_t *tile_dst = tile_ent + PART_THREADS * W;     // tiles sized by the actual window count: 73 KiB at W = 16 -> two workgroups per CU
     const size_t b = blockIdx.x;
     const int tid = threadIdx.x, wave = tid >> 6;
-    const Fr *sc = dense + b * dense_stride;
+    const size_t jbase = (size_t)(blockIdx.x % split) * n;
+    const Fr *sc = dense + (b / split) * dense_stride + jbase;
     // ---- pass 0: coarse histogram (privatised per wavefront)
     for (uint32_t i = tid; i < (uint32_t)nwave * nbin; i += PART_THREADS) wave_hist[(i / nbin) * MAX_COARSE + (i % nbin)] = 0;
     if (tid < (int)nbin) { bin_cursor[tid] = 0; tile_cnt[tid] = 0; }
@@ -300,7 +309,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_msm_partition(const Fr *__rest
                         const uint32_t neg = d < 0, bk = (uint32_t)(neg ? -d : d) - 1;
                         const uint32_t bin = bk >> FINE_BITS;
                         const uint32_t r = atomicAdd(&tile_cnt[bin], 1u);
-                        ent[w] = (uint32_t)(j * W + w) | ((bk & ((1u << FINE_BITS) - 1)) << 21) | (neg << 31);
+                        ent[w] = (uint32_t)((jbase + j) * W + w) | ((bk & ((1u << FINE_BITS) - 1)) << 21) | (neg << 31);
                         binrank[w] = (bin << 16) | r;
                     }
                 }
@@ -626,6 +635,55 @@ struct SumsSel<Fp> { static G1XYZZ *get(MsmScratch &s) { return s.sums1.p; } sta
 template <>
 struct SumsSel<Fp2> { static G2XYZZ *get(MsmScratch &s) { return s.sums2.p; } static size_t cap(MsmScratch &s) { return s.sums2.n; } };
 
+// Dense two-level path of a small batch, every instance split into `split` virtual instances (G1 only).
+template <class F>
+static void msm_dense_split(const MsmBases<F> &mb, const Fr *scalars, size_t B, MsmScratch &sc, XYZZ<F> *out, hipStream_t s, hipEvent_t *seg_events,
+                            uint32_t split) {
+    if constexpr (sizeof(F) == 32) {
+        const int c = mb.c, W = mb.W;
+        const uint32_t nb = 1u << (c - 1);
+        const size_t Bv = B * split, nv = mb.n / split, max_entries = nv * W;
+        const uint32_t L = seg_len(nb, Bv);
+        const size_t nseg = nb / L, npart = nseg;
+        const size_t stride = msm_part_stride(mb.n, c);
+        XYZZ<F> *part = PartSel<F>::get(sc), *sums = SumsSel<F>::get(sc);
+        if (sc.entries.n < Bv * max_entries + 1 || sc.entries2.n < Bv * max_entries + 1 || sc.bucket_start.n < Bv * (nb + 1) ||
+            PartSel<F>::cap(sc) < Bv * stride + 1 || SumsSel<F>::cap(sc) < Bv * (size_t)nb || sc.coarse_base.n < Bv * (MAX_COARSE + 1) || sc.vout1.n < Bv)
+            throw ZkError("msm scratch too small for the split dense path");
+        static bool attr2 = false;
+        const size_t lds2 = (size_t)(PART_THREADS / 64 * MAX_COARSE + (MAX_COARSE + 1) + 3 * MAX_COARSE + 2 * PART_THREADS * (size_t)W) * sizeof(uint32_t);
+        if (!attr2) { ZK_HIP(hipFuncSetAttribute((const void *)k_msm_partition, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)); attr2 = true; }
+        hipLaunchKernelGGL(k_msm_partition, dim3((unsigned)Bv), dim3(PART_THREADS), lds2, s, scalars, mb.dense_stride, nv, c, W, sc.coarse_base.p,
+                           sc.entries2.p, max_entries, split);
+        hipLaunchKernelGGL(k_msm_binsort, dim3(1u << (c - 1 - FINE_BITS), (unsigned)Bv), dim3(256), 0, s, sc.coarse_base.p, sc.entries2.p, sc.entries.p,
+                           max_entries, c, sc.bucket_start.p);
+        size_t piece = 2048;
+        while (piece > 64 && (max_entries * Bv) / piece < 262144) piece >>= 1;
+        uint32_t nlanes = (uint32_t)((max_entries + piece - 1) / piece);
+        if (nlanes < 1) nlanes = 1;
+        if (seg_events) ZK_HIP(hipEventRecord(seg_events[0], s));
+        hipLaunchKernelGGL((k_msm_accumulate<F, true>), dim3(ceil_div((size_t)nlanes * Bv, 64)), dim3(64), 0, s, mb.table.p, sc.bucket_start.p, sc.entries.p,
+                           max_entries, c, Bv, nlanes, sums);
+        if (seg_events) ZK_HIP(hipEventRecord(seg_events[1], s));
+        hipLaunchKernelGGL(k_msm_bucket_reduce<F>, dim3(ceil_div(nseg * Bv, 64)), dim3(64), 0, s, sums, sc.bucket_start.p, c, Bv, part, stride, (size_t)0, L);
+        size_t off = 0, cnt = npart;
+        do {
+            const size_t groups = (cnt + FOLD_GROUP - 1) / FOLD_GROUP;
+            const bool last = groups == 1;
+            hipLaunchKernelGGL(k_sum_groups<F>, dim3(ceil_div(groups * Bv, 64)), dim3(64), 0, s, part + off, stride, cnt, FOLD_GROUP,
+                               last ? (XYZZ<F> *)sc.vout1.p : part + off + cnt, last ? (size_t)1 : stride, Bv);
+            off += cnt;
+            cnt = groups;
+        } while (cnt > 1);
+        hipLaunchKernelGGL(k_sum_groups<F>, dim3(ceil_div(B, 64)), dim3(64), 0, s, (const XYZZ<F> *)sc.vout1.p, (size_t)split, (size_t)split, (size_t)split, out,
+                           (size_t)1, B);
+        ZK_HIP(hipGetLastError());
+    } else {
+        (void)mb; (void)scalars; (void)B; (void)sc; (void)out; (void)s; (void)seg_events; (void)split;
+        throw ZkError("split dense path is G1 only");
+    }
+}
+
 template <class F>
 static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, MsmScratch &sc, XYZZ<F> *out, hipStream_t s, hipEvent_t *seg_events) {
     const size_t n = mb.n;
@@ -653,17 +711,27 @@ static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, M
     }
     if (mb.dense) {
         // scalars = instance-major [B][dense_stride] copy; no +-1 fast path (every quotient coefficient is wide)
-        ZK_HIP(hipMemsetAsync(part, 0, B * stride * sizeof(XYZZ<F>), s));
         if (c - 1 > FINE_BITS && c - 1 - FINE_BITS <= 8 && W <= 24 && n * (size_t)W <= (1u << 21) && sc.entries2.n >= B * max_entries + 1) {
+            // small batch: split every instance into `split` virtual instances (see reserve_dense); everything downstream just sees
+            // B * split instances of n / split scalars, and the split results are added at the end
+            uint32_t split = 1;
+            if (sizeof(F) == 32 && sc.vout1.n > VIRT_MIN)
+                while (split < DENSE_SPLIT_MAX && B * split * 2 <= VIRT_MIN && (n % (split * 2)) == 0 && n / (split * 2) >= 4096) split *= 2;
+            if (split > 1) {
+                msm_dense_split(mb, scalars, B, sc, out, s, seg_events, split);
+                return;
+            }
+            ZK_HIP(hipMemsetAsync(part, 0, B * stride * sizeof(XYZZ<F>), s));
             static bool attr2 = false;
             const size_t lds2 = (size_t)(PART_THREADS / 64 * MAX_COARSE + (MAX_COARSE + 1) + 3 * MAX_COARSE + 2 * PART_THREADS * (size_t)W) * sizeof(uint32_t);
             if (!attr2) { ZK_HIP(hipFuncSetAttribute((const void *)k_msm_partition, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)); attr2 = true; }
             sc.coarse_base.ensure(B * (MAX_COARSE + 1));
             hipLaunchKernelGGL(k_msm_partition, dim3((unsigned)B), dim3(PART_THREADS), lds2, s, scalars, mb.dense_stride, n, c, W, sc.coarse_base.p,
-                               sc.entries2.p, max_entries);
+                               sc.entries2.p, max_entries, 1u);
             hipLaunchKernelGGL(k_msm_binsort, dim3(1u << (c - 1 - FINE_BITS), (unsigned)B), dim3(256), 0, s, sc.coarse_base.p, sc.entries2.p, sc.entries.p,
                                max_entries, c, sc.bucket_start.p);
         } else {
+            ZK_HIP(hipMemsetAsync(part, 0, B * stride * sizeof(XYZZ<F>), s));
             hipLaunchKernelGGL(k_msm_sort<true>, dim3((unsigned)B), dim3(SORT_THREADS), lds, s, scalars, mb.dense_stride, (const uint32_t *)nullptr,
                                (const uint32_t *)nullptr, (const Fr *)nullptr, n, c, W, sc.bucket_start.p, sc.entries.p, max_entries);
         }

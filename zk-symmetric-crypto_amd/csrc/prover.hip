@@ -473,7 +473,10 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm,
         // at once, beside the transforms
         ZK_HIP(hipStreamWaitEvent(tail, R.ev[3], 0));
         msm_batch(pk.A, S.sb.wires.p, B, R.ms_a, R.m_ar.p, tail);
-        msm_batch(pk.B1, S.sb.wires.p, B, R.ms_a, R.m_bs1.p, tail);
+        if (before_msm) ZK_HIP(hipStreamWaitEvent(st, before_msm, 0));
+        msm_batch(pk.B1, S.sb.wires.p, B, R.ms, R.m_bs1.p, st);            // beside the A MSM; the main stream's own chain is the shortest
+        ZK_HIP(hipEventRecord(R.ev[12], st));
+        ZK_HIP(hipStreamWaitEvent(tail, R.ev[12], 0));
         enqueue_tail_early(S, tail);
         dom.dif(S.sb.a.p, B, true, nullptr, st);
         dom.dit(S.sb.a.p, B, false, dom.coset_pre.p, st);
