@@ -1,6 +1,6 @@
 set -x
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r01g; rm -rf $O; mkdir -p $O
+O=gpurun_out/r01h; rm -rf $O; mkdir -p $O
 python bench.py --alg 0 > $O/bench_chacha.json 2> $O/bench_chacha.err
 python bench.py --alg 2 --cpu-proofs 48 > $O/bench_aes256.json 2> $O/bench_aes256.err
 python bench.py --alg 1 --cpu-proofs 0 > $O/bench_aes128.json 2> $O/bench_aes128.err
