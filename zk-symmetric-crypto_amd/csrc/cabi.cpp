@@ -5,6 +5,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <exception>
 #include <atomic>
 #include <condition_variable>
 #include <deque>
@@ -205,18 +206,27 @@ void parallel_for(size_t n, Fn fn) {
     if (nt > 16) nt = 16;
     if (n < 64 || nt <= 1) { for (size_t i = 0; i < n; i++) fn(i); return; }
     std::atomic<size_t> next{0};
+    std::exception_ptr first_error;
+    std::mutex err_lock;
     auto worker = [&] {
-        for (;;) {
-            const size_t i0 = next.fetch_add(32);
-            if (i0 >= n) return;
-            const size_t i1 = i0 + 32 < n ? i0 + 32 : n;
-            for (size_t i = i0; i < i1; i++) fn(i);
+        try {
+            for (;;) {
+                const size_t i0 = next.fetch_add(32);
+                if (i0 >= n) return;
+                const size_t i1 = i0 + 32 < n ? i0 + 32 : n;
+                for (size_t i = i0; i < i1; i++) fn(i);
+            }
+        } catch (...) {          // an exception must not leave a std::thread: keep the first one for the caller
+            std::lock_guard<std::mutex> lk(err_lock);
+            if (!first_error) first_error = std::current_exception();
+            next.store(n);
         }
     };
     std::vector<std::thread> th;
     for (unsigned t = 1; t < nt; t++) th.emplace_back(worker);
     worker();
     for (auto &t : th) t.join();
+    if (first_error) std::rethrow_exception(first_error);
 }
 
 // one decoded request with its witness assignment and cipher output (or the panic value it produced)
@@ -236,6 +246,9 @@ void prepare(const Json &j, Prepared &p) {
         p.ok = true;
     } catch (const Panic &e) {
         p.panic = e.json;
+    } catch (const std::exception &e) {       // not a modelled panic: answer this request like a Go error object, keep the others
+        fprintf(stderr, "zkprove: %s\n", e.what());
+        p.panic = "{}";
     }
 }
 
