@@ -244,7 +244,7 @@ extern "C" double zkp_microbench(int kind, long threads, int iters) {
     }
     ZK_HIP(hipEventSynchronize(e1));
     ZK_HIP(hipEventElapsedTime(&ms, e0, e1));
-    hipEventDestroy(e0); hipEventDestroy(e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return ms;
     ZKP_CATCH(-1.0)
 }
