@@ -239,6 +239,25 @@ __global__ __launch_bounds__(SORT_THREADS) void k_msm_sort(const Fr *__restrict_
 //   k_msm_binsort  : one workgroup per (coarse bin, instance): counting sort of the bin (~4096 entries) by the
 //                    7 low bucket bits into the final array; all scattered writes stay inside a 16 KiB window (L2).
 // Intermediate entry: idx (21 bits) | fine bucket (7 bits) << 21 | sign << 31.
+// Exclusive prefix sum of up to 256 LDS counters by ONE wavefront (lanes 0..63 of the workgroup, four counters per lane):
+// out[k] = sum_{i<k} in[i]; returns the total in every lane.  Replaces single-thread scans that cost ~70 cycles of LDS latency
+// per counter, once per tile / bin.
+__device__ __forceinline__ uint32_t wave_exclusive_scan_256(const uint32_t *in, uint32_t *out, uint32_t n, int lane) {
+    uint32_t v[4], s = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const uint32_t k = 4u * lane + q; v[q] = k < n ? in[k] : 0u; s += v[q]; }
+    uint32_t incl = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    uint32_t run = incl - s;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const uint32_t k = 4u * lane + q; if (k < n) out[k] = run; run += v[q]; }
+    return __shfl(incl, 63, 64);
+}
+
 static constexpr int FINE_BITS = 7;
 static constexpr int PART_THREADS = 512;
 static constexpr int MAX_COARSE = 256;
@@ -276,15 +295,15 @@ __global__ __launch_bounds__(PART_THREADS) void k_msm_partition(const Fr *__rest
         }
     }
     __syncthreads();
-    if (tid == 0) {
-        uint32_t run = 0;
-        for (uint32_t k = 0; k < nbin; k++) {
-            uint32_t t = 0;
-            for (int wv = 0; wv < nwave; wv++) t += wave_hist[wv * MAX_COARSE + k];
-            bin_base[k] = run;
-            run += t;
-        }
-        bin_base[nbin] = run;
+    if (tid < (int)nbin) {                      // fold the per-wavefront histograms into tile_off (scratch here)
+        uint32_t t = 0;
+        for (int wv = 0; wv < nwave; wv++) t += wave_hist[wv * MAX_COARSE + tid];
+        tile_off[tid] = t;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const uint32_t total = wave_exclusive_scan_256(tile_off, bin_base, nbin, tid);
+        if (tid == 0) bin_base[nbin] = total;
     }
     __syncthreads();
     for (uint32_t k = tid; k <= nbin; k += PART_THREADS) coarse_base[b * (MAX_COARSE + 1) + k] = bin_base[k];
@@ -316,10 +335,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_msm_partition(const Fr *__rest
             }
         }
         __syncthreads();
-        if (tid == 0) {
-            uint32_t run = 0;
-            for (uint32_t k = 0; k < nbin; k++) { tile_off[k] = run; run += tile_cnt[k]; }
-        }
+        if (tid < 64) wave_exclusive_scan_256(tile_cnt, tile_off, nbin, tid);
         __syncthreads();
 #pragma unroll
         for (int w = 0; w < 24; w++) {
@@ -367,10 +383,11 @@ __global__ __launch_bounds__(256) void k_msm_binsort(const uint32_t *__restrict_
         atomicAdd(&hist[(v >> 21) & fmask], 1u);
     }
     __syncthreads();
-    if (tid == 0) {
-        uint32_t run = 0;
-        for (int k = 0; k < (1 << FINE_BITS); k++) { cursor[k] = run; bs[k] = lo + run; run += hist[k]; }
-        if (bin + 1 == gridDim.x) bs[1 << FINE_BITS] = lo + run;          // bucket_start[nb] = total
+    if (tid < 64) {
+        const uint32_t total = wave_exclusive_scan_256(hist, cursor, 1u << FINE_BITS, tid);
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const uint32_t k = 4u * tid + q; if (k < (1u << FINE_BITS)) bs[k] = lo + cursor[k]; }    // own writes
+        if (tid == 0 && bin + 1 == gridDim.x) bs[1 << FINE_BITS] = lo + total;          // bucket_start[nb] = total
     }
     __syncthreads();
     if (fits) {
