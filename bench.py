@@ -29,8 +29,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1024, help="proofs per GPU per step")
     ap.add_argument("--alg", type=int, default=0, help="0 chacha20 (headline), 1 aes-128-ctr, 2 aes-256-ctr")
     ap.add_argument("--no-pipeline", action="store_true", help="one stream, no overlap of consecutive steps")
