@@ -116,6 +116,11 @@ int zkp_msm_g1_dense(long n, long batch, const uint8_t *points, const uint8_t *s
  * ze[i] = 1/(N D) sum_k w^-ik g^-k Z_k (2^logn points) and zc[j] = -1/(N D) sum_k w^-jk Z_k (ncons points), D = g^N - 1;
  * replaces the last four transforms of gnark's computeH (backend/groth16/bn254/prove.go) per proof. */
 int zkp_fold_quotient_bases(int logn, long ncons, const uint8_t *z, uint8_t *ze, uint8_t *zc);
+/* second half of the folding: K'_w = K_w + sum_{terms of wire w} coeffs[coeff] * zc[cons] (the R1CS output matrix applied to zc).
+ * k: the points of the wires rows_k (ascending); terms: (wire, cons, coeff index) u32 triples.  Returns the number of folded rows
+ * written to out_rows / out_points (union of rows_k and the term wires, ascending), -1 on error. */
+long zkp_fold_output_matrix(long nzc, const uint8_t *zc, long nk, const uint8_t *k, const uint32_t *rows_k, long nterms, const uint32_t *terms,
+                            long ncoeff, const uint8_t *coeffs, uint32_t *out_rows, uint8_t *out_points);
 /* kind 0: Fp mul (2/iter) 1: G1 mixed add 2: G2 mixed add; returns milliseconds */
 double zkp_microbench(int kind, long threads, int iters);
 

@@ -167,6 +167,39 @@ def test_fold_quotient_bases_matches_definition(zk, oracle, logn, ncons):
     assert np.array_equal(zc, oracle.g1_fixed_base(oracle.ints_to_le32(zc_s)))
 
 
+def test_fold_output_matrix_matches_definition(zk, oracle):
+    """keyfold.hip, second half: K'_w = K_w + sum_j O_jw Zc_j with small, negative (r - small), zero and wide coefficients, a wire with
+    hundreds of terms (chunked partial sums), wires only in K, wires only in the matrix"""
+    rng = np.random.default_rng(77)
+    nzc, nwires = 40, 30
+    zc_s = oracle.le32_to_ints(_rand_fr(rng, nzc))
+    zc = oracle.g1_fixed_base(oracle.ints_to_le32(zc_s))
+    rows_k = np.array([3, 4, 7, 8, 9, 20, 29], np.uint32)
+    k_s = oracle.le32_to_ints(_rand_fr(rng, len(rows_k)))
+    k = oracle.g1_fixed_base(oracle.ints_to_le32(k_s))
+    coeffs = [0, 1, 2, R - 1, R - 5, 65537, int.from_bytes(rng.bytes(31), "little"), (R - int.from_bytes(rng.bytes(20), "little")) % R]
+    terms = []
+    for _ in range(400):
+        terms.append((0, int(rng.integers(nzc)), int(rng.integers(len(coeffs)))))          # the constant wire: many terms
+    for w in (4, 5, 9, 12, 12, 12, 29, 17):
+        for _ in range(int(rng.integers(1, 6))):
+            terms.append((w, int(rng.integers(nzc)), int(rng.integers(len(coeffs)))))
+    rng.shuffle(terms)
+    t = np.array(terms, np.uint32).reshape(-1)
+    co = oracle.ints_to_le32(coeffs)
+    cap = len(rows_k) + len(terms)
+    out_rows, out_pts = np.zeros(cap, np.uint32), np.zeros((cap, 64), np.uint8)
+    n = zk.lib.zkp_fold_output_matrix(nzc, zc.ctypes.data, len(rows_k), k.ctypes.data, rows_k.ctypes.data, len(terms), t.ctypes.data, len(coeffs),
+                                      co.ctypes.data, out_rows.ctypes.data, out_pts.ctypes.data)
+    assert n > 0, zk.last_error()
+    exp = {int(w): ks for w, ks in zip(rows_k, k_s)}
+    for w, cons, ci in terms:
+        exp[w] = (exp.get(w, 0) + coeffs[ci] * zc_s[cons]) % R
+    assert list(out_rows[:n]) == sorted(exp)
+    want = oracle.g1_fixed_base(oracle.ints_to_le32([exp[w] for w in sorted(exp)]))
+    assert np.array_equal(out_pts[:n], want)
+
+
 def test_full_size_ntt_round_trip_and_linearity(zk):
     """N = 2^16 (the ChaCha domain), batch 64: inverse(forward(x)) == x through both kernel families, and the transform is
     linear -- size-independent properties at a size the CPU oracle would take minutes for"""

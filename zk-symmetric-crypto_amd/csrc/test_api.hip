@@ -189,6 +189,32 @@ extern "C" int zkp_fold_quotient_bases(int logn, long ncons, const uint8_t *z, u
     ZKP_CATCH(-1)
 }
 
+// key folding, second half (keyfold.hip): K'_w = K_w + sum over the terms of wire w of coeff * Zc[cons].
+// zc: nzc*64, k: nk*64 canonical LE points of the wires rows_k[nk] (ascending); terms: nterms*(wire, cons, coeff index) u32 triples;
+// coeffs: ncoeff*32 canonical LE scalars.  out_rows (cap nk + nterms) / out_points receive the folded set; returns its size or -1.
+extern "C" long zkp_fold_output_matrix(long nzc, const uint8_t *zc, long nk, const uint8_t *k, const uint32_t *rows_k, long nterms, const uint32_t *terms,
+                                       long ncoeff, const uint8_t *coeffs, uint32_t *out_rows, uint8_t *out_points) {
+    ZKP_TRY
+    DevBuf<G1Affine> dzc((size_t)nzc + 1), dk((size_t)nk + 1);
+    ZK_HIP(hipMemcpy(dzc.p, zc, (size_t)nzc * 64, hipMemcpyHostToDevice));
+    if (nk) ZK_HIP(hipMemcpy(dk.p, k, (size_t)nk * 64, hipMemcpyHostToDevice));
+    fp_to_mont_dev(dzc.p, (size_t)nzc * 2, 0);
+    fp_to_mont_dev(dk.p, (size_t)nk * 2, 0);
+    DevBuf<Fr> dco((size_t)ncoeff + 1);
+    ZK_HIP(hipMemcpy(dco.p, coeffs, (size_t)ncoeff * 32, hipMemcpyHostToDevice));
+    fr_to_mont(dco.p, (size_t)ncoeff, 0);
+    std::vector<OutputTerm> tv((size_t)nterms);
+    for (long i = 0; i < nterms; i++) tv[i] = OutputTerm{terms[3 * i], terms[3 * i + 1], terms[3 * i + 2]};
+    std::vector<uint32_t> rk(rows_k, rows_k + nk), rows;
+    DevBuf<G1Affine> outp;
+    fold_output_matrix(dzc.p, dk.p, rk, std::move(tv), dco.p, outp, rows, 0);
+    hipLaunchKernelGGL(zk::k_fp_from_mont, dim3(ceil_div(rows.size() * 2 + 1, 256)), dim3(256), 0, 0, (Fp *)outp.p, rows.size() * 2);
+    ZK_HIP(hipMemcpy(out_points, outp.p, rows.size() * 64, hipMemcpyDeviceToHost));
+    memcpy(out_rows, rows.data(), rows.size() * 4);
+    return (long)rows.size();
+    ZKP_CATCH(-1)
+}
+
 // -------- micro-benchmarks: raw field-multiplication / point-addition throughput on the device
 namespace zk {
 template <class F>
