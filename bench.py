@@ -1,42 +1,186 @@
 #!/usr/bin/env python3
-"""bench.py -- Groth16 proofs/s of the MI355X prover on BASELINE.json's headline workload.
+"""bench.py -- Groth16 proofs/s of the MI355X prover on BASELINE.json's headline workloads.
 
-A "step" = one pass of the whole proving path (witness solve -> computeH (7 NTT) -> 4 G1 MSM + 1 G2 MSM
--> finalize) over ONE batch of 1024 independent ChaCha20 circuit instances per GPU, witness assignments
-already resident in HBM.  N > 1: one process per GPU (torchrun), each rank proves its own batch, no data-path
-collective (proofs are independent units); barrier + max-over-ranks timing.
+A "step" = one pass of the whole proving path (witness solve -> 4 NTT + A*B on the coset -> 4 G1 MSM + 1 G2 MSM
+(+ 2 Pedersen MSMs for AES) -> proof tail) over ONE batch of 1024 independent circuit instances per GPU, witness
+assignments already resident in HBM.  The headline `value` is ChaCha20 (BASELINE config 2); the AES-256-CTR half of
+the metric (config 3) is timed in the same process right after it and reported under "aes256_ctr" in the same line.
+
+N > 1 (`--gpus N`): one process per GPU.  Started as the driver does (torchrun: WORLD_SIZE set) this file is a rank;
+started plainly (`python bench.py --gpus N`) it first launches the N ranks itself as CHILD processes
+(`python -m torch.distributed.run --nproc-per-node N bench.py ...`) before anything touches a GPU and relays rank 0's
+JSON line.  Each rank proves its own batch (independent proofs: no data-path collective); RCCL
+carries the barrier, the max-over-ranks time and the end-of-run all_gather of the fixed-size proof records
+([B][384] u8 per rank), which rank 0 spot-checks with the product's verifier.  With K steps of 1024 proofs per GPU,
+`--gpus 8 --steps 8` is exactly BASELINE config 4 (65 536 ChaCha20 proofs, 8 192 per GPU).
 
 Prints ONE JSON line (see the driver contract).  The CPU oracle is used only for `cpu_baseline`.
 """
 import argparse
+import hashlib
 import importlib
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 # algorithmic HBM bytes per proof, SURVEY.md section 8d / BASELINE.md section 2
 BYTES_PER_PROOF = {0: 56378656, 1: 113334016, 2: 128283328}
-# dominant kernel = quotient MSM bucket kernel (k_msm_accumulate<Fp> on G1.Z): one 32 B scalar + one 64 B base per term
+# dominant kernel = bucket accumulation of the quotient MSM over G1.Z: one 32 B scalar + one 64 B base per term
 Z_TERMS = {0: 65535, 1: 131071, 2: 131071}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+METRIC = "Groth16 proofs/sec (ChaCha20 1-block, AES-256-CTR 1-block) at 1/2/4/8 GPU"
+PHASES = ("solve", "commit", "ntt", "msm_g1", "msm_g2", "finalize", "total", "z_segments")
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1024, help="proofs per GPU per step")
-    ap.add_argument("--alg", type=int, default=0, help="0 chacha20 (headline), 1 aes-128-ctr, 2 aes-256-ctr")
+    ap.add_argument("--alg", type=int, default=0, help="headline algorithm: 0 chacha20 (default), 1 aes-128-ctr, 2 aes-256-ctr")
+    ap.add_argument("--no-aes256", action="store_true", help="skip the AES-256-CTR leg of the metric")
     ap.add_argument("--no-pipeline", action="store_true", help="one stream, no overlap of consecutive steps")
     ap.add_argument("--cpu-proofs", type=int, default=-1, help="cpu_baseline sample: proofs per worker process (0 = skip, -1 = default 8)")
-    args = ap.parse_args()
+    ap.add_argument("--master-port", type=int, default=0)
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="CPU check of the N-rank launcher + gather plumbing (gloo, no GPU, nothing is proved or timed)")
+    return ap.parse_args(argv)
 
+
+# ------------------------------------------------------------------------------------------------ launcher
+def launch_ranks(args):
+    """`python bench.py --gpus N` with no rendezvous in the environment: start the N ranks as children of THIS process, which
+    never imports torch.cuda nor loads libzkprove.so (no exec* from a GPU-initialised process), and relay rank 0's line."""
+    port = args.master_port or (29000 + os.getpid() % 20000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["ZKP_BENCH_LAUNCHED"] = "1"
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    lines = [l for l in res.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+    if lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    return res.returncode if res.returncode else (0 if lines else 1)
+
+
+# ------------------------------------------------------------------------------------------------ one rank
+class Leg:
+    """One algorithm on this rank: synthetic key, InitAlgorithm, resident batch."""
+
+    def __init__(self, zk, alg, B, rank):
+        H = zk.synth
+        self.zk, self.alg, self.B = zk, alg, B
+        r1cs = H.r1cs_bytes(alg)
+        # the reference's pk.* are not distributable: synthetic proving key generated on the GPU (ZkpSetup) in gnark's format
+        t0 = time.time()
+        pk, self.vk = zk.setup(r1cs, H.toxic_from_seed(1), raw=True)
+        self.t_setup = time.time() - t0
+        t0 = time.time()
+        if not zk.init_algorithm(alg, pk, r1cs):
+            raise SystemExit("InitAlgorithm failed")
+        self.t_init = time.time() - t0
+        # synthetic instances: SplitMix64(0x5EED0000 + config index), independent stream per rank
+        import numpy as np
+        rng = H.SplitMix64(0x5EED0000 + (1 if alg == 0 else 2) + 1000 * rank)
+        self.insts = [H.make_instance(alg, rng) for _ in range(B)]
+        wits = np.zeros((B, zk.lib.zkp_n_inputs(alg)), np.uint32)
+        self.outputs = []
+        for i, inst in enumerate(self.insts):
+            _, w, out = zk.request_witness(H.request_json(alg, inst))      # product host logic (ciphers + packing)
+            wits[i] = w
+            self.outputs.append(out)
+        self.rb = zk.ResidentBatch(alg, wits, [i["r"] for i in self.insts], [i["s"] for i in self.insts], [i["randomize"] for i in self.insts])
+
+    def run(self, steps, pipeline):
+        if pipeline:
+            return [self.rb.steps(steps)]
+        return [self.rb.step() for _ in range(steps)]
+
+
+def profile_manifest():
+    """profiles/current.json names the files (and the commit they were collected at) that carry the numbers bench.py cannot
+    measure from inside one run: the PMC traffic of the dominant kernel and the mixed-addition microbenchmark."""
+    try:
+        m = json.load(open(os.path.join(ROOT, "profiles", "current.json")))
+    except Exception:
+        return {}
+    return m
+
+
+def roofline_objects(alg, B, mean, value_per_gpu, manifest):
+    zdur_ms = mean.get("z_segments", 0.0) or mean["msm_g1"]
+    zbytes = Z_TERMS[alg] * 96 * B
+    achieved = zbytes / (zdur_ms * 1e-3) / 1e9
+    traffic, traffic_src = None, None
+    pm = manifest.get("pmc_traffic", {}).get(str(alg))
+    if pm and B == 1024:
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", pm["file"])))
+            v = d["kernels"][pm["kernel"]]
+            traffic = (v["FETCH_SIZE_KB_per_launch_max"] + v["WRITE_SIZE_KB_per_launch_max"]) * 1024.0
+            traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command line; collected at commit %s -- not measured by this run)" % (pm["file"], manifest.get("commit", "?"))
+        except Exception:
+            traffic = None
+    mb = manifest.get("microbench", {})
+    nwin = 16
+    roof = {"bound": "hbm", "kernel": manifest.get("dominant_kernel", "bucket accumulation of the quotient MSM over G1.Z"), "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "launch_ms": zdur_ms, "algorithmic_bytes_per_launch": zbytes,
+            "whole_path_GBps": value_per_gpu * BYTES_PER_PROOF[alg] / 1e9,
+            "point_adds_per_s": Z_TERMS[alg] * nwin * B / (zdur_ms * 1e-3),
+            "mixed_add_peak_per_s": mb.get("g1_mixed_add_per_s"), "fp_mul_peak_per_s": mb.get("fp_mul_per_s"),
+            "microbench_source": mb.get("file"),
+            "note": "integer-ALU bound (v_mad_u64_u32 + carry chains), not HBM bound: every term costs W=16 curve additions (one per signed 16-bit window, "
+                    "window multiples precomputed); launch_ms = HIP events around the accumulation launches of the quotient MSM on the prover's stream; MFMA not applicable"}
+    n_dom = 1 << (16 if alg == 0 else 17)
+    ntt_model = 7 * n_dom * 32 * 2 * B
+    ntt_moved = manifest.get("ntt_round_trips", 3) * 4 * n_dom * 32 * 2 * B
+    rntt = {"bound": "hbm", "kernel": "NTT passes of one batch (4 transforms: inverse + coset-forward of a and b)", "achieved": ntt_model / (mean["ntt"] * 1e-3) / 1e9,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ntt_model / (mean["ntt"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "phase_ms": mean["ntt"], "algorithmic_bytes": ntt_model, "bytes_moved_by_design": ntt_moved,
+            "moved_GBps": ntt_moved / (mean["ntt"] * 1e-3) / 1e9,
+            "note": "algorithmic bytes = SURVEY 8(d)'s 7-transform figure of the reference; the folded pipeline executes 4 (DESIGN.md 3a); integer-ALU bound: one 254-bit "
+                    "Montgomery multiplication per butterfly"}
+    return roof, rntt
+
+
+def selftest_rank(args, rank, world):
+    """Launcher / gather plumbing on CPU (gloo): every rank fabricates its slice of fixed-size records, rank 0 gathers."""
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    B = 4
+    recs = torch.full((B, 384), rank + 1, dtype=torch.uint8)
+    recs[:, 0] = torch.arange(B, dtype=torch.uint8)
+    out = [torch.zeros_like(recs) for _ in range(world)]
+    dist.all_gather(out, recs)
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    if rank == 0:
+        allrec = torch.stack(out)
+        print(json.dumps({"launcher_selftest": True, "n_gpus": world, "gathered_records": int(allrec.shape[0] * allrec.shape[1]),
+                          "rank_stamps": [int(allrec[r, 0, 1]) for r in range(world)], "max_time": float(t.item()),
+                          "launched_by_bench": bool(os.environ.get("ZKP_BENCH_LAUNCHED"))}), flush=True)
+    dist.destroy_process_group()
+    return 0
+
+
+def run_rank(args):
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.launcher_selftest:
+        return selftest_rank(args, rank, world)
+
+    sys.path.insert(0, ROOT)
     # stdout must carry exactly ONE JSON line: everything else that writes to fd 1 (the library mirrors the reference's
     # "Initialized <alg>" println, RCCL banners, ...) is sent to stderr; the JSON goes to the saved descriptor at the end
     import ctypes
@@ -44,9 +188,7 @@ def main():
     sys.stdout.flush()
     os.dup2(2, 1)
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import numpy as np
     import torch
     dist = None
     if world > 1 or os.environ.get("ZKP_BENCH_FORCE_DIST"):       # the env switch exercises the RCCL path on a 1-GPU box
@@ -57,128 +199,140 @@ def main():
     zk = importlib.import_module("zk-symmetric-crypto_amd")
     if zk.device_count() < 1:
         raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
-    zk.lib.ZkpSetDevice(local_rank)
+    if zk.lib.ZkpSetDevice(local_rank) != 0:
+        raise SystemExit("ZkpSetDevice(%d) failed" % local_rank)
     zk.lib.ZkpAllowUnpinnedKeys(1)
-
-    H = zk.synth                  # product-side synthetic workload generator (no oracle in the GPU leg)
-    alg, B = args.alg, args.batch
-    r1cs_bytes = H.r1cs_bytes(alg)
-    # the reference's pk.* are not distributable: generate a synthetic proving key on the GPU (ZkpSetup) in gnark's format
-    t0 = time.time()
-    pk_bytes, _vk = zk.setup(r1cs_bytes, H.toxic_from_seed(1), raw=True)
-    t_setup = time.time() - t0
-    t0 = time.time()
-    if not zk.init_algorithm(alg, pk_bytes, r1cs_bytes):
-        raise SystemExit("InitAlgorithm failed")
-    t_init = time.time() - t0
-
-    # synthetic instances: SplitMix64(0x5EED0000 + config index), independent stream per rank
-    rng = H.SplitMix64(0x5EED0000 + 1 + 1000 * rank)
-    insts = [H.make_instance(alg, rng) for _ in range(B)]
-    import numpy as np
-    wits = np.zeros((B, zk.lib.zkp_n_inputs(alg)), np.uint32)
-    for i, inst in enumerate(insts):
-        a, w, _ = zk.request_witness(H.request_json(alg, inst))      # product host logic (ciphers + packing)
-        wits[i] = w
-    rb = zk.ResidentBatch(alg, wits, [i["r"] for i in insts], [i["s"] for i in insts], [i["randomize"] for i in insts])
+    H = zk.synth
+    B, K = args.batch, args.steps
+    pipeline = not args.no_pipeline
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # K steps = K passes over the resident batch.  Default: consecutive passes are software-pipelined on three HIP streams
-    # (witness solve of pass k+1 and proof tail of pass k-1 under the NTT + MSM stage of pass k); every pass does the full work.
-    if args.no_pipeline:
-        for _ in range(args.warmup):
-            rb.step()
-    elif args.warmup:
-        rb.steps(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    phases = []
-    if args.no_pipeline:
-        for _ in range(args.steps):
-            phases.append(rb.step())
-    else:
-        phases.append(rb.steps(args.steps))
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    proofs, errs = rb.fetch()
-    ok = int((errs == 0).sum())
+    def timed(leg):
+        """W untimed warm-up passes, then exactly K passes between barrier + synchronize; max over ranks."""
+        if args.warmup:
+            leg.run(args.warmup, pipeline)
+        barrier()
+        t0 = time.perf_counter()
+        phases = leg.run(K, pipeline)
+        barrier()
+        dt_local = time.perf_counter() - t0
+        dt = dt_local
+        per_rank = [dt_local]
+        if dist is not None:
+            t = torch.tensor([dt_local], dtype=torch.float64, device="cuda")
+            every = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(every, t)
+            per_rank = [float(x.item()) for x in every]
+            dt = max(per_rank)
+        proofs, errs = leg.rb.fetch()
+        ok = int((errs == 0).sum())
+        # end-of-run gather of the fixed-size proof records (SURVEY 8e): [world][B][384] u8 on every rank via RCCL
+        gathered = proofs[None]
+        oks = [ok]
+        if dist is not None:
+            mine = torch.from_numpy(proofs).cuda()
+            allp = torch.empty((world,) + tuple(mine.shape), dtype=torch.uint8, device="cuda")
+            dist.all_gather_into_tensor(allp, mine)
+            okt = torch.tensor([ok], dtype=torch.int64, device="cuda")
+            okall = [torch.zeros_like(okt) for _ in range(world)]
+            dist.all_gather(okall, okt)
+            oks = [int(x.item()) for x in okall]
+            gathered = allp.cpu().numpy()
+        mean = {k: sum(p[k] for p in phases) / len(phases) for k in phases[0]}
+        return dict(dt=dt, per_rank=per_rank, mean=mean, ok=sum(oks), gathered=gathered)
+
+    def spot_check(leg, res):
+        """rank 0: the first proof of every rank's gathered slice must verify (product verifier, host pairing).  Rank r's
+        instance 0 is regenerated from its seed stream, so a mixed-up gather cannot pass."""
+        if not zk.init_verifier(leg.alg, leg.vk):
+            return "verifier init failed"
+        has_commit = leg.alg != 0
+        good = 0
+        for r in range(world):
+            rng = H.SplitMix64(0x5EED0000 + (1 if leg.alg == 0 else 2) + 1000 * r)
+            inst = H.make_instance(leg.alg, rng)
+            _, _, out = zk.request_witness(H.request_json(leg.alg, inst))
+            pb = zk.proof_serialize(res["gathered"][r, 0], has_commit)
+            good += bool(zk.verify(H.CIPHER[leg.alg], pb, out, list(zip(inst["nonces"], inst["counters"])), inst["data"]))
+        return "%d/%d" % (good, world)
+
+    manifest = profile_manifest()
+    legs_out = {}
+    head = Leg(zk, args.alg, B, rank)
+    res = timed(head)
+    algs = [(args.alg, head, res)]
+    if args.alg == 0 and not args.no_aes256:
+        aes = Leg(zk, 2, B, rank)
+        algs.append((2, aes, timed(aes)))
 
     if rank == 0:
-        K = args.steps
-        total_proofs = B * world * K
-        value = total_proofs / dt
-        mean = {k: sum(p[k] for p in phases) / len(phases) for k in phases[0]}
-        zdur_ms = mean.get("z_segments", 0.0) or mean["msm_g1"]
-        zbytes = Z_TERMS[alg] * 96 * B
-        achieved = zbytes / (zdur_ms * 1e-3) / 1e9
-        # HBM traffic of that kernel from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
-        # passes, same command line); only valid for the configuration it was collected on (chacha20, batch 1024)
-        traffic = None
-        try:
-            import glob
-            pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-            if pm and alg == 0 and B == 1024:
-                for k, v in json.load(open(pm[-1]))["kernels"].items():
-                    if "k_msm_accumulate<zk::Field<zk::FpParams>, true>" in k:
-                        traffic = (v["FETCH_SIZE_KB_per_launch_max"] + v["WRITE_SIZE_KB_per_launch_max"]) * 1024.0
-        except Exception:
-            traffic = None
+        lines = {}
+        for alg, leg, r in algs:
+            value = B * world * K / r["dt"]
+            roof, rntt = roofline_objects(alg, B, r["mean"], value / world, manifest)
+            lines[alg] = {
+                "value": value, "unit": "proofs/s", "ms_per_step": r["dt"] / K * 1e3,
+                "per_rank_proofs_per_s": [B * K / t for t in r["per_rank"]],
+                "blocks_per_s": value * (2 if alg == 0 else 5),
+                "workload": "%s one circuit instance per proof (%d cipher blocks), batch=%d proofs per GPU per step, synthetic keys/plaintexts, synthetic proving key"
+                            % (H.CIPHER[alg], 2 if alg == 0 else 5, B),
+                "phases_ms": r["mean"], "solver_ok": r["ok"], "solver_ok_of": B * world,
+                "gathered_proof_records": int(r["gathered"].shape[0] * r["gathered"].shape[1]),
+                "gathered_sha256": hashlib.sha256(r["gathered"].tobytes()).hexdigest(),
+                "gather_spot_check_verified": spot_check(leg, r),
+                "init_s": leg.t_init, "setup_s": leg.t_setup,
+                "roofline": roof, "roofline_ntt": rntt,
+            }
+        h = lines[args.alg]
         out = {
-            "metric": "Groth16 proofs/sec (ChaCha20 1-block, AES-256-CTR 1-block) at 1/2/4/8 GPU",
-            "value": value, "unit": "proofs/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
-            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "metric": METRIC, "value": h["value"], "unit": "proofs/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": h["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32x8 (254-bit Montgomery, integer)", "data": "synthetic",
-            "config": {"workload": "%s one circuit instance per proof (%d cipher blocks), batch=%d proofs per GPU, synthetic keys/plaintexts, synthetic proving key"
-                                   % (H.CIPHER[alg], 2 if alg == 0 else 5, B),
-                       "algorithm_id": alg, "batch_per_gpu": B, "pipelined_steps": not args.no_pipeline, "parallelism": "dp%d (independent proofs, no collective)" % world,
-                       "blocks_per_s": value * (2 if alg == 0 else 5)},
-            "phases_ms": mean, "phases_note": ("pipelined: 'solve' (+'commit') and 'finalize' ran on their own streams UNDER the neighbouring passes' ntt/msm and are not additive; total = whole call / steps" if not args.no_pipeline else "single stream: phases are additive"), "solver_ok": ok, "init_s": t_init, "setup_s": t_setup,
-            "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate<Fp, dense> (bucket accumulation of the quotient MSM over G1.Z)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "launch_ms": zdur_ms, "algorithmic_bytes_per_launch": zbytes,
-                         "whole_path_GBps": value / world * BYTES_PER_PROOF[alg] / 1e9,
-                         "mixed_adds_per_s": Z_TERMS[alg] * 16 * B / (zdur_ms * 1e-3), "mixed_add_peak_per_s": 10.8e9,
-                         "note": "integer-ALU bound (v_mad_u64_u32 + v_addc_co_u32 chains): the kernel runs W=16 mixed additions per term and gathers one "
-                                 "64-byte window multiple per addition (traffic = 16 x 64 B per term by design, served mostly from MALL/HBM); "
-                                 "mixed_add_peak = back-to-back G1 mixed additions measured by scripts/gpu_microbench.py; MFMA not applicable"},
+            "config": {"workload": h["workload"], "algorithm_id": args.alg, "batch_per_gpu": B, "pipelined_steps": pipeline,
+                       "parallelism": "dp%d (independent proofs per rank, no data-path collective; RCCL: barrier, timing, all_gather of proof records)" % world,
+                       "proofs_total": B * world * K, "blocks_per_s": h["blocks_per_s"],
+                       "aes256_ctr_proofs_per_s": lines[2]["value"] if 2 in lines and args.alg != 2 else None},
+            "phases_ms": h["phases_ms"],
+            "phases_note": ("pipelined: 'solve' (+'commit') and 'finalize' ran on their own streams UNDER the neighbouring passes' ntt/msm and are not additive; total = whole call / steps"
+                            if pipeline else "single stream: phases are additive"),
+            "solver_ok": h["solver_ok"], "per_rank_proofs_per_s": h["per_rank_proofs_per_s"],
+            "gathered_proof_records": h["gathered_proof_records"], "gathered_sha256": h["gathered_sha256"],
+            "gather_spot_check_verified": h["gather_spot_check_verified"],
+            "init_s": h["init_s"], "setup_s": h["setup_s"],
+            "roofline": h["roofline"], "roofline_ntt": h["roofline_ntt"],
         }
-        # the transforms (north_star asks for the achieved HBM fraction of MSM and NTT): algorithmic bytes = SURVEY 8(d)'s
-        # 7-transform figure of the reference (7 * N * 32 * 2 per proof); the folded pipeline executes 4 transforms in 3 HBM
-        # round trips each, timed with HIP events around the whole transform phase
-        n_dom = 1 << (16 if alg == 0 else 17)
-        ntt_model = 7 * n_dom * 32 * 2 * B
-        ntt_moved = 4 * n_dom * 32 * 2 * 3 * B
-        out["roofline_ntt"] = {"bound": "hbm", "kernel": "k_ntt_dif_lds / k_ntt_dit_lds passes of one batch (4 transforms)", "achieved": ntt_model / (mean["ntt"] * 1e-3) / 1e9,
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ntt_model / (mean["ntt"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                               "phase_ms": mean["ntt"], "algorithmic_bytes": ntt_model, "bytes_moved_by_design": ntt_moved,
-                               "moved_GBps": ntt_moved / (mean["ntt"] * 1e-3) / 1e9,
-                               "note": "integer-ALU bound: one 254-bit Montgomery multiplication per butterfly; see DESIGN.md section 3"}
+        if 2 in lines and args.alg != 2:
+            out["aes256_ctr"] = lines[2]
         if args.cpu_proofs != 0 and world == 1:
             # CPU baseline: scripts/cpu_baseline.py in its own interpreter (no GPU runtime): one single-threaded oracle
-            # prover process per worker, forked after key generation; best of {cores/2, cores} workers
-            import subprocess
+            # prover process per worker, forked after key generation; best of {cores, 1.5 x cores} workers
             per = args.cpu_proofs if args.cpu_proofs > 0 else 8
             try:
-                res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "cpu_baseline.py"), str(alg), str(per)],
-                                     capture_output=True, text=True, timeout=900)
-                line = [l for l in res.stdout.splitlines() if l.startswith("{")]
-                out["cpu_baseline"] = json.loads(line[-1]) if line else {"error": (res.stderr or "no output")[-400:]}
+                cp = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "cpu_baseline.py"), str(args.alg), str(per)],
+                                    capture_output=True, text=True, timeout=900)
+                line = [l for l in cp.stdout.splitlines() if l.startswith("{")]
+                out["cpu_baseline"] = json.loads(line[-1]) if line else {"error": (cp.stderr or "no output")[-400:]}
             except Exception as e:          # the baseline must never take the GPU result down with it
                 out["cpu_baseline"] = {"error": repr(e)}
         sys.stdout.flush()
         ctypes.CDLL(None).fflush(None)
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)          # before torch / HIP are touched in this process
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -48,6 +48,10 @@ ProveReturn TOPRFFinalize(GoSlice params);
  * bytes, e.g. the vk returned by ZkpSetup or one of the reference's generated/vk.* files). */
 unsigned char Verify(GoSlice params);
 void VFree(void *pointer);
+/* libverify.go:28-64 (server side of TOPRF; out of scope like the two prover-side helpers above): bound by the unchanged loader
+ * (js/src/gnark/utils.ts:89-90), return the JSON string "toprf is not supported by libzkprove"; release r0 with VFree. */
+ProveReturn OPRFEvaluate(GoSlice params);
+ProveReturn GenerateThresholdKeys(GoSlice params);
 unsigned char ZkpInitVerifier(unsigned char algorithmID, GoSlice vk);
 
 /* ---------------------------------------------------------------- 2. extensions */
@@ -55,8 +59,16 @@ unsigned char ZkpInitVerifier(unsigned char algorithmID, GoSlice vk);
  * Needed because the reference's pk.* files are not distributable with this repo; default 0 (strict,
  * as the reference).  The R1CS pin is always enforced. */
 void ZkpAllowUnpinnedKeys(int allow);
-/* Select the HIP device for this process (default: LOCAL_RANK env or 0).  Call before InitAlgorithm. */
+/* Devices.  hipSetDevice is per thread, so the library binds the device itself at every entry point, whichever thread calls.
+ *  - ZkpSetDevice(k) or LOCAL_RANK=k (one process per GPU, torchrun): this process uses device k only.
+ *  - neither: InitAlgorithm keeps one replica of the algorithm on EVERY visible device (HIP_VISIBLE_DEVICES narrows that) and
+ *    ProveBatch / coalesced Prove calls split their requests over the replicas in contiguous slices (>= 64 requests per device;
+ *    independent proofs, no exchange between devices), so the unchanged callers use a whole 8-GPU node through the same ABI.
+ *  - ZKPROVE_DEVICES="all" | "0,2,3" overrides both (a device may be listed twice).
+ * Call ZkpSetDevice before InitAlgorithm; returns 0, or -1 for a device that does not exist.
+ * ZkpDeviceReplicas(id) = number of device replicas of an initialised algorithm (0 = not initialised). */
 int ZkpSetDevice(int device);
+int ZkpDeviceReplicas(int algorithmID);
 /* Drop all initialised algorithms (frees HBM). */
 void ZkpReset(void);
 /* params = JSON array of Prove requests (all for the same cipher); returns a JSON array of Prove

@@ -1,0 +1,171 @@
+"""BASELINE.json's configurations at their full sizes on the HIP path, through the C ABI (task 1):
+config 1 (the fixed RFC 8439 vector of chacha_test.go:123-152 through Prove), config 3 (AES-256-CTR, resident batch of
+1024), the per-GPU share of config 4 (8192 ChaCha20 requests through ProveBatch), and the in-library device sharding
+(two replicas) that lets the unchanged callers use every GPU of a node."""
+import base64
+import json
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import gnark_format as gf
+from oracle import pairing
+from oracle import r1cs_format as rf
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _fresh(zk, alg, seed=1):
+    """keys from the product's own setup with the oracle fixture's toxic waste (both provers then share a key)"""
+    from oracle import ref
+    zk.lib.ZkpAllowUnpinnedKeys(1)
+    r1cs = zk.synth.r1cs_bytes(alg)
+    pk, vk = zk.setup(r1cs, ref.toxic_from_seed(seed), raw=True)
+    zk.lib.ZkpReset()
+    assert zk.init_algorithm(alg, pk, r1cs) and zk.init_verifier(alg, vk)
+
+
+def test_config1_rfc8439_vector_through_prove(zk, oracle):
+    """BASELINE config 1 / SURVEY 8d-1: key 00..1f, nonce 00 00 00 00 00 00 00 4a 00 00 00 00, counters 1,2, the 128-byte bPt / bCt
+    literals of gnark/circuits/chachaV3/chacha_test.go:123-152.  Prove's ciphertext is pinned by the reference; with fixed blinding
+    the proof bytes equal the oracle's, and a second run with PRNG blinding verifies."""
+    _fresh(zk, 0)
+    key = bytes(range(32))
+    nonce = bytes.fromhex("000000000000004a00000000")
+    pt = bytes.fromhex(
+        "4c616469657320616e642047656e746c656d656e206f662074686520636c617373206f66202739393a204966204920636f"
+        "756c64206f6666657220796f75206f6e6c79206f6e652074697020666f7220746865206675747572652c2073756e736372"
+        "65656e20776f756c642062652069" "4c616469657320616e642047656e746c")
+    ct = bytes.fromhex(
+        "6e2e359a2568f98041ba0728dd0d6981e97e7aec1d4360c20a27afccfd9fae0bf91b65c5524733ab8f593dabcd62b357"
+        "1639d624e65152ab8f530c359f0861d807ca0dbf500d6a6156a38e088a22b65e52bc514d16ccf806818ce91ab7793736"
+        "5af90bbf74a35be6b40b8eedf2785e42" "bf02106a16533ac0e69f9caf5cffb081")
+    inst = dict(key=key, nonces=[nonce, nonce], counters=[1, 2], data=pt, r=1, s=1, randomize=0)
+    res = json.loads(zk.prove_deterministic_raw(H.request_json(0, inst), 1, 1, 0))
+    assert base64.b64decode(res["ciphertext"]) == ct                           # the reference-held known answer
+    exp, out, *_ = H.oracle_proof_bytes(0, inst)
+    assert out == ct and base64.b64decode(res["proof"]) == exp                  # r = s = 1: bit-identical to the oracle
+    blocks = [(nonce, 1), (nonce, 2)]
+    assert zk.verify("chacha20", exp, ct, blocks, pt)
+    rnd = zk.prove(json.loads(H.request_json(0, inst)))                         # urandom blinding
+    assert rnd["proof"] != res["proof"] and base64.b64decode(rnd["ciphertext"]) == ct
+    assert zk.verify("chacha20", base64.b64decode(rnd["proof"]), ct, blocks, pt)
+    zk.lib.ZkpReset()
+
+
+def test_config3_aes256_full_size_batch_every_proof_verifies(zk, oracle):
+    """BASELINE config 3 at full size (AES-256-CTR, resident batch 1024, two pipelined passes): no solver error, 1024 distinct
+    proofs, every one passes the product's verifier, a proof does not verify against its neighbour's public inputs, and
+    instances 0 / 511 / 1023 are bit-identical to the oracle's proofs (BSB22 commitment and its proof of knowledge included)."""
+    from concurrent.futures import ThreadPoolExecutor
+    alg, B = 2, 1024
+    _fresh(zk, alg)
+    rng = H.SplitMix64(0x5EED0000 + 2)
+    insts = [H.make_instance(alg, rng) for _ in range(B)]
+    wits, outs = [], []
+    for inst in insts:
+        _, w, out = zk.request_witness(H.request_json(alg, inst))
+        wits.append(w); outs.append(out)
+    rb = zk.ResidentBatch(alg, np.array(wits, np.uint32), [i["r"] for i in insts], [i["s"] for i in insts], [i["randomize"] for i in insts])
+    rb.steps(2)
+    proofs, errs = rb.fetch()
+    assert not errs.any()
+    ser = [zk.proof_serialize(proofs[k], True) for k in range(B)]
+    assert len(set(ser)) == B and all(len(s) == 196 for s in ser)
+
+    def check(k):
+        return zk.verify(H.CIPHER[alg], ser[k], outs[k], list(zip(insts[k]["nonces"], insts[k]["counters"])), insts[k]["data"])
+    with ThreadPoolExecutor(max_workers=16) as ex:
+        ok = list(ex.map(check, range(B)))
+    assert all(ok), "instances failing verification: %s" % [k for k, v in enumerate(ok) if not v][:10]
+    assert not zk.verify(H.CIPHER[alg], ser[0], outs[1], list(zip(insts[0]["nonces"], insts[0]["counters"])), insts[0]["data"])
+    for k in (0, 511, 1023):
+        exp, out, *_ = H.oracle_proof_bytes(alg, insts[k])
+        assert ser[k] == exp and outs[k] == out
+    zk.lib.ZkpReset()
+
+
+def test_config4_per_gpu_share_8192_requests_through_prove_batch(zk, oracle):
+    """BASELINE config 4 = 65 536 ChaCha20 proofs over 8 GPUs = 8 192 per GPU: one ProveBatch call of 8 192 requests (eight
+    device chunks of 1024, software-pipelined).  Order preserved, every ciphertext right, every 16th proof plus the chunk
+    edges verified against ITS request (and not against the neighbour's), the last proof also under the oracle's pairing."""
+    from concurrent.futures import ThreadPoolExecutor
+    alg, n = 0, 8192
+    _fresh(zk, alg)
+    rng = H.SplitMix64(0x5EED0000 + 4)
+    insts = [H.make_instance(alg, rng) for _ in range(n)]
+    body = ("[" + ",".join(H.request_json(alg, i).decode() for i in insts) + "]").encode()
+    res = json.loads(zk.prove_batch_raw(body))
+    assert len(res) == n and all(isinstance(r, dict) and "proof" in r for r in res)
+    outs = [zk.request_witness(H.request_json(alg, i))[2] for i in insts]
+    assert all(base64.b64decode(res[k]["ciphertext"]) == outs[k] for k in range(n))
+    assert len({r["proof"] for r in res}) == n
+    picks = sorted(set(list(range(0, n, 16)) + [c * 1024 + d for c in range(8) for d in (0, 1, 1022, 1023)]))
+
+    def check(k):
+        blocks = list(zip(insts[k]["nonces"], insts[k]["counters"]))
+        good = zk.verify("chacha20", base64.b64decode(res[k]["proof"]), outs[k], blocks, insts[k]["data"])
+        cross = zk.verify("chacha20", base64.b64decode(res[(k + 1) % n]["proof"]), outs[k], blocks, insts[k]["data"])
+        return good and not cross
+    with ThreadPoolExecutor(max_workers=16) as ex:
+        ok = list(ex.map(check, picks))
+    assert all(ok), "requests failing: %s" % [picks[i] for i, v in enumerate(ok) if not v][:10]
+    vk = gf.vk_from_pk(H.oracle_pk(alg))
+    wit, _ = H.oracle_witness(alg, insts[n - 1])
+    assert pairing.groth16_verify(vk, gf.proof_parse(base64.b64decode(res[n - 1]["proof"])), wit[:2304])
+    zk.lib.ZkpReset()
+
+
+_SHARD_SCRIPT = r"""
+import base64, importlib, json, os, sys, threading
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+zk = importlib.import_module("zk-symmetric-crypto_amd")
+import helpers as H
+from oracle import ref
+zk.lib.ZkpAllowUnpinnedKeys(1)
+alg = {alg}
+r1cs = zk.synth.r1cs_bytes(alg)
+pk, vk = zk.setup(r1cs, ref.toxic_from_seed(1), raw=True)
+assert zk.init_algorithm(alg, pk, r1cs) and zk.init_verifier(alg, vk)
+zk.lib.ZkpDeviceReplicas.restype = int
+nrep = zk.lib.ZkpDeviceReplicas(alg)
+rng = H.SplitMix64(31337)
+n = 300
+insts = [H.make_instance(alg, rng) for _ in range(n)]
+res = json.loads(zk.prove_batch_raw(("[" + ",".join(H.request_json(alg, i).decode() for i in insts) + "]").encode()))
+ok = 0
+for k in range(n):
+    out = zk.request_witness(H.request_json(alg, insts[k]))[2]
+    blocks = list(zip(insts[k]["nonces"], insts[k]["counters"]))
+    ok += bool(base64.b64decode(res[k]["ciphertext"]) == out and zk.verify(H.CIPHER[alg], base64.b64decode(res[k]["proof"]), out, blocks, insts[k]["data"]))
+# Prove from a thread that never touched HIP before (Node's libuv pool, a goroutine's OS thread): the library binds the device itself
+box = []
+inst = insts[7]
+t = threading.Thread(target=lambda: box.append(zk.prove_deterministic_raw(H.request_json(alg, inst), inst["r"], inst["s"], inst["randomize"])))
+t.start(); t.join()
+exp, out, *_ = H.oracle_proof_bytes(alg, inst)
+got = json.loads(box[0])
+print(json.dumps(dict(replicas=nrep, verified=ok, n=n, thread_proof_matches_oracle=base64.b64decode(got["proof"]) == exp)))
+"""
+
+
+@pytest.mark.parametrize("alg", [0, 2])
+def test_in_library_sharding_over_two_device_replicas(alg):
+    """The drop-in library scales without its callers knowing about devices: with more than one device it keeps a replica of the
+    algorithm on each and ProveBatch cuts its request array into contiguous slices, one host thread per device (cabi.cpp,
+    prove_prepared).  A 1-GPU box exercises exactly that code with ZKPROVE_DEVICES=0,0 (two replicas on device 0): every one
+    of 300 proofs must verify against ITS request.  Also: Prove from a brand-new thread (hipSetDevice is per thread)."""
+    env = dict(os.environ, ZKPROVE_DEVICES="0,0")
+    env.pop("LOCAL_RANK", None)
+    res = subprocess.run([sys.executable, "-c", _SHARD_SCRIPT.format(root=H.ROOT, alg=alg)], env=env, capture_output=True, text=True, timeout=1200)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["replicas"] == 2
+    assert out["verified"] == out["n"] == 300
+    assert out["thread_proof_matches_oracle"]

@@ -23,6 +23,31 @@ def test_library_exports_every_declared_symbol(zk):
     for n in names:
         assert hasattr(zk.lib, n), "libzkprove.so does not export %s" % n
     zk.lib.enforce_binding()
+    # every symbol the two unchanged reference loaders bind: koffi (js/src/gnark/utils.ts:81-92) and cgo
+    # (libprove.go:18-86, libverify.go:18-64) -- the library stands in for libprove.so AND libverify.so
+    loader = {"Verify", "Free", "VFree", "Prove", "InitAlgorithm", "GenerateThresholdKeys", "OPRFEvaluate", "GenerateOPRFRequestData",
+              "TOPRFFinalize", "enforce_binding"}
+    assert loader <= set(names)
+    for fn in ("OPRFEvaluate", "GenerateThresholdKeys", "GenerateOPRFRequestData", "TOPRFFinalize"):
+        f = getattr(zk.lib, fn)
+        f.restype, f.argtypes = zk.ProveReturn, [zk.GoSlice]
+        sl, keep = zk._slice(b"{}")
+        ret = f(sl)
+        assert json.loads(zk.C.string_at(ret.r0, ret.r1)) == "toprf is not supported by libzkprove"
+        zk.lib.VFree(ret.r0)
+
+
+def test_dropin_target_writes_the_reference_artefact_names(zk, tmp_path):
+    """gnark/scripts/build.sh:7,15-26 writes bin/gnark/$GOOS-$GOARCH-lib{prove,verify}.so; js/src/gnark/utils.ts:63-74 loads exactly
+    those names.  `make dropin` puts the library there under both names."""
+    import ctypes
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", os.path.join(H.ROOT, "zk-symmetric-crypto_amd"), "dropin", "DROPIN_DIR=%s" % tmp_path])
+    for role, syms in (("libprove", ("InitAlgorithm", "Prove", "Free", "GenerateOPRFRequestData", "TOPRFFinalize")),
+                       ("libverify", ("Verify", "VFree", "GenerateThresholdKeys", "OPRFEvaluate"))):
+        lib = ctypes.CDLL(str(tmp_path / ("linux-x86_64-%s.so" % role)))
+        for sname in syms:
+            assert hasattr(lib, sname)
 
 
 @pytest.mark.parametrize("name", ["chacha20", "aes128", "aes256"])

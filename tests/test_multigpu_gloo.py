@@ -58,6 +58,24 @@ def test_two_rank_sharding_and_gather():
     assert all(s > 0 for s in sums)
 
 
+def test_bench_launcher_starts_n_ranks_and_gathers():
+    """`python bench.py --gpus 2` with no rendezvous in the environment must itself start two ranks (children of a parent that never
+    touches a GPU), and rank 0 must see both ranks' fixed-size records after the gather.  --launcher-selftest runs exactly that
+    plumbing on CPU (gloo): nothing is proved or timed."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launcher-selftest",
+                          "--master-port", str(31000 + os.getpid() % 2000)], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout                      # exactly one JSON line reaches the caller
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["launched_by_bench"] is True
+    assert out["gathered_records"] == 8 and out["rank_stamps"] == [1, 2]      # both ranks' slices arrived, in rank order
+    assert out["max_time"] == 2.0                                             # max over ranks
+
+
 def test_shard_range_partitions():
     import importlib
     sys.path.insert(0, ROOT)

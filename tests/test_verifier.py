@@ -46,6 +46,32 @@ def test_verify_accepts_oracle_proofs_and_rejects_tampering(zk, oracle, alg):
     assert zk.verify_raw(json.dumps(bad).encode()) is False
 
 
+def test_verifier_rejects_g2_points_outside_the_subgroup(zk, oracle):
+    """gnark-crypto's G2Affine.SetBytes (proof.ReadFrom, the embedded vk) refuses points of the twist that are not in the
+    order-r subgroup (cofactor 2p - r); so must Verify (Bs of the proof) and ZkpInitVerifier (beta2 / gamma2 / delta2)."""
+    alg = 0
+    inst = H.make_instance(alg, H.SplitMix64(4242))
+    proof, out, *_ = H.oracle_proof_bytes(alg, inst)
+    vkb = gf.vk_bytes(gf.vk_from_pk(H.oracle_pk(alg)))
+    assert zk.init_verifier(alg, vkb)
+    assert zk.verify_raw(json.dumps(_req(alg, inst, proof, out)).encode()) is True
+    xx = 1
+    while True:                                    # a random twist point is (almost surely) outside G2
+        comp = bytearray((0).to_bytes(32, "big") + xx.to_bytes(32, "big")); comp[0] |= 0x80
+        try:
+            pt, _ = gf.g2_decode(bytes(comp))
+            break
+        except ValueError:
+            xx += 1
+    assert gf.g2_on_curve(pt)
+    bad = bytearray(proof); bad[32:96] = gf.g2_compress(pt)                    # Proof.WriteTo: Ar(32) Bs(64) Krs(32) ...
+    assert zk.verify_raw(json.dumps(_req(alg, inst, bytes(bad), out)).encode()) is False
+    for off in (64, 128, 224):                                                 # vk: alpha1(32) beta1(32) beta2(64) gamma2(64) delta1(32) delta2(64)
+        badvk = bytearray(vkb); badvk[off:off + 64] = gf.g2_compress(pt)
+        assert not zk.init_verifier(alg, bytes(badvk))
+    assert zk.init_verifier(alg, vkb)
+
+
 def test_verify_malformed_requests_return_false(zk):
     for bad in (b"", b"{", b"[]", b'{"cipher":"rot13"}', b'{"cipher":"chacha20","proof":"AAAA","publicSignals":{}}',
                 b'{"cipher":"chacha20","proof":"!!","publicSignals":{"ciphertext":"","blocks":[],"input":""}}'):

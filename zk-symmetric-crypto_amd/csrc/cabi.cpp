@@ -32,28 +32,86 @@ constexpr int CHACHA_BLOCKS = 2;   // gnark/circuits/chachaV3/common.go:8
 constexpr int AES_BLOCKS = 5;      // gnark/circuits/aesV2/common.go:10
 
 struct Slot {
-    std::mutex lock;                     // impl/library.go:77-78 initLock
-    std::unique_ptr<Algorithm> alg;      // non-null == initDone
+    std::mutex lock;                                      // impl/library.go:77-78 initLock
+    std::vector<std::unique_ptr<Algorithm>> replicas;     // one per device of device_list(); non-empty == initDone.  [0] serves Prove()
 };
 Slot g_slots[3];
 bool g_allow_unpinned = false;
-int g_device = -1;
-std::once_flag g_dev_once;
+
+// ---- devices ---------------------------------------------------------------------------------------------------
+// One process per GPU (torchrun: LOCAL_RANK; or ZkpSetDevice) -> exactly that device.  Otherwise the library is the only
+// user of the node's GPUs as far as it can tell (the unchanged JS / Go callers know nothing about devices): it keeps a
+// replica of every initialised algorithm on each visible device and ProveBatch splits its requests over them
+// (independent proofs, contiguous slices, no collective -- SURVEY.md section 8e).  ZKPROVE_DEVICES = "all" | "0,2,3"
+// overrides both; HIP_VISIBLE_DEVICES narrows what "visible" means as usual.
+std::mutex g_dev_lock;
+int g_default_device = -1;               // resolved lazily
+bool g_device_explicit = false;          // ZkpSetDevice was called
+std::vector<int> g_device_list;          // resolved lazily, fixed once the first algorithm is initialised
+
+int visible_devices() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) return 0;
+    return n;
+}
+int resolve_default_locked() {
+    if (g_default_device >= 0) return g_default_device;
+    int dev = 0;
+    if (const char *lr = getenv("LOCAL_RANK")) {
+        dev = atoi(lr);
+        const int n = visible_devices();
+        if (n > 0) dev %= n;
+    }
+    return g_default_device = dev;
+}
+std::vector<int> device_list() {
+    std::lock_guard<std::mutex> lk(g_dev_lock);
+    if (!g_device_list.empty()) return g_device_list;
+    const int n = visible_devices();
+    std::vector<int> out;
+    if (const char *e = getenv("ZKPROVE_DEVICES")) {
+        if (!strcmp(e, "all")) { for (int d = 0; d < n; d++) out.push_back(d); }
+        else
+            for (const char *p = e; *p;) {
+                char *end = nullptr;
+                const long d = strtol(p, &end, 10);
+                if (end == p) break;
+                if (d >= 0 && d < n) out.push_back((int)d);         // the same device may be listed twice (two replicas: tests)
+                p = *end ? end + 1 : end;
+            }
+    }
+    if (out.empty()) {
+        if (g_device_explicit || getenv("LOCAL_RANK") || n <= 1) out.push_back(resolve_default_locked());
+        else for (int d = 0; d < n; d++) out.push_back(d);
+    }
+    if (g_default_device < 0) g_default_device = out[0];
+    return g_device_list = out;
+}
 
 thread_local std::string g_err;
 
-void select_device() {
-    std::call_once(g_dev_once, [] {
-        int dev = g_device;
-        if (dev < 0) {
-            const char *lr = getenv("LOCAL_RANK");
-            dev = lr ? atoi(lr) : 0;
-            int n = 0;
-            if (hipGetDeviceCount(&n) == hipSuccess && n > 0) dev %= n;
-        }
-        (void)hipSetDevice(dev);
-    });
+}  // namespace
+
+namespace zk {
+int default_device() {
+    std::lock_guard<std::mutex> lk(g_dev_lock);
+    return resolve_default_locked();
 }
+void set_default_device(int dev) {
+    std::lock_guard<std::mutex> lk(g_dev_lock);
+    g_default_device = dev;
+    g_device_explicit = true;
+    g_device_list.clear();
+}
+void bind_device(int dev) {
+    thread_local int bound = -1;            // hipSetDevice is thread-local state; skip the call when this thread already sits on dev
+    if (bound == dev) return;
+    ZK_HIP(hipSetDevice(dev));
+    bound = dev;
+}
+}  // namespace zk
+
+namespace {
 
 ProveReturn make_return(const std::string &s) {
     ProveReturn r;
@@ -190,9 +248,15 @@ void build_witness(const Request &rq, std::vector<uint32_t> &w, std::vector<uint
     }
 }
 
-Algorithm *get_alg(int id) {
+Algorithm *get_alg(int id) {                     // replica on the default device
     std::lock_guard<std::mutex> lk(g_slots[id].lock);
-    return g_slots[id].alg.get();
+    return g_slots[id].replicas.empty() ? nullptr : g_slots[id].replicas[0].get();
+}
+std::vector<Algorithm *> get_replicas(int id) {
+    std::lock_guard<std::mutex> lk(g_slots[id].lock);
+    std::vector<Algorithm *> out;
+    for (auto &r : g_slots[id].replicas) out.push_back(r.get());
+    return out;
 }
 
 std::string response_json(const std::vector<uint8_t> &proof, const std::vector<uint8_t> &ct) {
@@ -252,10 +316,20 @@ void prepare(const Json &j, Prepared &p) {
     }
 }
 
-// Prove prepared requests of ONE algorithm as one GPU batch (chunked and pipelined inside Algorithm::prove_batch).
+// Prove prepared requests of ONE algorithm: one GPU batch per device replica (chunked and pipelined inside
+// Algorithm::prove_batch).  With more than one replica the requests are cut into contiguous slices, one per device, each driven
+// by its own host thread (which binds that device); the proofs are independent, so there is no exchange between devices and the
+// results are simply written back at their request's index.
+constexpr size_t MIN_SHARD = 64;          // below this a slice does not fill a GPU: fewer devices are used
+void shard_range(size_t total, size_t rank, size_t world, size_t &lo, size_t &hi) {
+    const size_t base = total / world, rem = total % world;
+    lo = rank * base + (rank < rem ? rank : rem);
+    hi = lo + base + (rank < rem ? 1 : 0);
+}
 std::vector<std::string> prove_prepared(int alg_id, const std::vector<const Prepared *> &items, const U256 *r_fix, const U256 *s_fix, const U256 *rnd_fix) {
-    Algorithm *alg = get_alg(alg_id);
-    if (!alg) panic_str(std::string("proving params are not initialized for cipher: ") + ALGS[alg_id].name);   // library.go:143-145
+    const std::vector<Algorithm *> reps = get_replicas(alg_id);
+    if (reps.empty()) panic_str(std::string("proving params are not initialized for cipher: ") + ALGS[alg_id].name);   // library.go:143-145
+    Algorithm *alg = reps[0];
     const size_t B = items.size(), ni = alg->n_inputs();
     std::vector<uint32_t> inputs(B * ni);
     for (size_t i = 0; i < B; i++) {
@@ -268,7 +342,28 @@ std::vector<std::string> prove_prepared(int alg_id, const std::vector<const Prep
     if (rnd_fix) { for (size_t i = 0; i < B; i++) rnd[i] = rnd_fix[i]; } else fr_random_fill(rnd.data(), B);
     std::vector<ProofPoints> pp(B);
     std::vector<uint32_t> errs(B);
-    alg->prove_batch(B, inputs.data(), r.data(), s.data(), rnd.data(), pp.data(), errs.data());
+    size_t nshard = std::min(reps.size(), std::max<size_t>(1, B / MIN_SHARD));
+    if (nshard <= 1) {
+        alg->prove_batch(B, inputs.data(), r.data(), s.data(), rnd.data(), pp.data(), errs.data());
+    } else {
+        std::exception_ptr first_error;
+        std::mutex err_lock;
+        auto run = [&](size_t k) {
+            try {
+                size_t lo, hi;
+                shard_range(B, k, nshard, lo, hi);
+                reps[k]->prove_batch(hi - lo, inputs.data() + lo * ni, r.data() + lo, s.data() + lo, rnd.data() + lo, pp.data() + lo, errs.data() + lo);
+            } catch (...) {
+                std::lock_guard<std::mutex> lk(err_lock);
+                if (!first_error) first_error = std::current_exception();
+            }
+        };
+        std::vector<std::thread> th;
+        for (size_t k = 1; k < nshard; k++) th.emplace_back(run, k);
+        run(0);
+        for (auto &t : th) t.join();
+        if (first_error) std::rethrow_exception(first_error);
+    }
     std::vector<std::string> res(B);
     const bool has_commit = alg->has_commit;
     parallel_for(B, [&](size_t i) {
@@ -336,7 +431,6 @@ std::string prove_coalesced(const Prepared &p) {
 ProveReturn prove_one(GoSlice params, const U256 *r, const U256 *s, const U256 *rnd) {
     std::string result;
     try {
-        select_device();
         Json j;
         std::string err;
         if (!json_parse((const char *)params.data, (size_t)params.len, j, err)) panic_err();   // *json.SyntaxError -> {"Offset":n}; offsets are not reproduced
@@ -370,14 +464,22 @@ void Free(void *pointer) { free(pointer); }
 
 void ZkpAllowUnpinnedKeys(int allow) { g_allow_unpinned = allow != 0; }
 int ZkpSetDevice(int device) {
-    g_device = device;
-    return hipSetDevice(device) == hipSuccess ? 0 : -1;
+    if (device < 0 || device >= visible_devices()) return -1;
+    set_default_device(device);
+    try { bind_device(device); } catch (const std::exception &) { return -1; }
+    return 0;
+}
+int ZkpDeviceReplicas(int algorithmID) {
+    if (algorithmID < 0 || algorithmID >= 3) return 0;
+    return (int)get_replicas(algorithmID).size();
 }
 void ZkpReset(void) {
     for (auto &s : g_slots) {
         std::lock_guard<std::mutex> lk(s.lock);
-        s.alg.reset();
+        s.replicas.clear();
     }
+    std::lock_guard<std::mutex> lk(g_dev_lock);
+    g_device_list.clear();                  // ZKPROVE_DEVICES / ZkpSetDevice are read again by the next InitAlgorithm
 }
 
 unsigned char InitAlgorithm(unsigned char algorithmID, GoSlice provingKey, GoSlice r1cs) {
@@ -386,10 +488,9 @@ unsigned char InitAlgorithm(unsigned char algorithmID, GoSlice provingKey, GoSli
         return 0;
     }
     try {
-        select_device();
         Slot &slot = g_slots[algorithmID];
         std::lock_guard<std::mutex> lk(slot.lock);
-        if (slot.alg) return 1;                                                    // library.go:92-94
+        if (!slot.replicas.empty()) return 1;                                      // library.go:92-94
         const AlgInfo &ai = ALGS[algorithmID];
         uint8_t h[32];
         sha256((const uint8_t *)provingKey.data, (size_t)provingKey.len, h);
@@ -402,9 +503,32 @@ unsigned char InitAlgorithm(unsigned char algorithmID, GoSlice provingKey, GoSli
             printf("circuit hash mismatch, expected %s, got %s\n", ai.circuit_hash, hex_encode(h, 32).c_str());   // library.go:115-117
             return 0;
         }
-        std::unique_ptr<Algorithm> a(new Algorithm());
-        a->load((const uint8_t *)provingKey.data, (size_t)provingKey.len, (const uint8_t *)r1cs.data, (size_t)r1cs.len);
-        slot.alg = std::move(a);
+        // one replica per device, loaded concurrently (each thread binds its device); a device other than the first that cannot
+        // take the key (out of memory, busy) is left out with a warning -- the first one failing fails the call
+        const std::vector<int> devs = device_list();
+        std::vector<std::unique_ptr<Algorithm>> reps(devs.size());
+        std::vector<std::string> fail(devs.size());
+        auto load = [&](size_t k) {
+            try {
+                std::unique_ptr<Algorithm> a(new Algorithm());
+                a->device = devs[k];
+                a->load((const uint8_t *)provingKey.data, (size_t)provingKey.len, (const uint8_t *)r1cs.data, (size_t)r1cs.len);
+                reps[k] = std::move(a);
+            } catch (const std::exception &e) {
+                fail[k] = e.what();
+            } catch (...) {
+                fail[k] = "unknown error";
+            }
+        };
+        std::vector<std::thread> th;
+        for (size_t k = 1; k < devs.size(); k++) th.emplace_back(load, k);
+        load(0);
+        for (auto &t : th) t.join();
+        if (!reps[0]) throw ZkError(fail[0]);
+        for (size_t k = 0; k < devs.size(); k++) {
+            if (reps[k]) slot.replicas.push_back(std::move(reps[k]));
+            else fprintf(stderr, "zkprove: %s not replicated on device %d: %s\n", ai.name, devs[k], fail[k].c_str());
+        }
         printf("Initialized %s\n", ai.name);                                        // library.go:129
         return 1;
     } catch (const std::exception &e) {
@@ -426,7 +550,6 @@ ProveReturn ZkpProveDeterministic(GoSlice params, const uint8_t *r32, const uint
 ProveReturn ProveBatch(GoSlice params) {
     std::string result;
     try {
-        select_device();
         Json j;
         std::string err;
         if (!json_parse((const char *)params.data, (size_t)params.len, j, err) || j.t != Json::ARR) panic_err();
@@ -466,6 +589,9 @@ ProveReturn ProveBatch(GoSlice params) {
 
 ProveReturn GenerateOPRFRequestData(GoSlice) { return make_return(json_quote("toprf is not supported by libzkprove")); }
 ProveReturn TOPRFFinalize(GoSlice) { return make_return(json_quote("toprf is not supported by libzkprove")); }
+// libverify.go:28-64 -- the unchanged loader binds both from libverify (js/src/gnark/utils.ts:89-90), so they must resolve
+ProveReturn OPRFEvaluate(GoSlice) { return make_return(json_quote("toprf is not supported by libzkprove")); }
+ProveReturn GenerateThresholdKeys(GoSlice) { return make_return(json_quote("toprf is not supported by libzkprove")); }
 
 // ------------------------------------------------------------------------------ bench / debug
 long zkp_n_inputs(int id) {

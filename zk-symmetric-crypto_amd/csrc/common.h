@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <atomic>
 #include <stdexcept>
 #include <string>
 
@@ -58,5 +59,29 @@ struct DevBuf {
 };
 
 static inline unsigned ceil_div(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+// ---- device binding ------------------------------------------------------------------------------------------
+// hipSetDevice is per THREAD.  Every exported entry point and every worker thread binds the device it is about to
+// use before its first HIP call (cabi.cpp); nothing relies on a binding made earlier by another thread.
+// default_device(): the process-wide choice -- ZkpSetDevice(k), else LOCAL_RANK (one process per GPU under
+// torchrun), else 0.
+int default_device();
+void set_default_device(int dev);
+void bind_device(int dev);                       // throws ZkError
+inline void bind_default_device() { bind_device(default_device()); }
+
+// hipFuncSetAttribute is per device: run fn the first time each device passes through
+struct PerDeviceOnce {
+    std::atomic<uint64_t> done{0};
+    template <class Fn>
+    void run(Fn fn) {
+        int d = 0;
+        ZK_HIP(hipGetDevice(&d));
+        const uint64_t bit = 1ull << (d & 63);
+        if (done.load(std::memory_order_acquire) & bit) return;
+        fn();                                    // idempotent: a racing second call is harmless
+        done.fetch_or(bit, std::memory_order_release);
+    }
+};
 
 }  // namespace zk

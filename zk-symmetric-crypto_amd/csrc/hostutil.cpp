@@ -1,4 +1,5 @@
 #include "hostutil.h"
+#include <mutex>
 #include <stdio.h>
 #include <string.h>
 #include <cmath>
@@ -284,10 +285,9 @@ void chacha20_block(const uint8_t key[32], uint32_t counter, const uint8_t nonce
 
 // ---------------------------------------------------------------------------------------- AES
 static uint8_t SBOX[256];
-static bool sbox_ready = false;
+static std::once_flag sbox_once;       // aes_encrypt_block runs on up to 16 host threads (ProveBatch) and in concurrent Prove calls
 static inline uint8_t xt(uint8_t a) { return (uint8_t)((a << 1) ^ ((a & 0x80) ? 0x1B : 0)); }
-static void sbox_init() {
-    if (sbox_ready) return;
+static void sbox_fill() {
     // multiplicative inverse via log tables over generator 3
     uint8_t exp[256], lg[256];
     uint8_t x = 1;
@@ -298,8 +298,8 @@ static void sbox_init() {
         for (int k = 0; k < 4; k++) { r = (uint8_t)((r << 1) | (r >> 7)); s ^= r; }
         SBOX[a] = s ^ 0x63;
     }
-    sbox_ready = true;
 }
+static void sbox_init() { std::call_once(sbox_once, sbox_fill); }
 void aes_encrypt_block(const uint8_t *key, size_t key_len, const uint8_t in[16], uint8_t out[16]) {
     sbox_init();
     const int nk = (int)key_len / 4, nr = nk + 6;

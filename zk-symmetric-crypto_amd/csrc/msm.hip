@@ -652,6 +652,12 @@ struct SumsSel<Fp> { static G1XYZZ *get(MsmScratch &s) { return s.sums1.p; } sta
 template <>
 struct SumsSel<Fp2> { static G2XYZZ *get(MsmScratch &s) { return s.sums2.p; } static size_t cap(MsmScratch &s) { return s.sums2.n; } };
 
+// the dynamic-LDS limit of a kernel is a per-device attribute
+static void partition_attr() {
+    static PerDeviceOnce once;
+    once.run([] { ZK_HIP(hipFuncSetAttribute((const void *)k_msm_partition, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)); });
+}
+
 // Dense two-level path of a small batch, every instance split into `split` virtual instances (G1 only).
 template <class F>
 static void msm_dense_split(const MsmBases<F> &mb, const Fr *scalars, size_t B, MsmScratch &sc, XYZZ<F> *out, hipStream_t s, hipEvent_t *seg_events,
@@ -667,9 +673,8 @@ static void msm_dense_split(const MsmBases<F> &mb, const Fr *scalars, size_t B, 
         if (sc.entries.n < Bv * max_entries + 1 || sc.entries2.n < Bv * max_entries + 1 || sc.bucket_start.n < Bv * (nb + 1) ||
             PartSel<F>::cap(sc) < Bv * stride + 1 || SumsSel<F>::cap(sc) < Bv * (size_t)nb || sc.coarse_base.n < Bv * (MAX_COARSE + 1) || sc.vout1.n < Bv)
             throw ZkError("msm scratch too small for the split dense path");
-        static bool attr2 = false;
         const size_t lds2 = (size_t)(PART_THREADS / 64 * MAX_COARSE + (MAX_COARSE + 1) + 3 * MAX_COARSE + 2 * PART_THREADS * (size_t)W) * sizeof(uint32_t);
-        if (!attr2) { ZK_HIP(hipFuncSetAttribute((const void *)k_msm_partition, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)); attr2 = true; }
+        partition_attr();
         hipLaunchKernelGGL(k_msm_partition, dim3((unsigned)Bv), dim3(PART_THREADS), lds2, s, scalars, mb.dense_stride, nv, c, W, sc.coarse_base.p,
                            sc.entries2.p, max_entries, split);
         hipLaunchKernelGGL(k_msm_binsort, dim3(1u << (c - 1 - FINE_BITS), (unsigned)Bv), dim3(256), 0, s, sc.coarse_base.p, sc.entries2.p, sc.entries.p,
@@ -720,12 +725,11 @@ static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, M
         return;
     }
     size_t lds = (size_t)(nb + SORT_THREADS) * sizeof(uint32_t);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    attr_set.run([] {
         ZK_HIP(hipFuncSetAttribute((const void *)k_msm_sort<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
         ZK_HIP(hipFuncSetAttribute((const void *)k_msm_sort<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
-        attr_set = true;
-    }
+    });
     if (mb.dense) {
         // scalars = instance-major [B][dense_stride] copy; no +-1 fast path (every quotient coefficient is wide)
         if (c - 1 > FINE_BITS && c - 1 - FINE_BITS <= 8 && W <= 24 && n * (size_t)W <= (1u << 21) && sc.entries2.n >= B * max_entries + 1) {
@@ -739,9 +743,8 @@ static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, M
                 return;
             }
             ZK_HIP(hipMemsetAsync(part, 0, B * stride * sizeof(XYZZ<F>), s));
-            static bool attr2 = false;
             const size_t lds2 = (size_t)(PART_THREADS / 64 * MAX_COARSE + (MAX_COARSE + 1) + 3 * MAX_COARSE + 2 * PART_THREADS * (size_t)W) * sizeof(uint32_t);
-            if (!attr2) { ZK_HIP(hipFuncSetAttribute((const void *)k_msm_partition, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)); attr2 = true; }
+            partition_attr();
             sc.coarse_base.ensure(B * (MAX_COARSE + 1));
             hipLaunchKernelGGL(k_msm_partition, dim3((unsigned)B), dim3(PART_THREADS), lds2, s, scalars, mb.dense_stride, n, c, W, sc.coarse_base.p,
                                sc.entries2.p, max_entries, 1u);

@@ -331,16 +331,16 @@ __global__ __launch_bounds__(256) void k_ntt_dit_lds(Fr *__restrict__ data, size
 template <int K1, int K2>
 static void launch_dif_lds(Fr *data, size_t B, int logn, int loglen, const Fr *tw, const Fr *postmul, hipStream_t s) {
     using T = LdsTile<K1, K2>;
-    static bool attr = false;
-    if (!attr) { ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_dif_lds<K1, K2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr = true; }
+    static PerDeviceOnce attr;
+    attr.run([] { ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_dif_lds<K1, K2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); });
     dim3 grid((unsigned)(((size_t)1 << logn) >> T::K), ceil_div(B, T::TI));
     hipLaunchKernelGGL((k_ntt_dif_lds<K1, K2>), grid, dim3(256), 65536, s, data, B, logn, loglen, tw, postmul);
 }
 template <int K1, int K2>
 static void launch_dit_lds(Fr *data, size_t B, int logn, int logS, const Fr *tw, const Fr *premul, hipStream_t s) {
     using T = LdsTile<K1, K2>;
-    static bool attr = false;
-    if (!attr) { ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_dit_lds<K1, K2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr = true; }
+    static PerDeviceOnce attr;
+    attr.run([] { ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_dit_lds<K1, K2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); });
     dim3 grid((unsigned)(((size_t)1 << logn) >> T::K), ceil_div(B, T::TI));
     hipLaunchKernelGGL((k_ntt_dit_lds<K1, K2>), grid, dim3(256), 65536, s, data, B, logn, logS, tw, premul);
 }

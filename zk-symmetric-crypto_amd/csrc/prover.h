@@ -41,6 +41,7 @@ class Algorithm {
     NttDomain dom;
     bool has_commit = false;
     size_t commit_level = 0;
+    int device = 0;          // the HIP device that holds this replica's key and buffers; every entry below binds it on the calling thread
 
     // throws ZkError
     void load(const uint8_t *pk_bytes, size_t pk_len, const uint8_t *r1cs_bytes, size_t r1cs_len);

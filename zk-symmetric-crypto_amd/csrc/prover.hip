@@ -126,6 +126,7 @@ struct Algorithm::Resident {
 
 Algorithm::Algorithm() {}
 Algorithm::~Algorithm() {
+    (void)hipSetDevice(device);
     if (res) {
         for (auto &e : res->ev) if (e) (void)hipEventDestroy(e);
         for (auto &st : res->set) for (hipEvent_t e : {st.solved, st.consumed, st.uploaded, st.t0, st.t1, st.t2, st.t3}) if (e) (void)hipEventDestroy(e);
@@ -137,6 +138,7 @@ Algorithm::~Algorithm() {
 }
 
 void Algorithm::load(const uint8_t *pkb, size_t pk_len, const uint8_t *r1cs_bytes, size_t r1cs_len) {
+    bind_device(device);
     r1cs_parse(r1cs_bytes, r1cs_len, cs);
     hipStream_t st = 0;
     prog.build(cs, st);
@@ -324,6 +326,7 @@ __global__ void k_store_commit(const G1Affine *com, const G1Affine *pok, ProofPo
 
 // ------------------------------------------------------------------------------- pipeline
 void Algorithm::resident_reserve(size_t B) {
+    bind_device(device);
     if (!res) {
         res.reset(new Resident());
         // the solve stage and the proof tail are chains of small latency-bound kernels: on high-priority streams they slip in
@@ -553,6 +556,7 @@ void Algorithm::collect_times(SolveSet &S, PhaseTimes *times) {
 }
 
 void Algorithm::resident_prove(PhaseTimes *times) {
+    bind_device(device);
     Resident &R = *res;
     hipStream_t st = R.stream;
     R.last_set = 0;
@@ -590,6 +594,7 @@ void Algorithm::ensure_second_set() {
 // nsteps batches back to back (the same resident inputs are re-proved each time), the SOLVE stage of batch k+1 overlapped
 // with the NTT + MSM stage of batch k.  times (optional) = phase times of the LAST batch; total = whole call / nsteps.
 void Algorithm::resident_prove_pipelined(int nsteps, PhaseTimes *times) {
+    bind_device(device);
     Resident &R = *res;
     if (nsteps <= 0) return;
     ensure_second_set();
@@ -627,6 +632,7 @@ void Algorithm::resident_prove_pipelined(int nsteps, PhaseTimes *times) {
 }
 
 void Algorithm::resident_download(ProofPoints *out, uint32_t *errs) {
+    bind_device(device);
     Resident &R = *res;
     SolveSet &S = R.set[R.last_set];
     ZK_HIP(hipMemcpy(out, S.out.p, R.B * sizeof(ProofPoints), hipMemcpyDeviceToHost));
@@ -639,6 +645,7 @@ void Algorithm::resident_download(ProofPoints *out, uint32_t *errs) {
 void Algorithm::prove_batch(size_t batch, const uint32_t *inputs, const U256 *r, const U256 *s, const U256 *randomize, ProofPoints *out,
                             uint32_t *errs, PhaseTimes *times) {
     std::lock_guard<std::mutex> lk(mu);
+    bind_device(device);
     const size_t ni = prog.n_inputs;
     const size_t nchunks = (batch + max_chunk - 1) / max_chunk;
     if (nchunks <= 1) {
@@ -700,6 +707,7 @@ void Algorithm::prove_batch(size_t batch, const uint32_t *inputs, const U256 *r,
 // parity-test hook: solved wires and quotient-stage products (A*B on the coset g<w>, natural order) of the last resident
 // batch, canonical form
 void Algorithm::debug_fetch(uint8_t *wires_out, uint8_t *h_out) {
+    bind_device(device);
     Resident &R = *res;
     const size_t B = R.B, nw = prog.n_wires, N = (size_t)1 << prog.log_domain;
     std::vector<Fr> tmp;

@@ -300,6 +300,7 @@ void groth16_setup(const uint8_t *r1cs_bytes, size_t r1cs_len, const uint8_t *to
 
 extern "C" int ZkpSetup(GoSlice r1cs, const uint8_t *toxic192, int raw, void **pk_out, long long *pk_len, void **vk_out, long long *vk_len) {
     try {
+        zk::bind_default_device();
         std::vector<uint8_t> pk, vk;
         zk::groth16_setup((const uint8_t *)r1cs.data, (size_t)r1cs.len, toxic192, raw != 0, pk, vk);
         *pk_out = malloc(pk.size()); memcpy(*pk_out, pk.data(), pk.size()); *pk_len = (long long)pk.size();

@@ -13,7 +13,7 @@ void fp_to_mont_dev(void *p, size_t count, hipStream_t s);
 static thread_local std::string g_last_error;
 extern "C" const char *zkp_last_error(void) { return g_last_error.c_str(); }
 
-#define ZKP_TRY try {
+#define ZKP_TRY try { zk::bind_default_device();
 #define ZKP_CATCH(rv)                         \
     }                                         \
     catch (const std::exception &e) {         \

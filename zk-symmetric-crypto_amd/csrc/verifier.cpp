@@ -174,6 +174,12 @@ struct Cur {
             r = G2Affine{x, y}; pos += 64;
         }
         if (!g2_on_curve(r)) throw ZkError("G2 point not on curve");
+        // the twist has cofactor 2p - r: gnark-crypto's G2Affine.SetBytes (proof.ReadFrom, the embedded vk) also rejects points
+        // outside the order-r subgroup, and the Miller loop below is only a pairing on it
+        if (!r.is_inf()) {
+            U256 rr = FR_MODULUS;
+            if (!scalar_mul(r, rr.l, 254).is_inf()) throw ZkError("G2 point not in the order-r subgroup");
+        }
         return r;
     }
 };
