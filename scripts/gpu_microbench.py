@@ -1,10 +1,20 @@
-"""Raw device throughput of the BN254 building blocks (run on the GPU box)."""
-import importlib, sys, os
+"""Raw device throughput of the BN254 building blocks (run on the GPU box).  Prints a table and, with an argument, writes the
+best rates as JSON (profiles/<tag>_microbench.json; bench.py reads the file profiles/current.json names)."""
+import importlib, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 zk = importlib.import_module("zk-symmetric-crypto_amd")
-for kind, name, per_iter in ((0, "Fp mul", 2), (1, "G1 madd", 1), (2, "G2 madd", 1)):
+best = {}
+for kind, name, per_iter, iters in ((0, "fp_mul", 2, 2000), (1, "g1_mixed_add", 1, 400), (2, "g2_mixed_add", 1, 150), (3, "fp_inv_fermat", 1, 4), (4, "fp_inv_gcd", 1, 16)):
     for threads in (256 * 256 * 4, 256 * 256 * 8, 256 * 256 * 16):
-        iters = 2000 if kind == 0 else (400 if kind == 1 else 150)
         ms = zk.lib.zkp_microbench(kind, threads, iters)
         ops = threads * iters * per_iter
-        print("%-8s threads=%8d iters=%5d  %8.3f ms  %8.2f Gop/s" % (name, threads, iters, ms, ops / ms / 1e6), flush=True)
+        rate = ops / ms * 1e3
+        best[name] = max(best.get(name, 0.0), rate)
+        print("%-14s threads=%8d iters=%5d  %8.3f ms  %9.3f Gop/s" % (name, threads, iters, ms, rate / 1e9), flush=True)
+out = {"fp_mul_per_s": best["fp_mul"], "g1_mixed_add_per_s": best["g1_mixed_add"], "g2_mixed_add_per_s": best["g2_mixed_add"],
+       "fp_inv_fermat_per_s": best["fp_inv_fermat"], "fp_inv_gcd_per_s": best["fp_inv_gcd"],
+       "inv_gcd_cost_in_fp_mul": best["fp_mul"] / best["fp_inv_gcd"], "inv_fermat_cost_in_fp_mul": best["fp_mul"] / best["fp_inv_fermat"],
+       "note": "zkp_microbench (csrc/test_api.hip): back-to-back dependent operations per thread, best of 4/8/16 wavefronts per SIMD worth of threads"}
+print(json.dumps(out))
+if len(sys.argv) > 1:
+    json.dump(out, open(sys.argv[1], "w"), indent=1)

@@ -2,6 +2,7 @@
 import numpy as np
 import pytest
 
+from oracle import gnark_format as gf
 from oracle import r1cs_format as rf
 
 R = rf.R_MOD
@@ -224,3 +225,20 @@ def test_full_size_ntt_round_trip_and_linearity(zk):
     for i in range(0, n, 1231):
         lhs = (int.from_bytes(y[0, i].tobytes(), "little") + int.from_bytes(y[1, i].tobytes(), "little")) % R
         assert lhs == int.from_bytes(tot[0, i].tobytes(), "little")
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_field_inversion_binary_gcd_matches_modular_inverse(zk, field):
+    """Field::inv_gcd (field.cuh): the shared inversion of the affine bucket additions.  Device result == pow(x, -1, m) for edge
+    values (0 -> 0, 1, m - 1, powers of two, values around 2^253) and random elements of Fp / Fr."""
+    m = gf.P if field == 0 else rf.R_MOD
+    rng = np.random.default_rng(77 + field)
+    vals = [0, 1, 2, 3, m - 1, m - 2, (m - 1) // 2, 1 << 253, (1 << 253) + 1, (1 << 62) - 1, 1 << 62, (1 << 30) + 1]
+    vals += [1 << k for k in range(0, 254, 13)]
+    vals += [int.from_bytes(rng.bytes(32), "little") % m for _ in range(4000)]
+    buf = np.frombuffer(b"".join(v.to_bytes(32, "little") for v in vals), np.uint8).copy()
+    out = np.zeros_like(buf)
+    assert zk.lib.zkp_field_inv(field, len(vals), buf.ctypes.data, out.ctypes.data) == 0
+    got = [int.from_bytes(out[32 * i:32 * i + 32].tobytes(), "little") for i in range(len(vals))]
+    exp = [pow(v, -1, m) if v else 0 for v in vals]
+    assert got == exp

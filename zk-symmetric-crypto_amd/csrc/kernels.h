@@ -63,6 +63,11 @@ struct MsmScratch {
     DevBuf<uint32_t> entries2, coarse_base;   // dense two-level sort: partitioned entries, per-instance coarse bin offsets
     DevBuf<G1XYZZ> vout1;                     // results of the virtual instances of a split small-batch dense MSM
     void reserve_dense(size_t B, size_t max_dense_entries);
+    // affine reduction tree (msm_tree.cuh): ping-pong layouts, final bucket points, per-wavefront prefix-product rows
+    DevBuf<G1Affine> treeA1, treeB1, fin1;
+    DevBuf<uint8_t> tree_scratch;
+    size_t tree_capA = 0, tree_capB = 0;
+    void reserve_tree(size_t B, size_t max_entries, size_t nb);
 };
 
 // out[b] (+)= sum_j scalars[row_j][b] * P_j for b in [0,B).  scalars: [rows][B] Fr Montgomery.

@@ -21,7 +21,9 @@
 //   * k_sum_groups folds the per-chunk / per-segment partial sums.
 // Results are group elements; any correct schedule yields the same affine point, which is what the
 // parity tests compare bit-for-bit with the oracle.
+#include <algorithm>
 #include "kernels.h"
+#include "msm_tree.cuh"
 
 namespace zk {
 
@@ -116,6 +118,27 @@ void MsmScratch::reserve_dense(size_t B_, size_t max_dense_entries) {
     entries2.ensure(B_ * max_dense_entries + 1);
     coarse_base.ensure((B_ > VIRT_MIN ? B_ : VIRT_MIN) * 257);
     vout1.ensure(VIRT_MIN + 1);
+}
+// lanes per instance of the accumulation kernels: ~2048 entries per lane at the worst case (all scalars wide); 2048 measured best
+// at B = 1024 (among 512..4096); small batches (a single Prove() call) cut the list finer so that the launch still has ~256k threads
+static uint32_t accumulate_lanes(size_t max_entries, size_t B) {
+    size_t piece = 2048;
+    while (piece > 64 && (max_entries * B) / piece < 262144) piece >>= 1;
+    const uint32_t nlanes = (uint32_t)((max_entries + piece - 1) / piece);
+    return nlanes < 1 ? 1 : nlanes;
+}
+void MsmScratch::reserve_tree(size_t B_, size_t max_entries, size_t nb) {
+    const size_t Bm = B_ > VIRT_MIN ? B_ : VIRT_MIN;
+    tree_capA = (max_entries + nb) / 2 + 2;
+    tree_capB = (tree_capA + nb) / 2 + 2;
+    treeA1.ensure(Bm * tree_capA);
+    treeB1.ensure(Bm * tree_capB);
+    fin1.ensure(Bm * nb);
+    // the finest cut any batch size uses decides the wavefront count
+    size_t waves = 0;
+    for (size_t b = 1; b <= Bm; b <<= 1) waves = std::max(waves, (size_t)ceil_div((size_t)accumulate_lanes(max_entries, b) * b, 64));
+    waves = std::max(waves, (size_t)ceil_div((size_t)accumulate_lanes(max_entries, Bm) * Bm, 64));
+    tree_scratch.ensure((waves + 1) * TREE_CH * 64 * tree_slot_bytes<Fp>());
 }
 void MsmScratch::reserve_compact(size_t B_, size_t max_sparse_n) {
     gen_count.ensure(B_ + 1);
@@ -638,6 +661,30 @@ __global__ __launch_bounds__(64) void k_sum_groups(const XYZZ<F> *__restrict__ i
     out[b * out_stride + g] = acc;
 }
 
+// Dense (quotient) MSM: affine reduction tree (msm_tree.cuh) instead of the extended-Jacobian walk; ZKPROVE_MSM_TREE=0 selects
+// the older kernel (kept for the A/B measurement in profiles/ and as the path of G2 and of the sparse MSMs)
+static bool tree_enabled() {
+    static const bool on = [] { const char *e = getenv("ZKPROVE_MSM_TREE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+// accumulate + bucket reduction of one sorted dense MSM through the tree kernels (G1)
+static void launch_tree_g1(const MsmBasesG1 &mb, MsmScratch &sc, size_t max_entries, int c, size_t Bv, uint32_t nlanes, G1XYZZ *part, size_t stride,
+                           size_t part_off, uint32_t L, hipStream_t s, hipEvent_t *seg_events) {
+    const uint32_t nb = 1u << (c - 1);
+    const size_t nseg = nb / L;
+    const size_t capA = (max_entries + nb) / 2 + 2, capB = (capA + nb) / 2 + 2;
+    const unsigned grid = ceil_div((size_t)nlanes * Bv, 64);
+    if (sc.treeA1.n < Bv * capA || sc.treeB1.n < Bv * capB || sc.fin1.n < Bv * (size_t)nb ||
+        sc.tree_scratch.n < (size_t)grid * TREE_CH * 64 * tree_slot_bytes<Fp>())
+        throw ZkError("msm tree scratch too small");
+    if (seg_events) ZK_HIP(hipEventRecord(seg_events[0], s));
+    hipLaunchKernelGGL((k_msm_tree<Fp, true>), dim3(grid), dim3(64), 0, s, mb.table.p, sc.bucket_start.p, sc.entries.p, max_entries, c, Bv, nlanes,
+                       sc.treeA1.p, capA, sc.treeB1.p, capB, sc.fin1.p, sc.tree_scratch.p);
+    if (seg_events) ZK_HIP(hipEventRecord(seg_events[1], s));
+    hipLaunchKernelGGL(k_msm_bucket_reduce_tree<Fp>, dim3(ceil_div(nseg * Bv, 64)), dim3(64), 0, s, sc.fin1.p, mb.table.p, sc.entries.p, max_entries,
+                       sc.bucket_start.p, c, Bv, part, stride, part_off, L);
+}
+
 template <class F>
 struct PartSel;
 template <>
@@ -679,15 +726,16 @@ static void msm_dense_split(const MsmBases<F> &mb, const Fr *scalars, size_t B, 
                            sc.entries2.p, max_entries, split);
         hipLaunchKernelGGL(k_msm_binsort, dim3(1u << (c - 1 - FINE_BITS), (unsigned)Bv), dim3(256), 0, s, sc.coarse_base.p, sc.entries2.p, sc.entries.p,
                            max_entries, c, sc.bucket_start.p);
-        size_t piece = 2048;
-        while (piece > 64 && (max_entries * Bv) / piece < 262144) piece >>= 1;
-        uint32_t nlanes = (uint32_t)((max_entries + piece - 1) / piece);
-        if (nlanes < 1) nlanes = 1;
-        if (seg_events) ZK_HIP(hipEventRecord(seg_events[0], s));
-        hipLaunchKernelGGL((k_msm_accumulate<F, true>), dim3(ceil_div((size_t)nlanes * Bv, 64)), dim3(64), 0, s, mb.table.p, sc.bucket_start.p, sc.entries.p,
-                           max_entries, c, Bv, nlanes, sums);
-        if (seg_events) ZK_HIP(hipEventRecord(seg_events[1], s));
-        hipLaunchKernelGGL(k_msm_bucket_reduce<F>, dim3(ceil_div(nseg * Bv, 64)), dim3(64), 0, s, sums, sc.bucket_start.p, c, Bv, part, stride, (size_t)0, L);
+        const uint32_t nlanes = accumulate_lanes(max_entries, Bv);
+        if (tree_enabled() && sc.treeA1.n) {
+            launch_tree_g1(mb, sc, max_entries, c, Bv, nlanes, part, stride, (size_t)0, L, s, seg_events);
+        } else {
+            if (seg_events) ZK_HIP(hipEventRecord(seg_events[0], s));
+            hipLaunchKernelGGL((k_msm_accumulate<F, true>), dim3(ceil_div((size_t)nlanes * Bv, 64)), dim3(64), 0, s, mb.table.p, sc.bucket_start.p, sc.entries.p,
+                               max_entries, c, Bv, nlanes, sums);
+            if (seg_events) ZK_HIP(hipEventRecord(seg_events[1], s));
+            hipLaunchKernelGGL(k_msm_bucket_reduce<F>, dim3(ceil_div(nseg * Bv, 64)), dim3(64), 0, s, sums, sc.bucket_start.p, c, Bv, part, stride, (size_t)0, L);
+        }
         size_t off = 0, cnt = npart;
         do {
             const size_t groups = (cnt + FOLD_GROUP - 1) / FOLD_GROUP;
@@ -704,6 +752,21 @@ static void msm_dense_split(const MsmBases<F> &mb, const Fr *scalars, size_t B, 
         (void)mb; (void)scalars; (void)B; (void)sc; (void)out; (void)s; (void)seg_events; (void)split;
         throw ZkError("split dense path is G1 only");
     }
+}
+
+// fold the npart partial sums of every instance, FOLD_GROUP at a time; the last level writes out[b]
+template <class F>
+static void msm_fold_parts(XYZZ<F> *part, size_t stride, size_t npart, XYZZ<F> *out, size_t B, hipStream_t s) {
+    size_t off = 0, cnt = npart;
+    do {
+        const size_t groups = (cnt + FOLD_GROUP - 1) / FOLD_GROUP;
+        const bool last = groups == 1;
+        hipLaunchKernelGGL(k_sum_groups<F>, dim3(ceil_div(groups * B, 64)), dim3(64), 0, s, part + off, stride, cnt, FOLD_GROUP,
+                           last ? out : part + off + cnt, last ? (size_t)1 : stride, B);
+        off += cnt;
+        cnt = groups;
+    } while (cnt > 1);
+    ZK_HIP(hipGetLastError());
 }
 
 template <class F>
@@ -763,13 +826,14 @@ static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, M
         hipLaunchKernelGGL(k_msm_sort<false>, dim3((unsigned)B), dim3(SORT_THREADS), lds, s, (const Fr *)nullptr, (size_t)0, sc.gen_count.p, sc.gen_idx.p,
                            sc.gen_val.p, n, c, W, sc.bucket_start.p, sc.entries.p, max_entries);
     }
-    // lanes per instance for the accumulate kernel: ~2048 entries per lane at the worst case (all scalars wide)
-    // 2048 entries per thread measured best at B = 1024 (among 512..4096); small batches (a single Prove() call) cut the
-    // list finer so that the launch still has ~256k threads
-    size_t piece = 2048;
-    while (piece > 64 && (max_entries * B) / piece < 262144) piece >>= 1;
-    uint32_t nlanes = (uint32_t)((max_entries + piece - 1) / piece);
-    if (nlanes < 1) nlanes = 1;
+    const uint32_t nlanes = accumulate_lanes(max_entries, B);
+    if constexpr (sizeof(F) == 32) {
+        if (mb.dense && tree_enabled() && sc.treeA1.n) {
+            launch_tree_g1(mb, sc, max_entries, c, B, nlanes, part, stride, nchunks, L, s, seg_events);
+            msm_fold_parts<F>(part, stride, npart, out, B, s);
+            return;
+        }
+    }
     XYZZ<F> *sums = SumsSel<F>::get(sc);
     if (SumsSel<F>::cap(sc) < B * (size_t)nb) throw ZkError("msm bucket-sum scratch too small");
     if (seg_events) ZK_HIP(hipEventRecord(seg_events[0], s));
@@ -781,17 +845,7 @@ static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, M
                            max_entries, c, B, nlanes, sums);
     if (seg_events) ZK_HIP(hipEventRecord(seg_events[1], s));
     hipLaunchKernelGGL(k_msm_bucket_reduce<F>, dim3(ceil_div(nseg * B, 64)), dim3(64), 0, s, sums, sc.bucket_start.p, c, B, part, stride, nchunks, L);
-    // fold the npart partial sums of every instance, FOLD_GROUP at a time; the last level writes out[b]
-    size_t off = 0, cnt = npart;
-    do {
-        const size_t groups = (cnt + FOLD_GROUP - 1) / FOLD_GROUP;
-        const bool last = groups == 1;
-        hipLaunchKernelGGL(k_sum_groups<F>, dim3(ceil_div(groups * B, 64)), dim3(64), 0, s, part + off, stride, cnt, FOLD_GROUP,
-                           last ? out : part + off + cnt, last ? (size_t)1 : stride, B);
-        off += cnt;
-        cnt = groups;
-    } while (cnt > 1);
-    ZK_HIP(hipGetLastError());
+    msm_fold_parts<F>(part, stride, npart, out, B, s);
 }
 void msm_batch(const MsmBasesG1 &mb, const Fr *sc, size_t B, MsmScratch &scr, G1XYZZ *out, hipStream_t s, hipEvent_t *ev) { msm_batch_impl<Fp>(mb, sc, B, scr, out, s, ev); }
 void msm_batch(const MsmBasesG2 &mb, const Fr *sc, size_t B, MsmScratch &scr, G2XYZZ *out, hipStream_t s) { msm_batch_impl<Fp2>(mb, sc, B, scr, out, s, nullptr); }

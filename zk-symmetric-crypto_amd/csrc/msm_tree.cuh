@@ -1,0 +1,277 @@
+// Bucket accumulation with AFFINE additions that share one field inversion ("batch-affine"), as a pairwise reduction tree.
+//
+// Replaces gnark-crypto v0.19.2 ecc/bn254 processChunkG1BatchAffine / batchAddG1Affine (multiexp_affine.go; the 350- and
+// 400-point batches in the reference's default.pgo): affine + affine costs 5 multiplications, 1 squaring
+// and a share of one inversion (Montgomery's trick) instead of the 8 + 2 of an extended-Jacobian mixed addition.
+//
+// MI355X formulation.  Input is the bucket-sorted entry list of an instance (k_msm_partition / k_msm_binsort / k_msm_sort).  One
+// thread owns one piece of it (whole buckets, ~2048 entries, exactly as k_msm_accumulate) and reduces every bucket of the piece by
+// halving rounds: round r adds the items of a bucket two by two, so a bucket of n entries is a single affine point after
+// ceil(log2 n) rounds.  All additions of one round are independent, which is what the shared inversion needs:
+//   forward  : walk the piece's pairs, multiply the running product c by the pair's denominator (x1 - x0), park the product before
+//              it and the pair's descriptor in a per-wavefront HBM scratch ([slot][lane] layout: every access is one 2 KiB / 1 KiB row);
+//   invert   : ONE inversion of c per thread and chunk of <= CH pairs (Field::inv_gcd, ~50 multiplications' worth);
+//   backward : slots in reverse: 1 / den = inv * c_before, inv *= den, lambda, x3, y3, store the sum.
+// The layout of every round is a pure function of the sorted layout (bucket_start) -- nothing is scanned or compacted:
+//   start_r(k) = (start_{r-1}(k) + k) >> 1,  count_r(k) = ceil(count_{r-1}(k) / 2),  start_0 = bucket_start,
+// which keeps start_r(k+1) - start_r(k) >= count_r(k).  Round r reads layout r-1 from one buffer and writes layout r to the
+// other; a bucket's final point goes to final[k].  Threads never touch each other's buckets: no synchronisation at all.
+// Exceptional pairs (an operand at infinity, P + P, P - P, an odd item without partner) take denominator 1 and are resolved by
+// selects in the backward pass, so parity with the oracle holds for adversarial inputs too (equal scalars, infinity bases).
+#pragma once
+#include "curve.cuh"
+
+namespace zk {
+
+static constexpr uint32_t TREE_ABSENT = 0xffffffffu;
+static constexpr uint32_t TREE_FINAL = 0x80000000u;        // dst flag: the sum is the bucket's final point -> final[k]
+static constexpr int TREE_CH = 256;                        // pairs per thread between two inversions
+template <class F>
+constexpr size_t tree_slot_bytes() { return sizeof(F) + 16; }       // prefix product + descriptor, per pair and lane
+
+__device__ __forceinline__ uint32_t tree_start(uint32_t s0, uint32_t k, int r) {
+    for (int i = 0; i < r; i++) s0 = (s0 + k) >> 1;
+    return s0;
+}
+__device__ __forceinline__ uint32_t tree_count(uint32_t n0, int r) { return r >= 32 ? (n0 ? 1u : 0u) : (uint32_t)(((uint64_t)n0 + ((1ull << r) - 1)) >> r); }
+
+template <class F>
+__device__ __forceinline__ F field_inv_shared(const F &x);
+template <>
+__device__ __forceinline__ Fp field_inv_shared<Fp>(const Fp &x) { return x.inv_gcd(); }
+template <>
+__device__ __forceinline__ Fp2 field_inv_shared<Fp2>(const Fp2 &x) {
+    const Fp n = (x.a0.sqr() + x.a1.sqr()).inv_gcd();
+    return Fp2{x.a0 * n, (x.a1 * n).neg()};
+}
+
+// classification of one pair; the SAME function decides the denominator in both passes
+//   generic : distinct x, both finite -> den = x1 - x0
+//   dbl     : P + P (y != 0)          -> den = 2 y
+//   else    : den = 1 (an operand at infinity or absent, P - P)
+template <class F>
+struct PairKind { bool inf0, inf1, xeq, dbl, generic; };
+template <class F>
+__device__ __forceinline__ PairKind<F> pair_kind(const Affine<F> &p0, const Affine<F> &p1) {
+    PairKind<F> k;
+    k.inf0 = p0.is_inf(); k.inf1 = p1.is_inf();
+    k.xeq = p0.x == p1.x;
+    k.generic = !k.inf0 && !k.inf1 && !k.xeq;
+    k.dbl = !k.inf0 && !k.inf1 && k.xeq && p0.y == p1.y && !p0.y.is_zero();
+    return k;
+}
+
+// sorted-layout walker of one piece for round r: emits (src0, src1, dst) of every pair of every bucket with >= 2 items
+struct TreeWalker {
+    const uint32_t *bs;
+    uint32_t k, k_end, e0, e1;      // current bucket, its original [e0, e1)
+    uint32_t t, m, n_prev, s_in, s_out;
+    int r;
+    bool more;                       // some bucket of the piece still has >= 2 items after this round
+    __device__ __forceinline__ void init(const uint32_t *bs_, uint32_t k0, uint32_t k1, int round) {
+        bs = bs_; k = k0; k_end = k1; r = round; t = 0; m = 0; more = false;
+        if (k < k_end) { e0 = bs[k]; e1 = bs[k + 1]; enter(); }
+    }
+    __device__ __forceinline__ void enter() {         // position on the first bucket >= k that has pairs
+        while (k < k_end) {
+            const uint32_t n0 = e1 - e0;
+            n_prev = tree_count(n0, r - 1);
+            if (n_prev >= 2) {
+                m = (n_prev + 1) >> 1;
+                s_in = tree_start(e0, k, r - 1);
+                s_out = tree_start(e0, k, r);
+                t = 0;
+                more = more || m >= 2;
+                return;
+            }
+            k++;
+            if (k < k_end) { e0 = e1; e1 = bs[k + 1]; }
+        }
+        m = 0;
+    }
+    // next pair of this lane; false when the piece is exhausted
+    __device__ __forceinline__ bool next(uint32_t &src0, uint32_t &src1, uint32_t &dst) {
+        if (k >= k_end) return false;
+        src0 = s_in + 2 * t;
+        src1 = (2 * t + 1 < n_prev) ? src0 + 1 : TREE_ABSENT;
+        dst = (m == 1) ? (TREE_FINAL | k) : (s_out + t);
+        t++;
+        if (t >= m) {
+            k++;
+            if (k < k_end) { e0 = e1; e1 = bs[k + 1]; enter(); }
+        }
+        return true;
+    }
+};
+
+template <class F>
+__device__ __forceinline__ Affine<F> tree_load_entry(const Affine<F> *__restrict__ table, uint32_t v) {
+    Affine<F> p = table[v & 0x7fffffffu];
+    if (v >> 31) p.y = p.y.neg();
+    return p;
+}
+
+// One thread per piece (same cut as k_msm_accumulate).  scratch: gridDim.x * TREE_CH * 64 * tree_slot_bytes<F>() bytes.
+template <class F, bool DENSE>
+__device__ __forceinline__ void tree_body(const Affine<F> *__restrict__ table, const uint32_t *__restrict__ bucket_start, const uint32_t *__restrict__ entries,
+                                          size_t max_entries, int c, size_t B, uint32_t nlanes, Affine<F> *__restrict__ bufA, size_t capA,
+                                          Affine<F> *__restrict__ bufB, size_t capB, Affine<F> *__restrict__ fin, uint8_t *__restrict__ scratch) {
+    const uint32_t nb = 1u << (c - 1);
+    const size_t tg = (size_t)blockIdx.x * 64 + threadIdx.x;
+    const bool live = tg < (size_t)nlanes * B;
+    const size_t b = live ? tg / nlanes : 0;
+    const uint32_t lane = live ? (uint32_t)(tg % nlanes) : 0;
+    const uint32_t *bs = bucket_start + b * (nb + 1);
+    const uint32_t *ent = entries + b * max_entries;
+    uint32_t k0 = 0, k1 = 0;
+    if (live) {
+        const uint32_t total = bs[nb];
+        auto first_bucket = [&](uint32_t target) -> uint32_t {      // first bucket k with bs[k] >= target
+            uint32_t lo = 0, hi = nb;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (bs[mid] >= target) hi = mid; else lo = mid + 1;
+            }
+            return lo;
+        };
+        k0 = first_bucket((uint32_t)(((uint64_t)total * lane + nlanes - 1) / nlanes));
+        k1 = lane + 1 == nlanes ? nb : first_bucket((uint32_t)(((uint64_t)total * (lane + 1) + nlanes - 1) / nlanes));
+        if (k0 > k1) k0 = k1;
+    }
+    Affine<F> *A = bufA + b * capA, *Bf = bufB + b * capB, *out_final = fin + b * nb;
+    // per-wavefront scratch rows: [slot][lane]
+    uint8_t *wave_base = scratch + (size_t)blockIdx.x * TREE_CH * 64 * tree_slot_bytes<F>();
+    F *pref = (F *)wave_base;                                              // [TREE_CH][64]
+    uint4 *desc = (uint4 *)(wave_base + (size_t)TREE_CH * 64 * sizeof(F));  // [TREE_CH][64]
+    const int ln = threadIdx.x;
+
+    for (int r = 1; r < 40; r++) {
+        const Affine<F> *in = (r & 1) ? Bf : A;          // layout r-1 (r >= 2)
+        Affine<F> *out = (r & 1) ? A : Bf;               // layout r
+        TreeWalker w;
+        w.init(bs, k0, k1, r);
+        while (true) {
+            // ---- forward: running product of the denominators
+            F cprod = F::one();
+            int cnt = 0, i = 0;
+            for (; i < TREE_CH; i++) {
+                uint32_t s0 = 0, s1 = TREE_ABSENT, dst = 0;
+                const bool have = w.next(s0, s1, dst);
+                if (!__any(have)) break;
+                if (have) {
+                    uint32_t v0 = s0, v1 = s1;
+                    F x0, x1;
+                    const Affine<F> *q0, *q1 = nullptr;
+                    if (r == 1) {
+                        v0 = ent[s0];
+                        q0 = table + (v0 & 0x7fffffffu);
+                        if (s1 != TREE_ABSENT) { v1 = ent[s1]; q1 = table + (v1 & 0x7fffffffu); }
+                    } else {
+                        q0 = in + s0;
+                        if (s1 != TREE_ABSENT) q1 = in + s1;
+                    }
+                    x0 = q0->x;
+                    x1 = q1 ? q1->x : F::zero();
+                    F den;
+                    if (q1 && x0 != x1 && !x0.is_zero() && !x1.is_zero()) {
+                        den = x1 - x0;                           // generic: the sign of y never matters here
+                    } else {                                     // rare: look at the whole points
+                        Affine<F> p0 = *q0, p1 = q1 ? *q1 : Affine<F>::inf();
+                        if (r == 1) { if (v0 >> 31) p0.y = p0.y.neg(); if (q1 && (v1 >> 31)) p1.y = p1.y.neg(); }
+                        const PairKind<F> kd = pair_kind(p0, p1);
+                        den = kd.generic ? p1.x - p0.x : (kd.dbl ? p0.y.dbl() : F::one());
+                    }
+                    pref[(size_t)i * 64 + ln] = cprod;
+                    desc[(size_t)i * 64 + ln] = make_uint4(v0, v1, dst, 0u);
+                    cprod = cprod * den;
+                    cnt++;
+                }
+            }
+            const int used = i;                                  // wave-uniform: the longest lane
+            if (used == 0) break;
+            // ---- one inversion per thread
+            F inv = field_inv_shared<F>(cprod);
+            // ---- backward
+            for (int j = used - 1; j >= 0; j--) {
+                if (j < cnt) {
+                    const uint4 d = desc[(size_t)j * 64 + ln];
+                    const F cbefore = pref[(size_t)j * 64 + ln];
+                    const bool has1 = d.y != TREE_ABSENT;
+                    Affine<F> p0, p1 = Affine<F>::inf();
+                    if (r == 1) {
+                        p0 = tree_load_entry(table, d.x);
+                        if (has1) p1 = tree_load_entry(table, d.y);
+                    } else {
+                        p0 = in[d.x];
+                        if (has1) p1 = in[d.y];
+                    }
+                    const PairKind<F> kd = pair_kind(p0, p1);
+                    Affine<F> res;
+                    if (kd.generic || kd.dbl) {
+                        const F den = kd.generic ? p1.x - p0.x : p0.y.dbl();
+                        const F dinv = inv * cbefore;
+                        inv = inv * den;
+                        F num;
+                        if (kd.generic) num = p1.y - p0.y;
+                        else { const F xx = p0.x.sqr(); num = xx.dbl() + xx; }
+                        const F lam = num * dinv;
+                        res.x = lam.sqr() - p0.x - p1.x;
+                        res.y = lam * (p0.x - res.x) - p0.y;
+                    } else {                                     // den = 1: inv unchanged
+                        res = kd.inf0 ? p1 : (kd.inf1 ? p0 : Affine<F>::inf());
+                    }
+                    if (d.z & TREE_FINAL) out_final[d.z & ~TREE_FINAL] = res;
+                    else out[d.z] = res;
+                }
+            }
+            if (used < TREE_CH) break;                           // every lane ran out of pairs inside this chunk
+        }
+        if (!__any(w.more)) break;
+    }
+}
+
+template <class F, bool DENSE>
+__global__ __launch_bounds__(64) void k_msm_tree(const Affine<F> *__restrict__ table, const uint32_t *__restrict__ bucket_start, const uint32_t *__restrict__ entries,
+                                                 size_t max_entries, int c, size_t B, uint32_t nlanes, Affine<F> *__restrict__ bufA, size_t capA,
+                                                 Affine<F> *__restrict__ bufB, size_t capB, Affine<F> *__restrict__ fin, uint8_t *__restrict__ scratch) {
+    tree_body<F, DENSE>(table, bucket_start, entries, max_entries, c, B, nlanes, bufA, capA, bufB, capB, fin, scratch);
+}
+
+// thread (b, seg): running-sum reduction of buckets [seg*L, seg*L + L) of instance b, bucket sums as produced by k_msm_tree:
+// n0 = 0 empty, n0 = 1 the entry itself (table), n0 >= 2 final[k]
+template <class F>
+__global__ __launch_bounds__(64) void k_msm_bucket_reduce_tree(const Affine<F> *__restrict__ fin, const Affine<F> *__restrict__ table,
+                                                               const uint32_t *__restrict__ entries, size_t max_entries,
+                                                               const uint32_t *__restrict__ bucket_start, int c, size_t B, XYZZ<F> *__restrict__ part,
+                                                               size_t part_stride, size_t part_off, uint32_t L) {
+    const uint32_t nb = 1u << (c - 1);
+    const uint32_t nseg = nb / L;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)nseg * B) return;
+    const size_t b = t / nseg;
+    const uint32_t seg = (uint32_t)(t % nseg);
+    const uint32_t *bs = bucket_start + b * (nb + 1);
+    const Affine<F> *in = fin + b * nb;
+    const uint32_t *ent = entries + b * max_entries;
+    XYZZ<F> run = XYZZ<F>::inf(), tot = XYZZ<F>::inf();
+    const uint32_t s0 = seg * L;
+    uint32_t hi = bs[s0 + L];
+    for (int k = (int)L - 1; k >= 0; k--) {
+        const uint32_t lo = bs[s0 + k];
+        if (hi > lo) run.madd(hi - lo == 1 ? tree_load_entry(table, ent[lo]) : in[s0 + k]);
+        hi = lo;
+        tot.add(run);
+    }
+    // contribution = tot + s0 * run   (bucket index i carries weight i+1)
+    if (s0 != 0 && !run.is_inf()) {
+        XYZZ<F> m = XYZZ<F>::inf();
+        for (int bit = 31 - __clz(s0); bit >= 0; bit--) {
+            m = m.dbl();
+            if ((s0 >> bit) & 1) m.add(run);
+        }
+        tot.add(m);
+    }
+    part[b * part_stride + part_off + seg] = tot;
+}
+
+}  // namespace zk

@@ -359,6 +359,7 @@ void Algorithm::resident_reserve(size_t B) {
     if (has_commit) acc(pk.ped.n, pk.ped.c, pk.ped.W);
     R.ms.reserve(B, max_entries, max_nb, max_part);
     R.ms.reserve_dense(B, pk.Z.n * (size_t)pk.Z.W);
+    R.ms.reserve_tree(B, pk.Z.n * (size_t)pk.Z.W, (size_t)1 << (pk.Z.c - 1));
     R.ms.reserve_compact(B, std::max({pk.A.n, pk.B1.n, pk.K.n, pk.B2.n, has_commit ? pk.ped.n : (size_t)1}));
     {
         const size_t Bs = std::min(B, SIDE_G2_MAX_B);

@@ -9,6 +9,7 @@
 
 using namespace zk;
 void fp_to_mont_dev(void *p, size_t count, hipStream_t s);
+void fp_from_mont_dev(void *p, size_t count, hipStream_t s);
 
 static thread_local std::string g_last_error;
 extern "C" const char *zkp_last_error(void) { return g_last_error.c_str(); }
@@ -125,7 +126,7 @@ static int msm_test(long n_, long batch, const uint8_t *points, const uint8_t *s
     MsmScratch sc;
     sc.reserve(B, n * mb.W, (size_t)1 << (c - 1), msm_part_stride(n, c));
     sc.reserve_compact(B, n);
-    if (dense) sc.reserve_dense(B, n * mb.W);
+    if (dense) { sc.reserve_dense(B, n * mb.W); sc.reserve_tree(B, n * mb.W, (size_t)1 << (c - 1)); }
     sc.reserve_sums(B, sizeof(F) == 32 ? (size_t)1 << (c - 1) : 1, sizeof(F) == 32 ? 1 : (size_t)1 << (c - 1));
     DevBuf<XYZZ<F>> res(B);
     DevBuf<Affine<F>> aff(B);
@@ -160,16 +161,19 @@ __global__ void k_fp_to_mont(Fp *a, size_t total) {
     if (i < total) a[i] = a[i].to_mont();
 }
 }
-void fp_to_mont_dev(void *p, size_t count, hipStream_t s) {
-    if (count) hipLaunchKernelGGL(zk::k_fp_to_mont, dim3(ceil_div(count, 256)), dim3(256), 0, s, (Fp *)p, count);
-}
-
 namespace zk {
 __global__ void k_fp_from_mont(Fp *a, size_t total) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < total) a[i] = a[i].from_mont();
 }
 }
+void fp_from_mont_dev(void *p, size_t count, hipStream_t s) {
+    if (count) hipLaunchKernelGGL(zk::k_fp_from_mont, dim3(ceil_div(count, 256)), dim3(256), 0, s, (Fp *)p, count);
+}
+void fp_to_mont_dev(void *p, size_t count, hipStream_t s) {
+    if (count) hipLaunchKernelGGL(zk::k_fp_to_mont, dim3(ceil_div(count, 256)), dim3(256), 0, s, (Fp *)p, count);
+}
+
 // key folding (keyfold.hip): z = pk.G1.Z, (2^logn - 1) * 64 canonical LE (x|y) -> ze: 2^logn * 64, zc: ncons * 64
 extern "C" int zkp_fold_quotient_bases(int logn, long ncons, const uint8_t *z, uint8_t *ze, uint8_t *zc) {
     ZKP_TRY
@@ -224,6 +228,20 @@ __global__ __launch_bounds__(256) void k_bench_mul(F *x, int iters) {
     for (int k = 0; k < iters; k++) { a = a * b; b = b * a; }
     x[i] = a + b;
 }
+// iters dependent inversions per thread: GCD = false -> Fermat ladder (inv), true -> binary GCD (inv_gcd)
+template <class F, bool GCD>
+__global__ __launch_bounds__(256) void k_bench_inv(F *x, int iters) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    F a = x[i];
+    for (int k = 0; k < iters; k++) a = (GCD ? a.inv_gcd() : a.inv()) + F::one();
+    x[i] = a;
+}
+// out[i] = in[i]^-1 by the binary-GCD inversion (Montgomery form in and out)
+template <class F>
+__global__ __launch_bounds__(64) void k_field_inv_gcd(const F *in, F *out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i].inv_gcd();
+}
 template <class F>
 __global__ __launch_bounds__(256) void k_bench_madd(XYZZ<F> *acc, const Affine<F> *pts, int iters) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -232,7 +250,32 @@ __global__ __launch_bounds__(256) void k_bench_madd(XYZZ<F> *acc, const Affine<F
     acc[i] = a;
 }
 }
-// returns milliseconds for `threads` threads x `iters` iterations; kind 0: 2 Fp mul / iter, 1: G1 madd, 2: G2 madd
+// in / out: n canonical little-endian 32-byte elements of Fp (field 0) or Fr (field 1); out[i] = in[i]^-1 mod m (0 -> 0), computed on
+// the device by Field::inv_gcd (conversion to and from Montgomery form included)
+extern "C" int zkp_field_inv(int field, long n, const uint8_t *in, uint8_t *out) {
+    ZKP_TRY
+    const size_t N = (size_t)n;
+    if (field == 0) {
+        DevBuf<Fp> d(N), o(N);
+        ZK_HIP(hipMemcpy(d.p, in, N * 32, hipMemcpyHostToDevice));
+        fp_to_mont_dev(d.p, N, 0);
+        hipLaunchKernelGGL(k_field_inv_gcd<Fp>, dim3(ceil_div(N, 64)), dim3(64), 0, 0, d.p, o.p, N);
+        fp_from_mont_dev(o.p, N, 0);
+        ZK_HIP(hipMemcpy(out, o.p, N * 32, hipMemcpyDeviceToHost));
+    } else {
+        DevBuf<Fr> d(N), o(N);
+        ZK_HIP(hipMemcpy(d.p, in, N * 32, hipMemcpyHostToDevice));
+        fr_to_mont(d.p, N, 0);
+        hipLaunchKernelGGL(k_field_inv_gcd<Fr>, dim3(ceil_div(N, 64)), dim3(64), 0, 0, d.p, o.p, N);
+        fr_from_mont(o.p, N, 0);
+        ZK_HIP(hipMemcpy(out, o.p, N * 32, hipMemcpyDeviceToHost));
+    }
+    ZK_HIP(hipDeviceSynchronize());
+    return 0;
+    ZKP_CATCH(-1)
+}
+// returns milliseconds for `threads` threads x `iters` iterations; kind 0: 2 Fp mul / iter, 1: G1 madd, 2: G2 madd, 3: Fp Fermat inversion,
+// 4: Fp binary-GCD inversion
 extern "C" double zkp_microbench(int kind, long threads, int iters) {
     ZKP_TRY
     size_t T = (size_t)threads;
@@ -247,6 +290,15 @@ extern "C" double zkp_microbench(int kind, long threads, int iters) {
         hipLaunchKernelGGL(k_bench_mul<Fp>, dim3(T / 256), dim3(256), 0, 0, x.p, 4);
         ZK_HIP(hipEventRecord(e0, 0));
         hipLaunchKernelGGL(k_bench_mul<Fp>, dim3(T / 256), dim3(256), 0, 0, x.p, iters);
+        ZK_HIP(hipEventRecord(e1, 0));
+    } else if (kind == 3 || kind == 4) {
+        DevBuf<Fp> x(T);
+        std::vector<Fp> h(T);
+        for (size_t i = 0; i < T; i++) for (int k = 0; k < 8; k++) h[i].l[k] = (uint32_t)(i * 2654435761u + k * 40503u + 17u) & (k == 7 ? 0x0fffffffu : 0xffffffffu);
+        x.upload(h.data(), T);
+        ZK_HIP(hipEventRecord(e0, 0));
+        if (kind == 3) hipLaunchKernelGGL((k_bench_inv<Fp, false>), dim3(T / 256), dim3(256), 0, 0, x.p, iters);
+        else hipLaunchKernelGGL((k_bench_inv<Fp, true>), dim3(T / 256), dim3(256), 0, 0, x.p, iters);
         ZK_HIP(hipEventRecord(e1, 0));
     } else if (kind == 1) {
         DevBuf<G1XYZZ> acc(T); acc.zero();
