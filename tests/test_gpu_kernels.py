@@ -242,3 +242,47 @@ def test_field_inversion_binary_gcd_matches_modular_inverse(zk, field):
     got = [int.from_bytes(out[32 * i:32 * i + 32].tobytes(), "little") for i in range(len(vals))]
     exp = [pow(v, -1, m) if v else 0 for v in vals]
     assert got == exp
+
+
+_TREE_SCRIPT = r"""
+import importlib, json, os, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+zk = importlib.import_module("zk-symmetric-crypto_amd")
+from oracle import ref as oracle
+oracle.lib(); oracle.set_threads(8)
+R = {R}
+def rand_fr(rng, n):
+    return np.frombuffer(b"".join((int.from_bytes(rng.bytes(32), "little") % R).to_bytes(32, "little") for _ in range(n)), np.uint8).reshape(n, 32).copy()
+res = {{}}
+for (n, batch, c) in {cases}:
+    rng = np.random.default_rng(n * 31 + c)
+    pts = oracle.g1_fixed_base(rand_fr(rng, n))
+    pts[5] = 0                                            # a base at infinity
+    pts[9] = pts[8]                                       # equal bases: P + P inside a bucket when their digits agree
+    sc = np.stack([rand_fr(rng, n) for _ in range(batch)])
+    sc[0, 9] = sc[0, 8]                                   # ... which this forces in every window of instance 0
+    sc[1, 9] = np.frombuffer(((R - int.from_bytes(sc[1, 8].tobytes(), "little")) % R).to_bytes(32, "little"), np.uint8)   # and P - P in instance 1
+    exp = np.stack([oracle.msm_g1(pts, sc[b]) for b in range(batch)])
+    got = np.zeros((batch, 64), np.uint8)
+    rc = zk.lib.zkp_msm_g1_dense(n, batch, pts.ctypes.data, sc.ctypes.data, got.ctypes.data, c)
+    res["%d,%d,%d" % (n, batch, c)] = bool(rc == 0 and np.array_equal(got, exp))
+print(json.dumps(res))
+"""
+
+
+@pytest.mark.parametrize("piece,cases", [("2048", [(8192, 4, 12), (20000, 2, 13)]), ("", [(4096, 64, 8), (3000, 3, 9)])])
+def test_msm_affine_tree_production_cut_matches_oracle(piece, cases):
+    """The affine reduction tree of the dense MSM (csrc/msm_tree.cuh) in the regime the prover runs it in: a thread owns MANY
+    buckets of ~30-90 entries (several halving rounds, several inversion chunks per round, ping-pong layouts reused), which the
+    small kernel tests above cannot reach because small batches are cut into one-bucket pieces.  ZKPROVE_MSM_PIECE forces the
+    production cut; bases at infinity, P + P and P - P pairs included.  Bit-exact against the oracle."""
+    import json, os, subprocess, sys
+    import helpers as H
+    env = dict(os.environ)
+    if piece:
+        env["ZKPROVE_MSM_PIECE"] = piece
+    res = subprocess.run([sys.executable, "-c", _TREE_SCRIPT.format(root=H.ROOT, R=R, cases=cases)], env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert all(out.values()), out

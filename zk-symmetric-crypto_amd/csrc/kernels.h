@@ -66,7 +66,6 @@ struct MsmScratch {
     // affine reduction tree (msm_tree.cuh): ping-pong layouts, final bucket points, per-wavefront prefix-product rows
     DevBuf<G1Affine> treeA1, treeB1, fin1;
     DevBuf<uint8_t> tree_scratch;
-    size_t tree_capA = 0, tree_capB = 0;
     void reserve_tree(size_t B, size_t max_entries, size_t nb);
 };
 

@@ -124,20 +124,27 @@ void MsmScratch::reserve_dense(size_t B_, size_t max_dense_entries) {
 static uint32_t accumulate_lanes(size_t max_entries, size_t B) {
     size_t piece = 2048;
     while (piece > 64 && (max_entries * B) / piece < 262144) piece >>= 1;
+    // parity tests force the production cut (many buckets and several inversion chunks per thread) at batch sizes the CPU oracle can follow
+    static const size_t forced = [] { const char *e = getenv("ZKPROVE_MSM_PIECE"); return e ? (size_t)atol(e) : (size_t)0; }();
+    if (forced >= 16) piece = forced;
     const uint32_t nlanes = (uint32_t)((max_entries + piece - 1) / piece);
     return nlanes < 1 ? 1 : nlanes;
 }
 void MsmScratch::reserve_tree(size_t B_, size_t max_entries, size_t nb) {
     const size_t Bm = B_ > VIRT_MIN ? B_ : VIRT_MIN;
-    tree_capA = (max_entries + nb) / 2 + 2;
-    tree_capB = (tree_capA + nb) / 2 + 2;
-    treeA1.ensure(Bm * tree_capA);
-    treeB1.ensure(Bm * tree_capB);
+    // the finest cut any batch size uses decides the wavefront count and the per-piece slack of the buffers
+    size_t waves = 0, needA = 0, needB = 0;
+    for (size_t b = 1;; b <<= 1) {
+        const size_t bb = b < Bm ? b : Bm;
+        const size_t nl = accumulate_lanes(max_entries, bb);
+        waves = std::max(waves, (size_t)ceil_div(nl * bb, 64));
+        needA = std::max(needA, bb * tree_capacity(max_entries, nb, nl, 1));
+        needB = std::max(needB, bb * tree_capacity(max_entries, nb, nl, 2));
+        if (bb == Bm) break;
+    }
+    treeA1.ensure(needA);
+    treeB1.ensure(needB);
     fin1.ensure(Bm * nb);
-    // the finest cut any batch size uses decides the wavefront count
-    size_t waves = 0;
-    for (size_t b = 1; b <= Bm; b <<= 1) waves = std::max(waves, (size_t)ceil_div((size_t)accumulate_lanes(max_entries, b) * b, 64));
-    waves = std::max(waves, (size_t)ceil_div((size_t)accumulate_lanes(max_entries, Bm) * Bm, 64));
     tree_scratch.ensure((waves + 1) * TREE_CH * 64 * tree_slot_bytes<Fp>());
 }
 void MsmScratch::reserve_compact(size_t B_, size_t max_sparse_n) {
@@ -672,14 +679,17 @@ static void launch_tree_g1(const MsmBasesG1 &mb, MsmScratch &sc, size_t max_entr
                            size_t part_off, uint32_t L, hipStream_t s, hipEvent_t *seg_events) {
     const uint32_t nb = 1u << (c - 1);
     const size_t nseg = nb / L;
-    const size_t capA = (max_entries + nb) / 2 + 2, capB = (capA + nb) / 2 + 2;
-    const unsigned grid = ceil_div((size_t)nlanes * Bv, 64);
+    const size_t capA = tree_capacity(max_entries, nb, nlanes, 1), capB = tree_capacity(max_entries, nb, nlanes, 2);
+    static const uint32_t dbg = [] { const char *e = getenv("ZKPROVE_TREE_DEBUG"); return e ? (uint32_t)atoi(e) : 0u; }();
+    const unsigned grid = (dbg & 8) ? (unsigned)(nlanes * Bv) : ceil_div((size_t)nlanes * Bv, 64);
+    if (dbg & 8) sc.tree_scratch.ensure((size_t)grid * TREE_CH * 64 * tree_slot_bytes<Fp>());
     if (sc.treeA1.n < Bv * capA || sc.treeB1.n < Bv * capB || sc.fin1.n < Bv * (size_t)nb ||
         sc.tree_scratch.n < (size_t)grid * TREE_CH * 64 * tree_slot_bytes<Fp>())
         throw ZkError("msm tree scratch too small");
+    if (dbg & 4) { ZK_HIP(hipMemsetAsync(sc.treeA1.p, 0, Bv * capA * sizeof(G1Affine), s)); ZK_HIP(hipMemsetAsync(sc.treeB1.p, 0, Bv * capB * sizeof(G1Affine), s)); }
     if (seg_events) ZK_HIP(hipEventRecord(seg_events[0], s));
     hipLaunchKernelGGL((k_msm_tree<Fp, true>), dim3(grid), dim3(64), 0, s, mb.table.p, sc.bucket_start.p, sc.entries.p, max_entries, c, Bv, nlanes,
-                       sc.treeA1.p, capA, sc.treeB1.p, capB, sc.fin1.p, sc.tree_scratch.p);
+                       sc.treeA1.p, capA, sc.treeB1.p, capB, sc.fin1.p, sc.tree_scratch.p, dbg);
     if (seg_events) ZK_HIP(hipEventRecord(seg_events[1], s));
     hipLaunchKernelGGL(k_msm_bucket_reduce_tree<Fp>, dim3(ceil_div(nseg * Bv, 64)), dim3(64), 0, s, sc.fin1.p, mb.table.p, sc.entries.p, max_entries,
                        sc.bucket_start.p, c, Bv, part, stride, part_off, L);

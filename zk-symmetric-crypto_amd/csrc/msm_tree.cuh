@@ -12,10 +12,12 @@
 //              it and the pair's descriptor in a per-wavefront HBM scratch ([slot][lane] layout: every access is one 2 KiB / 1 KiB row);
 //   invert   : ONE inversion of c per thread and chunk of <= CH pairs (Field::inv_gcd, ~50 multiplications' worth);
 //   backward : slots in reverse: 1 / den = inv * c_before, inv *= den, lambda, x3, y3, store the sum.
-// The layout of every round is a pure function of the sorted layout (bucket_start) -- nothing is scanned or compacted:
-//   start_r(k) = (start_{r-1}(k) + k) >> 1,  count_r(k) = ceil(count_{r-1}(k) / 2),  start_0 = bucket_start,
-// which keeps start_r(k+1) - start_r(k) >= count_r(k).  Round r reads layout r-1 from one buffer and writes layout r to the
-// other; a bucket's final point goes to final[k].  Threads never touch each other's buckets: no synchronisation at all.
+// The layout of every round is a pure function of the sorted layout (bucket_start) -- nothing is scanned or compacted.  Relative
+// to its piece (first bucket k0), bucket k = k0 + k' holds its count_r items of round r at
+//   start_r(k') = (start_{r-1}(k') + k') >> 1,  count_r = ceil(count_{r-1} / 2),  start_0(k') = bucket_start[k] - bucket_start[k0],
+// which keeps start_r(k'+1) - start_r(k') >= count_r(k').  Odd rounds live in buffer A, even rounds in buffer B, each piece inside
+// an interval of its own (tree_piece_base): threads run their rounds at their own pace, so a thread's round-3 items must never
+// land on another thread's unread round-1 items.  A bucket's final point goes to final[k].  No synchronisation at all.
 // Exceptional pairs (an operand at infinity, P + P, P - P, an odd item without partner) take denominator 1 and are resolved by
 // selects in the backward pass, so parity with the oracle holds for adversarial inputs too (equal scalars, infinity bases).
 #pragma once
@@ -29,18 +31,18 @@ static constexpr int TREE_CH = 256;                        // pairs per thread b
 template <class F>
 constexpr size_t tree_slot_bytes() { return sizeof(F) + 16; }       // prefix product + descriptor, per pair and lane
 
-__device__ __forceinline__ uint32_t tree_start(uint32_t s0, uint32_t k, int r) {
+ZK_HD uint32_t tree_start(uint32_t s0, uint32_t k, int r) {
     for (int i = 0; i < r; i++) s0 = (s0 + k) >> 1;
     return s0;
 }
-__device__ __forceinline__ uint32_t tree_count(uint32_t n0, int r) { return r >= 32 ? (n0 ? 1u : 0u) : (uint32_t)(((uint64_t)n0 + ((1ull << r) - 1)) >> r); }
+ZK_HD uint32_t tree_count(uint32_t n0, int r) { return r >= 32 ? (n0 ? 1u : 0u) : (uint32_t)(((uint64_t)n0 + ((1ull << r) - 1)) >> r); }
 
 template <class F>
-__device__ __forceinline__ F field_inv_shared(const F &x);
+ZK_HD F field_inv_shared(const F &x);
 template <>
-__device__ __forceinline__ Fp field_inv_shared<Fp>(const Fp &x) { return x.inv_gcd(); }
+ZK_HD Fp field_inv_shared<Fp>(const Fp &x) { return x.inv_gcd(); }
 template <>
-__device__ __forceinline__ Fp2 field_inv_shared<Fp2>(const Fp2 &x) {
+ZK_HD Fp2 field_inv_shared<Fp2>(const Fp2 &x) {
     const Fp n = (x.a0.sqr() + x.a1.sqr()).inv_gcd();
     return Fp2{x.a0 * n, (x.a1 * n).neg()};
 }
@@ -52,7 +54,7 @@ __device__ __forceinline__ Fp2 field_inv_shared<Fp2>(const Fp2 &x) {
 template <class F>
 struct PairKind { bool inf0, inf1, xeq, dbl, generic; };
 template <class F>
-__device__ __forceinline__ PairKind<F> pair_kind(const Affine<F> &p0, const Affine<F> &p1) {
+ZK_HD PairKind<F> pair_kind(const Affine<F> &p0, const Affine<F> &p1) {
     PairKind<F> k;
     k.inf0 = p0.is_inf(); k.inf1 = p1.is_inf();
     k.xeq = p0.x == p1.x;
@@ -61,25 +63,40 @@ __device__ __forceinline__ PairKind<F> pair_kind(const Affine<F> &p0, const Affi
     return k;
 }
 
-// sorted-layout walker of one piece for round r: emits (src0, src1, dst) of every pair of every bucket with >= 2 items
+// Interval of piece p = buckets [k0, k1) of an instance inside buffer A (shift 1) or B (shift 2): it starts at
+// (bucket_start[k0] >> shift) + k0 + 2 p, which leaves every piece at least max(entries >> shift, buckets) + buckets / ... slots --
+// enough for start_r(k1 - k0) of every round r of that parity (start_r never exceeds max(start_{r-1}, buckets)).
+ZK_HD size_t tree_piece_base(uint32_t bs_k0, uint32_t k0, uint32_t piece, int shift) { return (size_t)(bs_k0 >> shift) + k0 + 2 * (size_t)piece; }
+// capacity of buffer A / B for an instance of at most max_entries entries, nb buckets, nlanes pieces
+inline size_t tree_capacity(size_t max_entries, size_t nb, size_t nlanes, int shift) { return (max_entries >> shift) + 2 * nb + 2 * nlanes + 4; }
+
+// sorted-layout walker of one piece for round r: emits (src0, src1, dst) of every pair of every bucket with >= 2 items.
+// src / dst are absolute indices: into the entry list (round 1 sources) or into the instance's buffer A / B.
 struct TreeWalker {
     const uint32_t *bs;
-    uint32_t k, k_end, e0, e1;      // current bucket, its original [e0, e1)
+    uint32_t k, k_first, k_end, e_first, e0, e1;      // current bucket, its original [e0, e1)
     uint32_t t, m, n_prev, s_in, s_out;
+    uint32_t base_in, base_out;                       // this piece's interval in the buffers of layout r-1 / r
     int r;
     bool more;                       // some bucket of the piece still has >= 2 items after this round
-    __device__ __forceinline__ void init(const uint32_t *bs_, uint32_t k0, uint32_t k1, int round) {
-        bs = bs_; k = k0; k_end = k1; r = round; t = 0; m = 0; more = false;
-        if (k < k_end) { e0 = bs[k]; e1 = bs[k + 1]; enter(); }
+    ZK_HD void init(const uint32_t *bs_, uint32_t k0, uint32_t k1, uint32_t piece, int round) {
+        bs = bs_; k = k0; k_first = k0; k_end = k1; r = round; t = 0; m = 0; more = false;
+        if (k < k_end) {
+            e0 = bs[k]; e1 = bs[k + 1]; e_first = e0;
+            const uint32_t bA = (uint32_t)tree_piece_base(e_first, k0, piece, 1), bB = (uint32_t)tree_piece_base(e_first, k0, piece, 2);
+            base_in = r == 1 ? e_first : (((r - 1) & 1) ? bA : bB);      // layout 0 = the entry list itself
+            base_out = (r & 1) ? bA : bB;
+            enter();
+        }
     }
-    __device__ __forceinline__ void enter() {         // position on the first bucket >= k that has pairs
+    ZK_HD void enter() {         // position on the first bucket >= k that has pairs
         while (k < k_end) {
             const uint32_t n0 = e1 - e0;
             n_prev = tree_count(n0, r - 1);
             if (n_prev >= 2) {
                 m = (n_prev + 1) >> 1;
-                s_in = tree_start(e0, k, r - 1);
-                s_out = tree_start(e0, k, r);
+                s_in = base_in + tree_start(e0 - e_first, k - k_first, r - 1);
+                s_out = base_out + tree_start(e0 - e_first, k - k_first, r);
                 t = 0;
                 more = more || m >= 2;
                 return;
@@ -90,7 +107,7 @@ struct TreeWalker {
         m = 0;
     }
     // next pair of this lane; false when the piece is exhausted
-    __device__ __forceinline__ bool next(uint32_t &src0, uint32_t &src1, uint32_t &dst) {
+    ZK_HD bool next(uint32_t &src0, uint32_t &src1, uint32_t &dst) {
         if (k >= k_end) return false;
         src0 = s_in + 2 * t;
         src1 = (2 * t + 1 < n_prev) ? src0 + 1 : TREE_ABSENT;
@@ -105,51 +122,47 @@ struct TreeWalker {
 };
 
 template <class F>
-__device__ __forceinline__ Affine<F> tree_load_entry(const Affine<F> *__restrict__ table, uint32_t v) {
+ZK_HD Affine<F> tree_load_entry(const Affine<F> *__restrict__ table, uint32_t v) {
     Affine<F> p = table[v & 0x7fffffffu];
     if (v >> 31) p.y = p.y.neg();
     return p;
 }
 
-// One thread per piece (same cut as k_msm_accumulate).  scratch: gridDim.x * TREE_CH * 64 * tree_slot_bytes<F>() bytes.
-template <class F, bool DENSE>
-__device__ __forceinline__ void tree_body(const Affine<F> *__restrict__ table, const uint32_t *__restrict__ bucket_start, const uint32_t *__restrict__ entries,
-                                          size_t max_entries, int c, size_t B, uint32_t nlanes, Affine<F> *__restrict__ bufA, size_t capA,
-                                          Affine<F> *__restrict__ bufB, size_t capB, Affine<F> *__restrict__ fin, uint8_t *__restrict__ scratch) {
-    const uint32_t nb = 1u << (c - 1);
-    const size_t tg = (size_t)blockIdx.x * 64 + threadIdx.x;
-    const bool live = tg < (size_t)nlanes * B;
-    const size_t b = live ? tg / nlanes : 0;
-    const uint32_t lane = live ? (uint32_t)(tg % nlanes) : 0;
-    const uint32_t *bs = bucket_start + b * (nb + 1);
-    const uint32_t *ent = entries + b * max_entries;
-    uint32_t k0 = 0, k1 = 0;
-    if (live) {
-        const uint32_t total = bs[nb];
-        auto first_bucket = [&](uint32_t target) -> uint32_t {      // first bucket k with bs[k] >= target
-            uint32_t lo = 0, hi = nb;
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (bs[mid] >= target) hi = mid; else lo = mid + 1;
-            }
-            return lo;
-        };
-        k0 = first_bucket((uint32_t)(((uint64_t)total * lane + nlanes - 1) / nlanes));
-        k1 = lane + 1 == nlanes ? nb : first_bucket((uint32_t)(((uint64_t)total * (lane + 1) + nlanes - 1) / nlanes));
-        if (k0 > k1) k0 = k1;
-    }
-    Affine<F> *A = bufA + b * capA, *Bf = bufB + b * capB, *out_final = fin + b * nb;
-    // per-wavefront scratch rows: [slot][lane]
-    uint8_t *wave_base = scratch + (size_t)blockIdx.x * TREE_CH * 64 * tree_slot_bytes<F>();
-    F *pref = (F *)wave_base;                                              // [TREE_CH][64]
-    uint4 *desc = (uint4 *)(wave_base + (size_t)TREE_CH * 64 * sizeof(F));  // [TREE_CH][64]
-    const int ln = threadIdx.x;
+// piece `lane` of `nlanes` of an instance: buckets [k0, k1), cut at equal entry counts rounded to bucket boundaries
+ZK_HD void tree_piece_bounds(const uint32_t *bs, uint32_t nb, uint32_t lane, uint32_t nlanes, uint32_t &k0, uint32_t &k1) {
+    const uint32_t total = bs[nb];
+    auto first_bucket = [&](uint32_t target) -> uint32_t {      // first bucket k with bs[k] >= target
+        uint32_t lo = 0, hi = nb;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (bs[mid] >= target) hi = mid; else lo = mid + 1;
+        }
+        return lo;
+    };
+    k0 = first_bucket((uint32_t)(((uint64_t)total * lane + nlanes - 1) / nlanes));
+    k1 = lane + 1 == nlanes ? nb : first_bucket((uint32_t)(((uint64_t)total * (lane + 1) + nlanes - 1) / nlanes));
+    if (k0 > k1) k0 = k1;
+}
 
+// wave vote of the device build; the host build (tests/host emulation of one lane at a time) has nothing to vote with
+ZK_HD bool tree_any(bool p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __any(p) != 0;
+#else
+    return p;
+#endif
+}
+
+// All halving rounds of the piece [k0, k1) of one instance.  pref / desc: this lane's columns of the wavefront's scratch rows
+// (element i of a column sits `stride` elements after element i - 1: 64 on the device, 1 in the host emulation).
+template <class F>
+ZK_HD void tree_piece(const Affine<F> *__restrict__ table, const uint32_t *bs, const uint32_t *ent, uint32_t k0, uint32_t k1, uint32_t piece, Affine<F> *A, Affine<F> *Bf,
+                      Affine<F> *out_final, F *pref, uint4 *desc, size_t stride, uint32_t dbg = 0) {
     for (int r = 1; r < 40; r++) {
         const Affine<F> *in = (r & 1) ? Bf : A;          // layout r-1 (r >= 2)
         Affine<F> *out = (r & 1) ? A : Bf;               // layout r
         TreeWalker w;
-        w.init(bs, k0, k1, r);
+        w.init(bs, k0, k1, piece, r);
         while (true) {
             // ---- forward: running product of the denominators
             F cprod = F::one();
@@ -157,7 +170,7 @@ __device__ __forceinline__ void tree_body(const Affine<F> *__restrict__ table, c
             for (; i < TREE_CH; i++) {
                 uint32_t s0 = 0, s1 = TREE_ABSENT, dst = 0;
                 const bool have = w.next(s0, s1, dst);
-                if (!__any(have)) break;
+                if (!tree_any(have)) break;
                 if (have) {
                     uint32_t v0 = s0, v1 = s1;
                     F x0, x1;
@@ -173,7 +186,7 @@ __device__ __forceinline__ void tree_body(const Affine<F> *__restrict__ table, c
                     x0 = q0->x;
                     x1 = q1 ? q1->x : F::zero();
                     F den;
-                    if (q1 && x0 != x1 && !x0.is_zero() && !x1.is_zero()) {
+                    if (!(dbg & 16) && q1 && x0 != x1 && !x0.is_zero() && !x1.is_zero()) {
                         den = x1 - x0;                           // generic: the sign of y never matters here
                     } else {                                     // rare: look at the whole points
                         Affine<F> p0 = *q0, p1 = q1 ? *q1 : Affine<F>::inf();
@@ -181,21 +194,25 @@ __device__ __forceinline__ void tree_body(const Affine<F> *__restrict__ table, c
                         const PairKind<F> kd = pair_kind(p0, p1);
                         den = kd.generic ? p1.x - p0.x : (kd.dbl ? p0.y.dbl() : F::one());
                     }
-                    pref[(size_t)i * 64 + ln] = cprod;
-                    desc[(size_t)i * 64 + ln] = make_uint4(v0, v1, dst, 0u);
+                    pref[(size_t)i * stride] = cprod;
+                    desc[(size_t)i * stride] = uint4{v0, v1, dst, 0u};
                     cprod = cprod * den;
                     cnt++;
                 }
             }
             const int used = i;                                  // wave-uniform: the longest lane
             if (used == 0) break;
+            if (dbg & 32) { if (used < TREE_CH) break; continue; }      // timing experiment: forward pass only (results are garbage)
             // ---- one inversion per thread
-            F inv = field_inv_shared<F>(cprod);
+            F inv = (dbg & 1) ? cprod.inv() : field_inv_shared<F>(cprod);
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (dbg & 2) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+#endif
             // ---- backward
             for (int j = used - 1; j >= 0; j--) {
                 if (j < cnt) {
-                    const uint4 d = desc[(size_t)j * 64 + ln];
-                    const F cbefore = pref[(size_t)j * 64 + ln];
+                    const uint4 d = desc[(size_t)j * stride];
+                    const F cbefore = pref[(size_t)j * stride];
                     const bool has1 = d.y != TREE_ABSENT;
                     Affine<F> p0, p1 = Affine<F>::inf();
                     if (r == 1) {
@@ -224,17 +241,41 @@ __device__ __forceinline__ void tree_body(const Affine<F> *__restrict__ table, c
                     else out[d.z] = res;
                 }
             }
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (dbg & 2) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+#endif
             if (used < TREE_CH) break;                           // every lane ran out of pairs inside this chunk
         }
-        if (!__any(w.more)) break;
+        if (!tree_any(w.more)) break;
     }
+}
+
+// One thread per piece (same cut as k_msm_accumulate).  scratch: gridDim.x * TREE_CH * 64 * tree_slot_bytes<F>() bytes.
+template <class F, bool DENSE>
+__device__ __forceinline__ void tree_body(const Affine<F> *__restrict__ table, const uint32_t *__restrict__ bucket_start, const uint32_t *__restrict__ entries,
+                                          size_t max_entries, int c, size_t B, uint32_t nlanes, Affine<F> *__restrict__ bufA, size_t capA,
+                                          Affine<F> *__restrict__ bufB, size_t capB, Affine<F> *__restrict__ fin, uint8_t *__restrict__ scratch, uint32_t dbg) {
+    const uint32_t nb = 1u << (c - 1);
+    const size_t tg = (dbg & 8) ? (size_t)blockIdx.x : (size_t)blockIdx.x * 64 + threadIdx.x;      // debug: one live lane per wavefront
+    const bool live = tg < (size_t)nlanes * B && (!(dbg & 8) || threadIdx.x == 0);
+    const size_t b = live ? tg / nlanes : 0;
+    const uint32_t lane = live ? (uint32_t)(tg % nlanes) : 0;
+    const uint32_t *bs = bucket_start + b * (nb + 1);
+    const uint32_t *ent = entries + b * max_entries;
+    uint32_t k0 = 0, k1 = 0;
+    if (live) tree_piece_bounds(bs, nb, lane, nlanes, k0, k1);
+    // per-wavefront scratch rows: [slot][lane]
+    uint8_t *wave_base = scratch + (size_t)blockIdx.x * TREE_CH * 64 * tree_slot_bytes<F>();
+    F *pref = (F *)wave_base + threadIdx.x;                                             // [TREE_CH][64]
+    uint4 *desc = (uint4 *)(wave_base + (size_t)TREE_CH * 64 * sizeof(F)) + threadIdx.x;  // [TREE_CH][64]
+    tree_piece<F>(table, bs, ent, k0, k1, lane, bufA + b * capA, bufB + b * capB, fin + b * nb, pref, desc, 64, dbg);
 }
 
 template <class F, bool DENSE>
 __global__ __launch_bounds__(64) void k_msm_tree(const Affine<F> *__restrict__ table, const uint32_t *__restrict__ bucket_start, const uint32_t *__restrict__ entries,
                                                  size_t max_entries, int c, size_t B, uint32_t nlanes, Affine<F> *__restrict__ bufA, size_t capA,
-                                                 Affine<F> *__restrict__ bufB, size_t capB, Affine<F> *__restrict__ fin, uint8_t *__restrict__ scratch) {
-    tree_body<F, DENSE>(table, bucket_start, entries, max_entries, c, B, nlanes, bufA, capA, bufB, capB, fin, scratch);
+                                                 Affine<F> *__restrict__ bufB, size_t capB, Affine<F> *__restrict__ fin, uint8_t *__restrict__ scratch, uint32_t dbg) {
+    tree_body<F, DENSE>(table, bucket_start, entries, max_entries, c, B, nlanes, bufA, capA, bufB, capB, fin, scratch, dbg);
 }
 
 // thread (b, seg): running-sum reduction of buckets [seg*L, seg*L + L) of instance b, bucket sums as produced by k_msm_tree:

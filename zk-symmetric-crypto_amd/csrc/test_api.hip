@@ -326,3 +326,73 @@ extern "C" double zkp_microbench(int kind, long threads, int iters) {
     return ms;
     ZKP_CATCH(-1.0)
 }
+
+// ---- debug harness: device tree kernel vs. host emulation of the same code on host-sorted input (prints per-bucket diffs)
+#include "msm_tree.cuh"
+#include <random>
+#include <array>
+#include <algorithm>
+namespace zk {
+template <class F, bool DENSE>
+__global__ void k_msm_tree(const Affine<F> *__restrict__ table, const uint32_t *__restrict__ bucket_start, const uint32_t *__restrict__ entries,
+                           size_t max_entries, int c, size_t B, uint32_t nlanes, Affine<F> *__restrict__ bufA, size_t capA,
+                           Affine<F> *__restrict__ bufB, size_t capB, Affine<F> *__restrict__ fin, uint8_t *__restrict__ scratch, uint32_t dbg);
+}
+static int dbg_signed_digit(const uint32_t *l, int w, int c, int &carry) {
+    const int bit = w * c; const int li = bit >> 5, sh = bit & 31;
+    uint64_t v = li < 8 ? l[li] : 0; if (li + 1 < 8) v |= (uint64_t)l[li + 1] << 32;
+    int raw = (int)((v >> sh) & ((1u << c) - 1)) + carry;
+    if (raw > (1 << (c - 1))) { carry = 1; return raw - (1 << c); }
+    carry = 0; return raw;
+}
+extern "C" int zkp_debug_tree(int n, int c, int piece, int dbg) {
+    ZKP_TRY
+    const int W = (254 + c - 1) / c; const uint32_t nb = 1u << (c - 1);
+    std::mt19937_64 rng(42);
+    G1Affine g{Fp::one(), Fp::one() + Fp::one()};
+    std::vector<G1Affine> pts(n);
+    for (int j = 0; j < n; j++) { uint32_t k[8] = {(uint32_t)rng(), (uint32_t)rng(), 0, 0, 0, 0, 0, 0}; pts[j] = scalar_mul(g, k, 64).to_affine(); }
+    std::vector<G1Affine> table((size_t)n * W);
+    for (int j = 0; j < n; j++) { XYZZ<Fp> cur = XYZZ<Fp>::from_affine(pts[j]); for (int w = 0; w < W; w++) { table[(size_t)j * W + w] = cur.to_affine(); for (int k = 0; k < c; k++) cur = cur.dbl(); } }
+    std::vector<std::array<uint32_t, 8>> sc(n);
+    for (auto &s : sc) { for (int i = 0; i < 8; i++) s[i] = (uint32_t)rng(); s[7] &= 0x0fffffff; }
+    std::vector<std::vector<uint32_t>> buckets(nb);
+    for (int j = 0; j < n; j++) { int carry = 0; for (int w = 0; w < W; w++) { int d = dbg_signed_digit(sc[j].data(), w, c, carry); if (!d) continue; uint32_t neg = d < 0; buckets[(neg ? -d : d) - 1].push_back((uint32_t)(j * W + w) | (neg << 31)); } }
+    std::vector<uint32_t> bs(nb + 1), ent;
+    for (uint32_t k = 0; k < nb; k++) { bs[k] = (uint32_t)ent.size(); ent.insert(ent.end(), buckets[k].begin(), buckets[k].end()); }
+    bs[nb] = (uint32_t)ent.size();
+    const size_t M = ent.size();
+    const uint32_t nlanes = (uint32_t)((M + piece - 1) / piece);
+    const size_t capA = tree_capacity(M, nb, nlanes, 1), capB = tree_capacity(M, nb, nlanes, 2);
+    std::vector<G1Affine> A(capA), Bf(capB), fin(nb), fin_dev(nb);
+    std::vector<Fp> pref(TREE_CH); std::vector<uint4> desc(TREE_CH);
+    for (uint32_t lane = 0; lane < nlanes; lane++) {
+        uint32_t k0, k1; tree_piece_bounds(bs.data(), nb, lane, nlanes, k0, k1);
+        tree_piece<Fp>(table.data(), bs.data(), ent.data(), k0, k1, lane, A.data(), Bf.data(), fin.data(), pref.data(), desc.data(), 1);
+    }
+    DevBuf<G1Affine> dt(table.size()), dA(capA), dB(capB), dfin(nb);
+    DevBuf<uint32_t> dbs(nb + 1), dent(M + 1);
+    dt.upload(table.data(), table.size()); dbs.upload(bs.data(), nb + 1); dent.upload(ent.data(), M);
+    const unsigned grid = (dbg & 8) ? nlanes : ceil_div(nlanes, 64);
+    DevBuf<uint8_t> dscr((size_t)grid * TREE_CH * 64 * tree_slot_bytes<Fp>());
+    ZK_HIP(hipMemset(dfin.p, 0xff, nb * sizeof(G1Affine)));
+    hipLaunchKernelGGL((k_msm_tree<Fp, true>), dim3(grid), dim3(64), 0, 0, dt.p, dbs.p, dent.p, M, c, (size_t)1, nlanes, dA.p, capA, dB.p, capB, dfin.p, dscr.p, (uint32_t)dbg);
+    ZK_HIP(hipDeviceSynchronize());
+    dfin.download(fin_dev.data(), nb);
+    ZK_HIP(hipDeviceSynchronize());
+    int bad = 0, hist[16] = {};
+    for (uint32_t k = 0; k < nb; k++) {
+        if (buckets[k].size() < 2) continue;
+        if (!(fin[k].x == fin_dev[k].x && fin[k].y == fin_dev[k].y)) {
+            bad++;
+            int lg = 0; while ((1u << lg) < buckets[k].size()) lg++;
+            hist[lg < 15 ? lg : 15]++;
+            if (bad <= 8) fprintf(stderr, "bucket %u n=%zu differs (dev x limb0 %08x host %08x)\n", k, buckets[k].size(), fin_dev[k].x.l[0], fin[k].x.l[0]);
+        }
+    }
+    fprintf(stderr, "debug_tree n=%d c=%d piece=%d dbg=%d entries=%zu lanes=%u: %d bad buckets; by ceil(log2 n):", n, c, piece, dbg, M, nlanes, bad);
+    for (int i = 0; i < 16; i++) fprintf(stderr, " %d", hist[i]);
+    fprintf(stderr, "\n");
+    return bad;
+    ZKP_CATCH(-1)
+}
