@@ -10,7 +10,8 @@ import sys
 
 
 def one(pattern):
-    f = glob.glob(pattern)
+    # rocprofv3 writes <dir>/<host>/<pid>_x.csv without -o and <dir>/<prefix>_x.csv with it
+    f = glob.glob(pattern) or glob.glob(pattern.replace("/*/*", "/*"))
     if not f:
         raise SystemExit("no file matches " + pattern)
     return f[0]
@@ -34,8 +35,14 @@ def main():
                 out.setdefault(k, {})[nm + "_KB_per_launch_max"] = max(v)
                 out[k][nm + "_launches"] = len(v)
         top = dict(sorted(out.items(), key=lambda kv: -kv[1].get("FETCH_SIZE_KB_per_launch_max", 0))[:25])
+        import subprocess
+        try:
+            head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+        except Exception:
+            head = "?"
         json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 1; values in KB as reported by "
                            "rocprofv3 (gfx950: FETCH_SIZE reads 1/2 of wide coalesced streams, MI355X_MICROARCH.md section HBM -- uncorrected here)",
+                   "summarized_at_commit": head,
                    "kernels": top}, open("profiles/%s_pmc_traffic.json" % tag, "w"), indent=1)
 
 

@@ -273,13 +273,13 @@ print(json.dumps(res))
 
 @pytest.mark.parametrize("piece,cases", [("2048", [(8192, 4, 12), (20000, 2, 13)]), ("", [(4096, 64, 8), (3000, 3, 9)])])
 def test_msm_affine_tree_production_cut_matches_oracle(piece, cases):
-    """The affine reduction tree of the dense MSM (csrc/msm_tree.cuh) in the regime the prover runs it in: a thread owns MANY
+    """The affine reduction tree of the dense MSM (csrc/msm_tree.cuh; opt-in with ZKPROVE_MSM_TREE=1) in the regime the prover would run it in: a thread owns MANY
     buckets of ~30-90 entries (several halving rounds, several inversion chunks per round, ping-pong layouts reused), which the
     small kernel tests above cannot reach because small batches are cut into one-bucket pieces.  ZKPROVE_MSM_PIECE forces the
     production cut; bases at infinity, P + P and P - P pairs included.  Bit-exact against the oracle."""
     import json, os, subprocess, sys
     import helpers as H
-    env = dict(os.environ)
+    env = dict(os.environ, ZKPROVE_MSM_TREE="1")
     if piece:
         env["ZKPROVE_MSM_PIECE"] = piece
     res = subprocess.run([sys.executable, "-c", _TREE_SCRIPT.format(root=H.ROOT, R=R, cases=cases)], env=env, capture_output=True, text=True, timeout=900)

@@ -130,7 +130,9 @@ static uint32_t accumulate_lanes(size_t max_entries, size_t B) {
     const uint32_t nlanes = (uint32_t)((max_entries + piece - 1) / piece);
     return nlanes < 1 ? 1 : nlanes;
 }
+static bool tree_enabled();
 void MsmScratch::reserve_tree(size_t B_, size_t max_entries, size_t nb) {
+    if (!tree_enabled()) return;                 // tens of GB at batch 1024: only for the experiment
     const size_t Bm = B_ > VIRT_MIN ? B_ : VIRT_MIN;
     // the finest cut any batch size uses decides the wavefront count and the per-piece slack of the buffers
     size_t waves = 0, needA = 0, needB = 0;
@@ -668,10 +670,12 @@ __global__ __launch_bounds__(64) void k_sum_groups(const XYZZ<F> *__restrict__ i
     out[b * out_stride + g] = acc;
 }
 
-// Dense (quotient) MSM: affine reduction tree (msm_tree.cuh) instead of the extended-Jacobian walk; ZKPROVE_MSM_TREE=0 selects
-// the older kernel (kept for the A/B measurement in profiles/ and as the path of G2 and of the sparse MSMs)
+// Dense (quotient) MSM: ZKPROVE_MSM_TREE=1 selects the affine reduction tree (msm_tree.cuh, gnark's batch-affine idea) instead of the
+// extended-Jacobian walk.  It is bit-exact (tests) but measured SLOWER on MI355X (126 vs 110 ms per 1024-batch, profiles/r02_tree_*):
+// Montgomery's trick needs two passes over every pair, which triples the random 64-byte traffic (4.4 G gathers + 100 GB of
+// prefix rows per launch against 1.07 G gathers), and that, not the multiplier, then bounds the kernel.  Kept as an experiment.
 static bool tree_enabled() {
-    static const bool on = [] { const char *e = getenv("ZKPROVE_MSM_TREE"); return !(e && e[0] == '0'); }();
+    static const bool on = [] { const char *e = getenv("ZKPROVE_MSM_TREE"); return e && e[0] == '1'; }();
     return on;
 }
 // accumulate + bucket reduction of one sorted dense MSM through the tree kernels (G1)

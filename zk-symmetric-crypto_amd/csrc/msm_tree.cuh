@@ -155,6 +155,124 @@ ZK_HD bool tree_any(bool p) {
 
 // All halving rounds of the piece [k0, k1) of one instance.  pref / desc: this lane's columns of the wavefront's scratch rows
 // (element i of a column sits `stride` elements after element i - 1: 64 on the device, 1 in the host emulation).
+//
+// Memory latency: a gathered base point takes 1-3 us to arrive while a multiplication takes ~0.5 us, so neither pass may wait for one
+// slot's data at a time.  The forward pass handles TREE_G slots per step -- all their index words first, then all their x coordinates,
+// then the arithmetic; the backward pass keeps the next slot's descriptor, prefix product and both points in flight while it
+// computes the current one.
+static constexpr int TREE_G = 4;
+
+template <class F, bool FIRST>
+struct TreeFwd {
+    // forward pass over at most TREE_CH slots: returns the wave-uniform number of rows used; cnt = this lane's slots
+    static ZK_HD int run(const Affine<F> *__restrict__ table, const uint32_t *ent, const Affine<F> *in, TreeWalker &w, F *pref, uint4 *desc, size_t stride,
+                         F &cprod, int &cnt, uint32_t dbg) {
+        int i = 0;
+        cnt = 0;
+        cprod = F::one();
+        for (; i < TREE_CH; i += TREE_G) {
+            uint32_t s0[TREE_G], s1[TREE_G], dst[TREE_G], v0[TREE_G], v1[TREE_G];
+            bool have[TREE_G];
+#pragma unroll
+            for (int g = 0; g < TREE_G; g++) { s0[g] = 0; s1[g] = TREE_ABSENT; dst[g] = 0; have[g] = w.next(s0[g], s1[g], dst[g]); }
+            if (!tree_any(have[0])) break;                        // a lane's slots are contiguous: nobody has one
+            // index words (round 1: the sorted entries; later rounds: positions in the previous layout)
+#pragma unroll
+            for (int g = 0; g < TREE_G; g++) {
+                v0[g] = s0[g]; v1[g] = s1[g];
+                if (FIRST && have[g]) { v0[g] = ent[s0[g]]; if (s1[g] != TREE_ABSENT) v1[g] = ent[s1[g]]; }
+            }
+            const Affine<F> *q0[TREE_G], *q1[TREE_G];
+            F x0[TREE_G], x1[TREE_G];
+#pragma unroll
+            for (int g = 0; g < TREE_G; g++) {
+                q0[g] = FIRST ? table + (v0[g] & 0x7fffffffu) : in + v0[g];
+                q1[g] = FIRST ? table + (v1[g] & 0x7fffffffu) : in + v1[g];
+                x0[g] = F::zero(); x1[g] = F::zero();
+                if (have[g]) { x0[g] = q0[g]->x; if (v1[g] != TREE_ABSENT) x1[g] = q1[g]->x; }
+            }
+            int rows = 0;
+#pragma unroll
+            for (int g = 0; g < TREE_G; g++) {
+                rows += tree_any(have[g]) ? 1 : 0;
+                if (have[g]) {
+                    const bool has1 = v1[g] != TREE_ABSENT;
+                    F den;
+                    if (!(dbg & 16) && has1 && x0[g] != x1[g] && !x0[g].is_zero() && !x1[g].is_zero()) {
+                        den = x1[g] - x0[g];                      // generic: the sign of y never matters here
+                    } else {                                      // rare: look at the whole points
+                        Affine<F> p0 = *q0[g], p1 = has1 ? *q1[g] : Affine<F>::inf();
+                        if (FIRST) { if (v0[g] >> 31) p0.y = p0.y.neg(); if (has1 && (v1[g] >> 31)) p1.y = p1.y.neg(); }
+                        const PairKind<F> kd = pair_kind(p0, p1);
+                        den = kd.generic ? p1.x - p0.x : (kd.dbl ? p0.y.dbl() : F::one());
+                    }
+                    pref[(size_t)(i + g) * stride] = cprod;
+                    desc[(size_t)(i + g) * stride] = uint4{v0[g], v1[g], dst[g], 0u};
+                    cprod = cprod * den;
+                    cnt++;
+                }
+            }
+            if (rows < TREE_G) { i += rows; break; }
+        }
+        return i;
+    }
+};
+
+template <class F, bool FIRST>
+struct TreeBwd {
+    struct Slot { uint4 d; F cb; Affine<F> p0, p1; };
+    static ZK_HD uint4 load_desc(const uint4 *desc, size_t stride, int j, int cnt) { return (j >= 0 && j < cnt) ? desc[(size_t)j * stride] : uint4{0u, TREE_ABSENT, 0u, 0u}; }
+    static ZK_HD void load_rest(Slot &s, const Affine<F> *__restrict__ table, const Affine<F> *in, const F *pref, size_t stride, int j, int cnt) {
+        s.p1 = Affine<F>::inf();
+        if (j >= 0 && j < cnt) {
+            s.cb = pref[(size_t)j * stride];
+            if (FIRST) {
+                s.p0 = table[s.d.x & 0x7fffffffu];
+                if (s.d.y != TREE_ABSENT) s.p1 = table[s.d.y & 0x7fffffffu];
+            } else {
+                s.p0 = in[s.d.x];
+                if (s.d.y != TREE_ABSENT) s.p1 = in[s.d.y];
+            }
+        }
+    }
+    // backward pass over rows used-1 .. 0
+    static ZK_HD void run(const Affine<F> *__restrict__ table, const Affine<F> *in, Affine<F> *out, Affine<F> *out_final, const F *pref, const uint4 *desc,
+                          size_t stride, F inv, int used, int cnt) {
+        Slot cur, nxt;
+        cur.d = load_desc(desc, stride, used - 1, cnt);
+        load_rest(cur, table, in, pref, stride, used - 1, cnt);
+        nxt.d = load_desc(desc, stride, used - 2, cnt);
+        for (int j = used - 1; j >= 0; j--) {
+            // next slot: its points (its descriptor arrived during the previous step); the descriptor after that
+            load_rest(nxt, table, in, pref, stride, j - 1, cnt);
+            const uint4 d2 = load_desc(desc, stride, j - 2, cnt);
+            if (j < cnt) {
+                Affine<F> p0 = cur.p0, p1 = cur.p1;
+                if (FIRST) { if (cur.d.x >> 31) p0.y = p0.y.neg(); if (cur.d.y != TREE_ABSENT && (cur.d.y >> 31)) p1.y = p1.y.neg(); }
+                const PairKind<F> kd = pair_kind(p0, p1);
+                Affine<F> res;
+                if (kd.generic || kd.dbl) {
+                    const F den = kd.generic ? p1.x - p0.x : p0.y.dbl();
+                    const F dinv = inv * cur.cb;
+                    inv = inv * den;
+                    F num;
+                    if (kd.generic) num = p1.y - p0.y;
+                    else { const F xx = p0.x.sqr(); num = xx.dbl() + xx; }
+                    const F lam = num * dinv;
+                    res.x = lam.sqr() - p0.x - p1.x;
+                    res.y = lam * (p0.x - res.x) - p0.y;
+                } else {                                     // den = 1: inv unchanged
+                    res = kd.inf0 ? p1 : (kd.inf1 ? p0 : Affine<F>::inf());
+                }
+                if (cur.d.z & TREE_FINAL) out_final[cur.d.z & ~TREE_FINAL] = res;
+                else out[cur.d.z] = res;
+            }
+            cur = nxt;
+            nxt.d = d2;
+        }
+    }
+};
+
 template <class F>
 ZK_HD void tree_piece(const Affine<F> *__restrict__ table, const uint32_t *bs, const uint32_t *ent, uint32_t k0, uint32_t k1, uint32_t piece, Affine<F> *A, Affine<F> *Bf,
                       Affine<F> *out_final, F *pref, uint4 *desc, size_t stride, uint32_t dbg = 0) {
@@ -164,86 +282,16 @@ ZK_HD void tree_piece(const Affine<F> *__restrict__ table, const uint32_t *bs, c
         TreeWalker w;
         w.init(bs, k0, k1, piece, r);
         while (true) {
-            // ---- forward: running product of the denominators
-            F cprod = F::one();
-            int cnt = 0, i = 0;
-            for (; i < TREE_CH; i++) {
-                uint32_t s0 = 0, s1 = TREE_ABSENT, dst = 0;
-                const bool have = w.next(s0, s1, dst);
-                if (!tree_any(have)) break;
-                if (have) {
-                    uint32_t v0 = s0, v1 = s1;
-                    F x0, x1;
-                    const Affine<F> *q0, *q1 = nullptr;
-                    if (r == 1) {
-                        v0 = ent[s0];
-                        q0 = table + (v0 & 0x7fffffffu);
-                        if (s1 != TREE_ABSENT) { v1 = ent[s1]; q1 = table + (v1 & 0x7fffffffu); }
-                    } else {
-                        q0 = in + s0;
-                        if (s1 != TREE_ABSENT) q1 = in + s1;
-                    }
-                    x0 = q0->x;
-                    x1 = q1 ? q1->x : F::zero();
-                    F den;
-                    if (!(dbg & 16) && q1 && x0 != x1 && !x0.is_zero() && !x1.is_zero()) {
-                        den = x1 - x0;                           // generic: the sign of y never matters here
-                    } else {                                     // rare: look at the whole points
-                        Affine<F> p0 = *q0, p1 = q1 ? *q1 : Affine<F>::inf();
-                        if (r == 1) { if (v0 >> 31) p0.y = p0.y.neg(); if (q1 && (v1 >> 31)) p1.y = p1.y.neg(); }
-                        const PairKind<F> kd = pair_kind(p0, p1);
-                        den = kd.generic ? p1.x - p0.x : (kd.dbl ? p0.y.dbl() : F::one());
-                    }
-                    pref[(size_t)i * stride] = cprod;
-                    desc[(size_t)i * stride] = uint4{v0, v1, dst, 0u};
-                    cprod = cprod * den;
-                    cnt++;
-                }
-            }
-            const int used = i;                                  // wave-uniform: the longest lane
-            if (used == 0) break;
+            F cprod;
+            int cnt = 0;
+            const int used = r == 1 ? TreeFwd<F, true>::run(table, ent, in, w, pref, desc, stride, cprod, cnt, dbg)
+                                    : TreeFwd<F, false>::run(table, ent, in, w, pref, desc, stride, cprod, cnt, dbg);
+            if (used == 0) break;                                // wave-uniform: the longest lane
             if (dbg & 32) { if (used < TREE_CH) break; continue; }      // timing experiment: forward pass only (results are garbage)
-            // ---- one inversion per thread
-            F inv = (dbg & 1) ? cprod.inv() : field_inv_shared<F>(cprod);
-#if defined(__HIP_DEVICE_COMPILE__)
-            if (dbg & 2) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
-#endif
-            // ---- backward
-            for (int j = used - 1; j >= 0; j--) {
-                if (j < cnt) {
-                    const uint4 d = desc[(size_t)j * stride];
-                    const F cbefore = pref[(size_t)j * stride];
-                    const bool has1 = d.y != TREE_ABSENT;
-                    Affine<F> p0, p1 = Affine<F>::inf();
-                    if (r == 1) {
-                        p0 = tree_load_entry(table, d.x);
-                        if (has1) p1 = tree_load_entry(table, d.y);
-                    } else {
-                        p0 = in[d.x];
-                        if (has1) p1 = in[d.y];
-                    }
-                    const PairKind<F> kd = pair_kind(p0, p1);
-                    Affine<F> res;
-                    if (kd.generic || kd.dbl) {
-                        const F den = kd.generic ? p1.x - p0.x : p0.y.dbl();
-                        const F dinv = inv * cbefore;
-                        inv = inv * den;
-                        F num;
-                        if (kd.generic) num = p1.y - p0.y;
-                        else { const F xx = p0.x.sqr(); num = xx.dbl() + xx; }
-                        const F lam = num * dinv;
-                        res.x = lam.sqr() - p0.x - p1.x;
-                        res.y = lam * (p0.x - res.x) - p0.y;
-                    } else {                                     // den = 1: inv unchanged
-                        res = kd.inf0 ? p1 : (kd.inf1 ? p0 : Affine<F>::inf());
-                    }
-                    if (d.z & TREE_FINAL) out_final[d.z & ~TREE_FINAL] = res;
-                    else out[d.z] = res;
-                }
-            }
-#if defined(__HIP_DEVICE_COMPILE__)
-            if (dbg & 2) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
-#endif
+            // ---- one inversion per thread and chunk
+            const F inv = (dbg & 1) ? cprod.inv() : field_inv_shared<F>(cprod);
+            if (r == 1) TreeBwd<F, true>::run(table, in, out, out_final, pref, desc, stride, inv, used, cnt);
+            else TreeBwd<F, false>::run(table, in, out, out_final, pref, desc, stride, inv, used, cnt);
             if (used < TREE_CH) break;                           // every lane ran out of pairs inside this chunk
         }
         if (!tree_any(w.more)) break;
