@@ -133,6 +133,8 @@ int zkp_fold_quotient_bases(int logn, long ncons, const uint8_t *z, uint8_t *ze,
  * written to out_rows / out_points (union of rows_k and the term wires, ascending), -1 on error. */
 long zkp_fold_output_matrix(long nzc, const uint8_t *zc, long nk, const uint8_t *k, const uint32_t *rows_k, long nterms, const uint32_t *terms,
                             long ncoeff, const uint8_t *coeffs, uint32_t *out_rows, uint8_t *out_points);
+/* device time (ms) of the prover's transform stage -- inverse + coset-forward NTT of two [2^logn][batch] matrices -- mean of iters runs */
+double zkp_bench_to_coset(int logn, long batch, int iters);
 /* field 0 = Fp, 1 = Fr; in / out: n canonical LE 32-byte elements; out[i] = in[i]^-1 (0 -> 0) by the device's binary-GCD inversion */
 int zkp_field_inv(int field, long n, const uint8_t *in, uint8_t *out);
 /* kind 0: Fp mul (2/iter) 1: G1 mixed add 2: G2 mixed add 3: Fp Fermat inversion 4: Fp binary-GCD inversion; returns milliseconds */

@@ -50,6 +50,8 @@ _sig("zkp_fold_quotient_bases", _i32, [_i32, _i64, _vp, _vp, _vp])
 _sig("zkp_fold_output_matrix", _i64, [_i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp])
 _sig("zkp_microbench", C.c_double, [_i32, _i64, _i32])
 _sig("zkp_field_inv", _i32, [_i32, _i64, _vp, _vp])
+_sig("zkp_bench_to_coset", C.c_double, [_i32, _i64, _i32])
+_sig("zkp_debug_tree", _i32, [_i32, _i32, _i32, _i32])
 
 
 def last_error() -> str:

@@ -100,7 +100,77 @@ struct Field {
 #pragma unroll
         for (int i = 0; i < 8; i++) t[i] = borrow ? t[i] : d[i];
     }
+#if defined(__HIP_DEVICE_COMPILE__)
+    // r = a + b as 256-bit integers (a, b < M: no carry out)
+    static ZK_D void asm_add(Field &r, const Field &a, const Field &b) {
+        if constexpr (P::ID == 0) {
+            asm(ZK_ADD_ASM_FP
+                : "=&v"(r.l[0]), "=&v"(r.l[1]), "=&v"(r.l[2]), "=&v"(r.l[3]), "=&v"(r.l[4]), "=&v"(r.l[5]), "=&v"(r.l[6]), "=&v"(r.l[7])
+                : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]),
+                  "v"(b.l[0]), "v"(b.l[1]), "v"(b.l[2]), "v"(b.l[3]), "v"(b.l[4]), "v"(b.l[5]), "v"(b.l[6]), "v"(b.l[7])
+                : "vcc");
+        } else {
+            asm(ZK_ADD_ASM_FR
+                : "=&v"(r.l[0]), "=&v"(r.l[1]), "=&v"(r.l[2]), "=&v"(r.l[3]), "=&v"(r.l[4]), "=&v"(r.l[5]), "=&v"(r.l[6]), "=&v"(r.l[7])
+                : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]),
+                  "v"(b.l[0]), "v"(b.l[1]), "v"(b.l[2]), "v"(b.l[3]), "v"(b.l[4]), "v"(b.l[5]), "v"(b.l[6]), "v"(b.l[7])
+                : "vcc");
+        }
+    }
+    // r < 2M -> r mod M
+    static ZK_D void asm_reduce(Field &r) {
+        uint32_t d0, d1, d2, d3, d4, d5, d6, d7;
+        if constexpr (P::ID == 0) {
+            asm(ZK_RED_ASM_FP
+                : "+v"(r.l[0]), "+v"(r.l[1]), "+v"(r.l[2]), "+v"(r.l[3]), "+v"(r.l[4]), "+v"(r.l[5]), "+v"(r.l[6]), "+v"(r.l[7]),
+                  "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4), "=&v"(d5), "=&v"(d6), "=&v"(d7)
+                :
+                : "vcc");
+        } else {
+            asm(ZK_RED_ASM_FR
+                : "+v"(r.l[0]), "+v"(r.l[1]), "+v"(r.l[2]), "+v"(r.l[3]), "+v"(r.l[4]), "+v"(r.l[5]), "+v"(r.l[6]), "+v"(r.l[7]),
+                  "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4), "=&v"(d5), "=&v"(d6), "=&v"(d7)
+                :
+                : "vcc");
+        }
+    }
+    // r = a - b mod M
+    static ZK_D void asm_sub(Field &r, const Field &a, const Field &b) {
+        uint32_t m, d0, d1, d2, d3, d4, d5, d6, d7;
+        if constexpr (P::ID == 0) {
+            asm(ZK_SUB_ASM_FP
+                : "=&v"(r.l[0]), "=&v"(r.l[1]), "=&v"(r.l[2]), "=&v"(r.l[3]), "=&v"(r.l[4]), "=&v"(r.l[5]), "=&v"(r.l[6]), "=&v"(r.l[7]), "=&v"(m)
+                : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]),
+                  "v"(b.l[0]), "v"(b.l[1]), "v"(b.l[2]), "v"(b.l[3]), "v"(b.l[4]), "v"(b.l[5]), "v"(b.l[6]), "v"(b.l[7])
+                : "vcc");
+            asm(ZK_SUBFIX_ASM_FP
+                : "+v"(r.l[0]), "+v"(r.l[1]), "+v"(r.l[2]), "+v"(r.l[3]), "+v"(r.l[4]), "+v"(r.l[5]), "+v"(r.l[6]), "+v"(r.l[7]),
+                  "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4), "=&v"(d5), "=&v"(d6), "=&v"(d7)
+                : "v"(m)
+                : "vcc");
+        } else {
+            asm(ZK_SUB_ASM_FR
+                : "=&v"(r.l[0]), "=&v"(r.l[1]), "=&v"(r.l[2]), "=&v"(r.l[3]), "=&v"(r.l[4]), "=&v"(r.l[5]), "=&v"(r.l[6]), "=&v"(r.l[7]), "=&v"(m)
+                : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]),
+                  "v"(b.l[0]), "v"(b.l[1]), "v"(b.l[2]), "v"(b.l[3]), "v"(b.l[4]), "v"(b.l[5]), "v"(b.l[6]), "v"(b.l[7])
+                : "vcc");
+            asm(ZK_SUBFIX_ASM_FR
+                : "+v"(r.l[0]), "+v"(r.l[1]), "+v"(r.l[2]), "+v"(r.l[3]), "+v"(r.l[4]), "+v"(r.l[5]), "+v"(r.l[6]), "+v"(r.l[7]),
+                  "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4), "=&v"(d5), "=&v"(d6), "=&v"(d7)
+                : "v"(m)
+                : "vcc");
+        }
+    }
+#endif
     friend ZK_HD Field operator+(const Field &a, const Field &b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // gfx950: 8 add-with-carry + 8 for the trial subtraction + 8 selects (hipcc turns the portable loop below into ~100
+        // instructions of 64-bit arithmetic); two asm statements because one takes at most 30 operands
+        Field r;
+        asm_add(r, a, b);
+        asm_reduce(r);
+        return r;
+#else
         Field r;
         uint32_t c = 0;
 #pragma unroll
@@ -112,8 +182,14 @@ struct Field {
         // M < 2^254 so a+b < 2^255: no carry out of 256 bits
         reduce_once(r.l);
         return r;
+#endif
     }
     friend ZK_HD Field operator-(const Field &a, const Field &b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        Field r;
+        asm_sub(r, a, b);
+        return r;
+#else
         Field r;
         uint32_t borrow = 0;
 #pragma unroll
@@ -130,6 +206,7 @@ struct Field {
             c = (uint32_t)(x >> 32);
         }
         return r;
+#endif
     }
     ZK_HD Field neg() const {
         if (is_zero()) return *this;
@@ -159,17 +236,16 @@ struct Field {
                          : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
                          : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]),
                            "v"(b.l[0]), "v"(b.l[1]), "v"(b.l[2]), "v"(b.l[3]), "v"(b.l[4]), "v"(b.l[5]), "v"(b.l[6]), "v"(b.l[7])
-                         : "v16", "v17", "v18", "v19", "s16", "s17", "s18", "s19", "s20", "s21", "s22", "s23", "s24", "vcc");
+                         : "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "s16", "s17", "s18", "s19", "s20", "s21", "s22", "s23", "s24", "vcc");
         } else {
             asm volatile(ZK_MUL_ASM_FR
                          : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
                          : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]),
                            "v"(b.l[0]), "v"(b.l[1]), "v"(b.l[2]), "v"(b.l[3]), "v"(b.l[4]), "v"(b.l[5]), "v"(b.l[6]), "v"(b.l[7])
-                         : "v16", "v17", "v18", "v19", "s16", "s17", "s18", "s19", "s20", "s21", "s22", "s23", "s24", "vcc");
+                         : "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "s16", "s17", "s18", "s19", "s20", "s21", "s22", "s23", "s24", "vcc");
         }
-        Field r;
+        Field r;        // the block ends with the conditional subtraction of the modulus
         r.l[0] = t0; r.l[1] = t1; r.l[2] = t2; r.l[3] = t3; r.l[4] = t4; r.l[5] = t5; r.l[6] = t6; r.l[7] = t7;
-        reduce_once(r.l);
         return r;
 #else
         // portable CIOS (host compilation only; the product never multiplies on the host)

@@ -66,13 +66,79 @@ def gen(mod):
     return L
 
 
+def limbs(v):
+    return [(v >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
+
+
+def gen_reduce(mod, r, d):
+    """r (8 register names, value < 2 mod) -> r mod `mod`; d = 8 scratch registers.
+    d = r + (2^256 - mod): the carry out of the top limb says r >= mod."""
+    neg = limbs((1 << 256) - mod)
+    # a literal (or an SGPR) next to the carry in VCC would be two constant-bus reads: the constant goes through the scratch VGPRs
+    L = ["v_mov_b32_e32 %s, 0x%08x" % (d[i], neg[i]) for i in range(8)]
+    L.append("v_add_co_u32_e32 %s, vcc, %s, %s" % (d[0], d[0], r[0]))
+    for i in range(1, 8):
+        L.append("v_addc_co_u32_e32 %s, vcc, %s, %s, vcc" % (d[i], d[i], r[i]))
+    for i in range(8):
+        L.append("v_cndmask_b32_e32 %s, %s, %s, vcc" % (r[i], r[i], d[i]))
+    return L
+
+
+def gen_add(mod):
+    """carry chain only: %0-%7 r = a + b (no reduction), %8-%15 a, %16-%23 b; followed by ZK_RED_ASM"""
+    r = ["%%%d" % i for i in range(8)]
+    a = ["%%%d" % (8 + i) for i in range(8)]
+    b = ["%%%d" % (16 + i) for i in range(8)]
+    L = ["v_add_co_u32_e32 %s, vcc, %s, %s" % (r[0], a[0], b[0])]
+    for i in range(1, 8):
+        L.append("v_addc_co_u32_e32 %s, vcc, %s, %s, vcc" % (r[i], a[i], b[i]))
+    return L
+
+
+def gen_sub(mod):
+    """%0-%7 r = a - b mod 2^256, %8 = all ones iff it borrowed, %9-%16 a, %17-%24 b; followed by ZK_SUBFIX_ASM"""
+    r = ["%%%d" % i for i in range(8)]
+    m = "%8"
+    a = ["%%%d" % (9 + i) for i in range(8)]
+    b = ["%%%d" % (17 + i) for i in range(8)]
+    L = ["v_sub_co_u32_e32 %s, vcc, %s, %s" % (r[0], a[0], b[0])]
+    for i in range(1, 8):
+        L.append("v_subb_co_u32_e32 %s, vcc, %s, %s, vcc" % (r[i], a[i], b[i]))
+    L.append("v_subb_co_u32_e64 %s, vcc, 0, 0, vcc" % m)
+    return L
+
+
+def gen_subfix(mod):
+    """%0-%7 r (in/out) += mod & mask, %8-%15 scratch (out), %16 mask (in; operand numbering: the tied inputs of r come after it)"""
+    r = ["%%%d" % i for i in range(8)]
+    d = ["%%%d" % (8 + i) for i in range(8)]
+    m = "%16"
+    ml = limbs(mod)
+    L = []
+    for i in range(8):
+        L.append("v_and_b32_e32 %s, 0x%08x, %s" % (d[i], ml[i], m))
+    L.append("v_add_co_u32_e32 %s, vcc, %s, %s" % (r[0], r[0], d[0]))
+    for i in range(1, 8):
+        L.append("v_addc_co_u32_e32 %s, vcc, %s, %s, vcc" % (r[i], r[i], d[i]))
+    return L
+
+
 def main():
     out = ["// GENERATED by gen_mul_asm.py -- do not edit.",
-           "// clobbers: v16-v19, s16-s24, vcc"]
+           "// ZK_MUL_ASM_*: clobbers v16-v27, s16-s24, vcc; the product leaves the block fully reduced",
+           "// ZK_ADD_ASM_* + ZK_RED_ASM_* = modular addition, ZK_SUB_ASM_* + ZK_SUBFIX_ASM_* = modular subtraction (two statements each:",
+           "// an asm statement takes at most 30 operands); they clobber vcc only, scratch registers are operands"]
     for name, mod in (("FP", P), ("FR", R)):
-        lines = gen(mod)
+        lines = gen(mod) + gen_reduce(mod, ["%%%d" % i for i in range(8)], ["v%d" % (20 + i) for i in range(8)])
         out.append("#define ZK_MUL_ASM_%s \\" % name)
         out.append(" \\\n".join('    "%s\\n\\t"' % l for l in lines))
+        out.append("")
+        for tag, fn in (("ADD", gen_add), ("SUB", gen_sub), ("SUBFIX", gen_subfix)):
+            out.append("#define ZK_%s_ASM_%s \\" % (tag, name))
+            out.append(" \\\n".join('    "%s\\n\\t"' % l for l in fn(mod)))
+            out.append("")
+        out.append("#define ZK_RED_ASM_%s \\" % name)
+        out.append(" \\\n".join('    "%s\\n\\t"' % l for l in gen_reduce(mod, ["%%%d" % i for i in range(8)], ["%%%d" % (8 + i) for i in range(8)])))
         out.append("")
     open("field_mul_asm.inc", "w").write("\n".join(out) + "\n")
     print("MACs per mul:", sum(1 for l in gen(P) if "v_mad_u64_u32" in l), "instructions:", len(gen(P)))

@@ -165,22 +165,29 @@ __global__ __launch_bounds__(256) void k_ntt_dit(Fr *__restrict__ data, size_t B
 // (TI * 2^(K1+K2) * 32 B = 64 KiB of LDS), does K1 butterfly stages in registers, exchanges through LDS and does
 // K2 more -- K1+K2 = 5..6 stages per HBM round trip instead of 3 (N = 2^16: 3 passes instead of 6).
 // Global accesses stay instance-contiguous (TI * 32 B segments).
+// TOTAL = field elements per tile (x 32 B of LDS); the workgroup has one thread per 8 of them, i.e. TOTAL / 8 threads.
+// Smaller tiles = more, smaller workgroups per CU in different phases (load / butterflies / store) at the same LDS footprint.
+#ifndef ZK_NTT_TILE
+#define ZK_NTT_TILE 2048
+#endif
 template <int K1, int K2>
 struct LdsTile {
     static constexpr int K = K1 + K2;
     static constexpr int E = 1 << K;               // elements per tile
-    static constexpr int TI = 2048 / E;            // instances per tile (E * TI = 2048 field elements = 64 KiB)
-    static constexpr int THREADS = 256;
-    static_assert(E * TI == 2048 && TI >= 1, "tile shape");
+    static constexpr int TOTAL = ZK_NTT_TILE;
+    static constexpr int TI = TOTAL / E;           // instances per tile
+    static constexpr int THREADS = TOTAL / 8;
+    static constexpr int LDS_BYTES = TOTAL * 32;
+    static_assert(E * TI == TOTAL && TI >= 1, "tile shape");
 };
 
 // DIF: stages loglen .. loglen-K+1 (block lengths len, len/2, ...).  Element e of the tile sits at
 // pos = blk*len + p + e*S with S = len >> K.
 template <int K1, int K2>
-__global__ __launch_bounds__(256) void k_ntt_dif_lds(Fr *__restrict__ data, size_t B, int logn, int loglen, const Fr *__restrict__ tw,
+__global__ __launch_bounds__(ZK_NTT_TILE / 8) void k_ntt_dif_lds(Fr *__restrict__ data, size_t B, int logn, int loglen, const Fr *__restrict__ tw,
                                                      const Fr *__restrict__ postmul) {
     using T = LdsTile<K1, K2>;
-    constexpr int K = T::K, E = T::E, TI = T::TI, R1 = 1 << K1, R2 = 1 << K2;
+    constexpr int K = T::K, E = T::E, TI = T::TI, R1 = 1 << K1, R2 = 1 << K2, NT = T::THREADS;
     extern __shared__ uint4 lds_raw[];
     Fr *lds = (Fr *)lds_raw;                       // [E][TI]
     const int tid = threadIdx.x;
@@ -195,7 +202,7 @@ __global__ __launch_bounds__(256) void k_ntt_dif_lds(Fr *__restrict__ data, size
     // ---- stage group A: thread holds e = q + R2' * m (R2' = E / R1), distances E/2 .. R2'
     {
         constexpr int STR = E / R1;                // element stride inside the thread's set
-        for (int q = tid / TI; q < STR; q += 256 / TI) {
+        for (int q = tid / TI; q < STR; q += NT / TI) {
             Fr x[R1];
 #pragma unroll
             for (int m = 0; m < R1; m++) {
@@ -223,7 +230,7 @@ __global__ __launch_bounds__(256) void k_ntt_dif_lds(Fr *__restrict__ data, size
     __syncthreads();
     // ---- stage group B: thread holds e = q2 * R2 + m, distances R2/2 .. 1
     {
-        for (int q2 = tid / TI; q2 < E / R2; q2 += 256 / TI) {
+        for (int q2 = tid / TI; q2 < E / R2; q2 += NT / TI) {
             Fr x[R2];
 #pragma unroll
             for (int m = 0; m < R2; m++) x[m] = lds[((size_t)q2 * R2 + m) * TI + bl];
@@ -256,10 +263,10 @@ __global__ __launch_bounds__(256) void k_ntt_dif_lds(Fr *__restrict__ data, size
 
 // DIT: stages with half-distances S, 2S, ... (S = 2^logS), tile element e at pos = blk*(S<<K) + p + e*S.
 template <int K1, int K2>
-__global__ __launch_bounds__(256) void k_ntt_dit_lds(Fr *__restrict__ data, size_t B, int logn, int logS, const Fr *__restrict__ tw,
+__global__ __launch_bounds__(ZK_NTT_TILE / 8) void k_ntt_dit_lds(Fr *__restrict__ data, size_t B, int logn, int logS, const Fr *__restrict__ tw,
                                                      const Fr *__restrict__ premul) {
     using T = LdsTile<K1, K2>;
-    constexpr int K = T::K, E = T::E, TI = T::TI, R1 = 1 << K1, R2 = 1 << K2;
+    constexpr int K = T::K, E = T::E, TI = T::TI, R1 = 1 << K1, R2 = 1 << K2, NT = T::THREADS;
     extern __shared__ uint4 lds_raw[];
     Fr *lds = (Fr *)lds_raw;
     const int tid = threadIdx.x;
@@ -272,7 +279,7 @@ __global__ __launch_bounds__(256) void k_ntt_dit_lds(Fr *__restrict__ data, size
     const bool active = b < B;
     // ---- group A: consecutive elements e = q * R1 + m, distances 1 .. R1/2
     {
-        for (int q = tid / TI; q < E / R1; q += 256 / TI) {
+        for (int q = tid / TI; q < E / R1; q += NT / TI) {
             Fr x[R1];
 #pragma unroll
             for (int m = 0; m < R1; m++) {
@@ -302,7 +309,7 @@ __global__ __launch_bounds__(256) void k_ntt_dit_lds(Fr *__restrict__ data, size
     __syncthreads();
     // ---- group B: strided elements e = q2 + R1 * m, distances R1 .. E/2
     {
-        for (int q2 = tid / TI; q2 < R1; q2 += 256 / TI) {
+        for (int q2 = tid / TI; q2 < R1; q2 += NT / TI) {
             Fr x[R2];
 #pragma unroll
             for (int m = 0; m < R2; m++) x[m] = lds[((size_t)q2 + (size_t)R1 * m) * TI + bl];
@@ -332,17 +339,17 @@ template <int K1, int K2>
 static void launch_dif_lds(Fr *data, size_t B, int logn, int loglen, const Fr *tw, const Fr *postmul, hipStream_t s) {
     using T = LdsTile<K1, K2>;
     static PerDeviceOnce attr;
-    attr.run([] { ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_dif_lds<K1, K2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); });
+    attr.run([] { ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_dif_lds<K1, K2>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES)); });
     dim3 grid((unsigned)(((size_t)1 << logn) >> T::K), ceil_div(B, T::TI));
-    hipLaunchKernelGGL((k_ntt_dif_lds<K1, K2>), grid, dim3(256), 65536, s, data, B, logn, loglen, tw, postmul);
+    hipLaunchKernelGGL((k_ntt_dif_lds<K1, K2>), grid, dim3(T::THREADS), T::LDS_BYTES, s, data, B, logn, loglen, tw, postmul);
 }
 template <int K1, int K2>
 static void launch_dit_lds(Fr *data, size_t B, int logn, int logS, const Fr *tw, const Fr *premul, hipStream_t s) {
     using T = LdsTile<K1, K2>;
     static PerDeviceOnce attr;
-    attr.run([] { ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_dit_lds<K1, K2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); });
+    attr.run([] { ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_dit_lds<K1, K2>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES)); });
     dim3 grid((unsigned)(((size_t)1 << logn) >> T::K), ceil_div(B, T::TI));
-    hipLaunchKernelGGL((k_ntt_dit_lds<K1, K2>), grid, dim3(256), 65536, s, data, B, logn, logS, tw, premul);
+    hipLaunchKernelGGL((k_ntt_dit_lds<K1, K2>), grid, dim3(T::THREADS), T::LDS_BYTES, s, data, B, logn, logS, tw, premul);
 }
 
 template <int K>

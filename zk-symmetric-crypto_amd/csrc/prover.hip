@@ -324,6 +324,89 @@ __global__ void k_store_commit(const G1Affine *com, const G1Affine *pok, ProofPo
     }
 }
 
+
+// ------------------------------------------------------------------------- BSB22 challenge on the device
+// challenge = fr.Hash(commitment.Marshal(), "bsb22-commitment", 1)[0]  (gnark backend/groth16/bn254/prove.go; gnark-crypto
+// field/hash: RFC 9380 expand_message_xmd with SHA-256, 48 bytes, big-endian, reduced mod r).  One thread per proof: five
+// SHA-256 compressions and one 384-bit reduction; keeps the solve stage stream-ordered (no device-host round trip in the
+// middle of the witness solve).  Same bytes as hostutil.cpp::hash_to_fr, which the parity tests pin against the oracle.
+__device__ __forceinline__ uint32_t sha_rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+__device__ void sha256_block(uint32_t st[8], const uint32_t w_in[16]) {
+    static const uint32_t K[64] = {
+        0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3,
+        0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+        0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13,
+        0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+        0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+        0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+    uint32_t w[64];
+    for (int i = 0; i < 16; i++) w[i] = w_in[i];
+    for (int i = 16; i < 64; i++) {
+        const uint32_t s0 = sha_rotr(w[i - 15], 7) ^ sha_rotr(w[i - 15], 18) ^ (w[i - 15] >> 3);
+        const uint32_t s1 = sha_rotr(w[i - 2], 17) ^ sha_rotr(w[i - 2], 19) ^ (w[i - 2] >> 10);
+        w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+    }
+    uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+    for (int i = 0; i < 64; i++) {
+        const uint32_t S1 = sha_rotr(e, 6) ^ sha_rotr(e, 11) ^ sha_rotr(e, 25);
+        const uint32_t ch = (e & f) ^ (~e & g);
+        const uint32_t t1 = h + S1 + ch + K[i] + w[i];
+        const uint32_t S0 = sha_rotr(a, 2) ^ sha_rotr(a, 13) ^ sha_rotr(a, 22);
+        const uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
+        const uint32_t t2 = S0 + mj;
+        h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
+}
+__device__ __forceinline__ void sha256_iv(uint32_t st[8]) {
+    st[0] = 0x6a09e667; st[1] = 0xbb67ae85; st[2] = 0x3c6ef372; st[3] = 0xa54ff53a; st[4] = 0x510e527f; st[5] = 0x9b05688c; st[6] = 0x1f83d9ab; st[7] = 0x5be0cd19;
+}
+// com: canonical affine commitments (little-endian limbs; infinity = zeros, serialised as zero bytes like the host code);
+// challenge: Montgomery form, as the solver reads it
+__global__ __launch_bounds__(64) void k_bsb22_challenge(const G1Affine *__restrict__ com, Fr *__restrict__ challenge, size_t B) {
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t DST[4] = {0x62736232u, 0x322d636fu, 0x6d6d6974u, 0x6d656e74u};      // "bsb22-commitment", big-endian words
+    // msg = X || Y, 32-byte big-endian each = limbs 7..0 as big-endian words
+    uint32_t m[16];
+    for (int i = 0; i < 8; i++) { m[i] = com[b].x.l[7 - i]; m[8 + i] = com[b].y.l[7 - i]; }
+    uint32_t b0[8], b1[8], b2[8], w[16];
+    // b0 = H(Z_pad(64) || msg(64) || 0x0030 || 0x00 || DST || 0x10): 148 bytes -> 3 blocks
+    sha256_iv(b0);
+    for (int i = 0; i < 16; i++) w[i] = 0;
+    sha256_block(b0, w);
+    sha256_block(b0, m);
+    w[0] = 0x00300000u | (DST[0] >> 24);                                            // 00 30 00 'b'
+    w[1] = (DST[0] << 8) | (DST[1] >> 24); w[2] = (DST[1] << 8) | (DST[2] >> 24); w[3] = (DST[2] << 8) | (DST[3] >> 24);
+    w[4] = (DST[3] << 8) | 0x10u;                                                   // ... 't' 0x10
+    w[5] = 0x80000000u;
+    for (int i = 6; i < 15; i++) w[i] = 0;
+    w[15] = 148 * 8;
+    sha256_block(b0, w);
+    // b_i = H((b0 ^ b_{i-1}) || i || DST || 0x10): 50 bytes -> 1 block
+    auto tail_block = [&](const uint32_t in[8], uint32_t idx, uint32_t out[8]) {
+        uint32_t t[16];
+        for (int i = 0; i < 8; i++) t[i] = in[i];
+        t[8] = (idx << 24) | (DST[0] >> 8);
+        t[9] = (DST[0] << 24) | (DST[1] >> 8); t[10] = (DST[1] << 24) | (DST[2] >> 8); t[11] = (DST[2] << 24) | (DST[3] >> 8);
+        t[12] = (DST[3] << 24) | (0x10u << 16) | 0x8000u;
+        t[13] = 0; t[14] = 0; t[15] = 50 * 8;
+        sha256_iv(out);
+        sha256_block(out, t);
+    };
+    tail_block(b0, 1, b1);
+    uint32_t x[8];
+    for (int i = 0; i < 8; i++) x[i] = b0[i] ^ b1[i];
+    tail_block(x, 2, b2);
+    // uniform = b1 || b2[0..15] as a 384-bit big-endian integer = hi * 2^256 + lo, hi = first 16 bytes
+    Fr hi = Fr::zero(), lo;
+    for (int i = 0; i < 4; i++) hi.l[3 - i] = b1[i];
+    for (int i = 0; i < 4; i++) lo.l[7 - i] = b1[4 + i];
+    for (int i = 0; i < 4; i++) lo.l[3 - i] = b2[i];
+    // Montgomery form of (hi R + lo) mod r  (R = 2^256; to_mont accepts any 256-bit operand)
+    challenge[b] = hi.to_mont().to_mont() + lo.to_mont();
+}
+
 // ------------------------------------------------------------------------------- pipeline
 void Algorithm::resident_reserve(size_t B) {
     bind_device(device);
@@ -433,17 +516,8 @@ void Algorithm::enqueue_solve(SolveSet &S, MsmScratch &commit_scratch, hipStream
             g1_to_affine_canonical(S.m_com.p, S.com_aff.p, B, st);
             g1_to_affine_canonical(S.m_pok.p, S.pok_aff.p, B, st);
         }
-        ZK_HIP(hipMemcpyAsync(S.h_com.data(), S.com_aff.p, B * sizeof(G1Affine), hipMemcpyDeviceToHost, st));
-        ZK_HIP(hipStreamSynchronize(st));
-        for (size_t b = 0; b < B; b++) {
-            uint8_t ser[64];
-            U256 x, y;
-            memcpy(x.l, S.h_com[b].x.l, 32); memcpy(y.l, S.h_com[b].y.l, 32);
-            u256_to_be(x, ser); u256_to_be(y, ser + 32);
-            S.h_chal[b] = hash_to_fr(ser, 64, "bsb22-commitment");
-        }
-        ZK_HIP(hipMemcpyAsync(S.chal.p, S.h_chal.data(), B * sizeof(U256), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_u256_to_mont, dim3(ceil_div(B, 64)), dim3(64), 0, st, S.chal.p, S.sb.challenge.p, B);
+        // challenge = H2F(C.Marshal(), "bsb22-commitment") on the device: the solve stage stays stream-ordered
+        hipLaunchKernelGGL(k_bsb22_challenge, dim3(ceil_div(B, 64)), dim3(64), 0, st, S.com_aff.p, S.sb.challenge.p, B);
         ZK_HIP(hipEventRecord(S.t2, st));
         solver_run_levels(prog, S.sb, commit_level, prog.levels.size(), st);
     } else {

@@ -327,6 +327,29 @@ extern "C" double zkp_microbench(int kind, long threads, int iters) {
     ZKP_CATCH(-1.0)
 }
 
+// milliseconds per to_coset() of a and b (the prover's 4 transforms) over `batch` instances of 2^logn elements, mean of iters
+extern "C" double zkp_bench_to_coset(int logn, long batch, int iters) {
+    ZKP_TRY
+    const size_t n = (size_t)1 << logn, B = (size_t)batch;
+    NttDomain dom;
+    dom.init(logn, 0);
+    DevBuf<Fr> a(n * B), b(n * B);
+    ZK_HIP(hipMemset(a.p, 0x11, n * B * sizeof(Fr)));
+    ZK_HIP(hipMemset(b.p, 0x07, n * B * sizeof(Fr)));
+    hipEvent_t e0, e1;
+    ZK_HIP(hipEventCreate(&e0)); ZK_HIP(hipEventCreate(&e1));
+    dom.to_coset(a.p, b.p, B, 0);
+    ZK_HIP(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; i++) dom.to_coset(a.p, b.p, B, 0);
+    ZK_HIP(hipEventRecord(e1, 0));
+    ZK_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    ZK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return ms / iters;
+    ZKP_CATCH(-1.0)
+}
+
 // ---- debug harness: device tree kernel vs. host emulation of the same code on host-sorted input (prints per-bucket diffs)
 #include "msm_tree.cuh"
 #include <random>
