@@ -226,10 +226,10 @@ struct Field {
     friend ZK_HD Field operator*(const Field &a, const Field &b) { return mul_impl(a, b); }
     // Out-of-line on purpose: one copy of the ~400-instruction body per field keeps kernels small
     // (instruction cache) and compile times sane; operands travel in VGPRs (by value).
-    static __host__ __device__ __attribute__((noinline)) Field mul_impl(Field a, Field b) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        // gfx950: one inline-asm block (generated by gen_mul_asm.py): FIPS Montgomery with
-        // v_mad_u64_u32 + v_addc_co_u32 carry pairs; +44 % over the compiled CIOS loop below.
+    // the multiplier block itself (generated by gen_mul_asm.py): FIPS Montgomery with v_mad_u64_u32 + v_addc_co_u32 carry
+    // pairs, ending with the conditional subtraction of the modulus; +44 % over the compiled CIOS loop
+    static ZK_D Field mul_block(const Field &a, const Field &b) {
         uint32_t t0, t1, t2, t3, t4, t5, t6, t7;
         if constexpr (P::ID == 0) {
             asm volatile(ZK_MUL_ASM_FP
@@ -244,9 +244,23 @@ struct Field {
                            "v"(b.l[0]), "v"(b.l[1]), "v"(b.l[2]), "v"(b.l[3]), "v"(b.l[4]), "v"(b.l[5]), "v"(b.l[6]), "v"(b.l[7])
                          : "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "s16", "s17", "s18", "s19", "s20", "s21", "s22", "s23", "s24", "vcc");
         }
-        Field r;        // the block ends with the conditional subtraction of the modulus
+        Field r;
         r.l[0] = t0; r.l[1] = t1; r.l[2] = t2; r.l[3] = t3; r.l[4] = t4; r.l[5] = t5; r.l[6] = t6; r.l[7] = t7;
         return r;
+    }
+#endif
+    // a * b with the multiplier block expanded in place: for the few innermost loops (bucket accumulation) where the 24 register
+    // moves of a call per multiplication show; everything else goes through the shared out-of-line copy below
+    static ZK_HD Field mul_inline(const Field &a, const Field &b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return mul_block(a, b);
+#else
+        return mul_impl(a, b);
+#endif
+    }
+    static __host__ __device__ __attribute__((noinline)) Field mul_impl(Field a, Field b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return mul_block(a, b);
 #else
         // portable CIOS (host compilation only; the product never multiplies on the host)
         uint32_t t[9];

@@ -492,23 +492,29 @@ __device__ __forceinline__ void accumulate_body(const Affine<F> *__restrict__ ta
         uint32_t v_next = 0;
         if (e_next < e_end) v_next = ent[e_next];
         if (v >> 31) p.y = p.y.neg();
-        acc.madd(p);
+        acc.template madd<true>(p);
         if (e_next >= e_end) break;
         e = e_next; v = v_next; p = table[v & 0x7fffffffu];
     }
     out[cur] = acc;
 }
+// Fp2 kernels: 2 wavefronts per SIMD (the unconstrained allocation takes 256 VGPRs plus a few AGPRs = 1 wavefront per SIMD, with
+// nothing to hide a 128-byte gather behind)
+#define ZK_FP2_WAVES(F) (sizeof(F) == 64 ? 2 : 1)
 template <class F, bool DENSE>
-__global__ __launch_bounds__(64) void k_msm_accumulate(const Affine<F> *__restrict__ table, const uint32_t *__restrict__ bucket_start,
+__global__ __launch_bounds__(64, ZK_FP2_WAVES(F)) void k_msm_accumulate(const Affine<F> *__restrict__ table, const uint32_t *__restrict__ bucket_start,
                                                        const uint32_t *__restrict__ entries, size_t max_entries, int c, size_t B,
                                                        uint32_t nlanes, XYZZ<F> *__restrict__ sums) {
     accumulate_body<F, DENSE>(table, bucket_start, entries, max_entries, c, B, nlanes, sums);
 }
 // G1: 3 wavefronts per SIMD (168 VGPRs, 64 B of scratch) hide the multiplier's dependent chains better than 2 at 190 VGPRs
 // (measured 111 vs 115 ms for the quotient MSM; 4 wavefronts at 128 VGPRs spill too much: 120 ms).  G2 needs all 256.
+#ifndef ZK_ACC_WAVES
+#define ZK_ACC_WAVES 3
+#endif
 #define ZK_ACC_G1(DENSE)                                                                                                                  \
     template <>                                                                                                                           \
-    __global__ __launch_bounds__(64, 3) void k_msm_accumulate<Fp, DENSE>(const Affine<Fp> *__restrict__ table, const uint32_t *__restrict__ bucket_start, \
+    __global__ __launch_bounds__(64, ZK_ACC_WAVES) void k_msm_accumulate<Fp, DENSE>(const Affine<Fp> *__restrict__ table, const uint32_t *__restrict__ bucket_start, \
                                                                          const uint32_t *__restrict__ entries, size_t max_entries, int c, size_t B,       \
                                                                          uint32_t nlanes, XYZZ<Fp> *__restrict__ sums) {                                  \
         accumulate_body<Fp, DENSE>(table, bucket_start, entries, max_entries, c, B, nlanes, sums);                                       \
@@ -557,7 +563,7 @@ __global__ __launch_bounds__(64) void k_msm_bucket_reduce(const XYZZ<F> *__restr
 // 20 additions per wavefront and chunk where adding the +-1 bases one by one took ~77 (49 % of the ChaCha wire scalars
 // are +-1, and a wavefront runs the maximum over its lanes).
 template <class F>
-__global__ __launch_bounds__(256) void k_msm_ones(const Affine<F> *__restrict__ tern, const Fr *__restrict__ scalars, size_t B,
+__global__ __launch_bounds__(256, ZK_FP2_WAVES(F)) void k_msm_ones(const Affine<F> *__restrict__ tern, const Fr *__restrict__ scalars, size_t B,
                                                   const uint32_t *__restrict__ rows, size_t n, XYZZ<F> *__restrict__ part,
                                                   size_t part_stride, size_t part_off, uint32_t *__restrict__ gen_count,
                                                   uint32_t *__restrict__ gen_idx, Fr *__restrict__ gen_val) {
@@ -658,7 +664,7 @@ void fr_transpose_mul(const Fr *x, const Fr *y, Fr *out, size_t rows, size_t B, 
 
 // out[b*out_stride + g] = sum_{i < group} in[b*in_stride + g*group + i]   (i bounded by count)
 template <class F>
-__global__ __launch_bounds__(64) void k_sum_groups(const XYZZ<F> *__restrict__ in, size_t in_stride, size_t count, size_t group,
+__global__ __launch_bounds__(64, ZK_FP2_WAVES(F)) void k_sum_groups(const XYZZ<F> *__restrict__ in, size_t in_stride, size_t count, size_t group,
                                                    XYZZ<F> *__restrict__ out, size_t out_stride, size_t B) {
     const size_t ngroups = (count + group - 1) / group;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
