@@ -114,8 +114,12 @@ void msm_bases_build(MsmBasesG2 &mb, const G2Affine *p, size_t n, const uint32_t
 // each, own buckets) so that its sort / accumulate / reduce chain has workgroups to spread over; the per-instance arrays are
 // therefore sized for at least VIRT_MIN instances.
 static constexpr size_t VIRT_MIN = 64, DENSE_SPLIT_MAX = 16;
-void MsmScratch::reserve_dense(size_t B_, size_t max_dense_entries) {
+void MsmScratch::reserve_dense(size_t B_, size_t max_dense_entries, size_t nb) {
     entries2.ensure(B_ * max_dense_entries + 1);
+    if (nb) {                                   // own sorted list of the dense MSM (see msm_dense_presort)
+        entries_z.ensure(B_ * max_dense_entries + 1);
+        bucket_start_z.ensure((B_ > VIRT_MIN ? B_ : VIRT_MIN) * (nb + 1));
+    }
     coarse_base.ensure((B_ > VIRT_MIN ? B_ : VIRT_MIN) * 257);
     vout1.ensure(VIRT_MIN + 1);
 }
@@ -685,8 +689,8 @@ static bool tree_enabled() {
     return on;
 }
 // accumulate + bucket reduction of one sorted dense MSM through the tree kernels (G1)
-static void launch_tree_g1(const MsmBasesG1 &mb, MsmScratch &sc, size_t max_entries, int c, size_t Bv, uint32_t nlanes, G1XYZZ *part, size_t stride,
-                           size_t part_off, uint32_t L, hipStream_t s, hipEvent_t *seg_events) {
+static void launch_tree_g1(const MsmBasesG1 &mb, MsmScratch &sc, const uint32_t *bs_p, const uint32_t *ent_p, size_t max_entries, int c, size_t Bv, uint32_t nlanes,
+                           G1XYZZ *part, size_t stride, size_t part_off, uint32_t L, hipStream_t s, hipEvent_t *seg_events) {
     const uint32_t nb = 1u << (c - 1);
     const size_t nseg = nb / L;
     const size_t capA = tree_capacity(max_entries, nb, nlanes, 1), capB = tree_capacity(max_entries, nb, nlanes, 2);
@@ -698,11 +702,11 @@ static void launch_tree_g1(const MsmBasesG1 &mb, MsmScratch &sc, size_t max_entr
         throw ZkError("msm tree scratch too small");
     if (dbg & 4) { ZK_HIP(hipMemsetAsync(sc.treeA1.p, 0, Bv * capA * sizeof(G1Affine), s)); ZK_HIP(hipMemsetAsync(sc.treeB1.p, 0, Bv * capB * sizeof(G1Affine), s)); }
     if (seg_events) ZK_HIP(hipEventRecord(seg_events[0], s));
-    hipLaunchKernelGGL((k_msm_tree<Fp, true>), dim3(grid), dim3(64), 0, s, mb.table.p, sc.bucket_start.p, sc.entries.p, max_entries, c, Bv, nlanes,
+    hipLaunchKernelGGL((k_msm_tree<Fp, true>), dim3(grid), dim3(64), 0, s, mb.table.p, bs_p, ent_p, max_entries, c, Bv, nlanes,
                        sc.treeA1.p, capA, sc.treeB1.p, capB, sc.fin1.p, sc.tree_scratch.p, dbg);
     if (seg_events) ZK_HIP(hipEventRecord(seg_events[1], s));
-    hipLaunchKernelGGL(k_msm_bucket_reduce_tree<Fp>, dim3(ceil_div(nseg * Bv, 64)), dim3(64), 0, s, sc.fin1.p, mb.table.p, sc.entries.p, max_entries,
-                       sc.bucket_start.p, c, Bv, part, stride, part_off, L);
+    hipLaunchKernelGGL(k_msm_bucket_reduce_tree<Fp>, dim3(ceil_div(nseg * Bv, 64)), dim3(64), 0, s, sc.fin1.p, mb.table.p, ent_p, max_entries,
+                       bs_p, c, Bv, part, stride, part_off, L);
 }
 
 template <class F>
@@ -748,7 +752,7 @@ static void msm_dense_split(const MsmBases<F> &mb, const Fr *scalars, size_t B, 
                            max_entries, c, sc.bucket_start.p);
         const uint32_t nlanes = accumulate_lanes(max_entries, Bv);
         if (tree_enabled() && sc.treeA1.n) {
-            launch_tree_g1(mb, sc, max_entries, c, Bv, nlanes, part, stride, (size_t)0, L, s, seg_events);
+            launch_tree_g1(mb, sc, sc.bucket_start.p, sc.entries.p, max_entries, c, Bv, nlanes, part, stride, (size_t)0, L, s, seg_events);
         } else {
             if (seg_events) ZK_HIP(hipEventRecord(seg_events[0], s));
             hipLaunchKernelGGL((k_msm_accumulate<F, true>), dim3(ceil_div((size_t)nlanes * Bv, 64)), dim3(64), 0, s, mb.table.p, sc.bucket_start.p, sc.entries.p,
@@ -772,6 +776,43 @@ static void msm_dense_split(const MsmBases<F> &mb, const Fr *scalars, size_t B, 
         (void)mb; (void)scalars; (void)B; (void)sc; (void)out; (void)s; (void)seg_events; (void)split;
         throw ZkError("split dense path is G1 only");
     }
+}
+
+// dense MSM, two-level sort applicable?  0 = no (single-level k_msm_sort<true>), 1 = yes, > 1 = yes with every instance of a small
+// batch split into that many virtual instances
+template <class F>
+static uint32_t dense_split_factor(const MsmBases<F> &mb, size_t B, const MsmScratch &sc) {
+    const int c = mb.c, W = mb.W;
+    const size_t n = mb.n, max_entries = n * W;
+    if (!(c - 1 > FINE_BITS && c - 1 - FINE_BITS <= 8 && W <= 24 && n * (size_t)W <= (1u << 21) && sc.entries2.n >= B * max_entries + 1)) return 0;
+    uint32_t split = 1;
+    if (sizeof(F) == 32 && sc.vout1.n > VIRT_MIN)
+        while (split < DENSE_SPLIT_MAX && B * split * 2 <= VIRT_MIN && (n % (split * 2)) == 0 && n / (split * 2) >= 4096) split *= 2;
+    return split;
+}
+template <class F>
+static void dense_two_level_sort(const MsmBases<F> &mb, const Fr *scalars, size_t B, MsmScratch &sc, uint32_t *ent_p, uint32_t *bs_p, hipStream_t s) {
+    const int c = mb.c, W = mb.W;
+    const size_t n = mb.n, max_entries = n * W;
+    const size_t lds2 = (size_t)(PART_THREADS / 64 * MAX_COARSE + (MAX_COARSE + 1) + 3 * MAX_COARSE + 2 * PART_THREADS * (size_t)W) * sizeof(uint32_t);
+    partition_attr();
+    sc.coarse_base.ensure(B * (MAX_COARSE + 1));
+    hipLaunchKernelGGL(k_msm_partition, dim3((unsigned)B), dim3(PART_THREADS), lds2, s, scalars, mb.dense_stride, n, c, W, sc.coarse_base.p,
+                       sc.entries2.p, max_entries, 1u);
+    hipLaunchKernelGGL(k_msm_binsort, dim3(1u << (c - 1 - FINE_BITS), (unsigned)B), dim3(256), 0, s, sc.coarse_base.p, sc.entries2.p, ent_p,
+                       max_entries, c, bs_p);
+}
+// Sort of the dense (quotient) MSM alone, on stream s, into the dense list buffers; the msm_batch call that follows (on a stream that
+// has waited for s) then starts at the accumulation.  Returns false (and does nothing) when the batch takes another sort path.
+bool msm_dense_presort(const MsmBasesG1 &mb, const Fr *scalars, size_t B, MsmScratch &sc, hipStream_t s) {
+    const size_t max_entries = mb.n * (size_t)mb.W;
+    const uint32_t nb = 1u << (mb.c - 1);
+    if (!mb.dense || mb.n == 0 || dense_split_factor(mb, B, sc) != 1) return false;
+    if (sc.entries_z.n < B * max_entries + 1 || sc.bucket_start_z.n < B * (size_t)(nb + 1)) return false;
+    dense_two_level_sort(mb, scalars, B, sc, sc.entries_z.p, sc.bucket_start_z.p, s);
+    ZK_HIP(hipGetLastError());
+    sc.presorted = true;
+    return true;
 }
 
 // fold the npart partial sums of every instance, FOLD_GROUP at a time; the last level writes out[b]
@@ -813,30 +854,30 @@ static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, M
         ZK_HIP(hipFuncSetAttribute((const void *)k_msm_sort<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
         ZK_HIP(hipFuncSetAttribute((const void *)k_msm_sort<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
     });
+    // the sorted list of the dense MSM lives in buffers of its own when they exist (entries_z): its sort may then run on another
+    // stream beside the wire MSMs (msm_dense_presort), which use entries / bucket_start
+    uint32_t *ent_p = sc.entries.p, *bs_p = sc.bucket_start.p;
+    if (mb.dense && sc.entries_z.n >= B * max_entries + 1 && sc.bucket_start_z.n >= B * (size_t)(nb + 1)) { ent_p = sc.entries_z.p; bs_p = sc.bucket_start_z.p; }
     if (mb.dense) {
         // scalars = instance-major [B][dense_stride] copy; no +-1 fast path (every quotient coefficient is wide)
-        if (c - 1 > FINE_BITS && c - 1 - FINE_BITS <= 8 && W <= 24 && n * (size_t)W <= (1u << 21) && sc.entries2.n >= B * max_entries + 1) {
+        const uint32_t split = dense_split_factor(mb, B, sc);
+        if (sc.presorted) {
+            if (ent_p != sc.entries_z.p || split != 1) throw ZkError("msm: presorted dense list without its buffers");
+            sc.presorted = false;                        // sorted on another stream; the caller has joined it into s
+            ZK_HIP(hipMemsetAsync(part, 0, B * stride * sizeof(XYZZ<F>), s));
+        } else if (split >= 1) {
             // small batch: split every instance into `split` virtual instances (see reserve_dense); everything downstream just sees
             // B * split instances of n / split scalars, and the split results are added at the end
-            uint32_t split = 1;
-            if (sizeof(F) == 32 && sc.vout1.n > VIRT_MIN)
-                while (split < DENSE_SPLIT_MAX && B * split * 2 <= VIRT_MIN && (n % (split * 2)) == 0 && n / (split * 2) >= 4096) split *= 2;
             if (split > 1) {
                 msm_dense_split(mb, scalars, B, sc, out, s, seg_events, split);
                 return;
             }
             ZK_HIP(hipMemsetAsync(part, 0, B * stride * sizeof(XYZZ<F>), s));
-            const size_t lds2 = (size_t)(PART_THREADS / 64 * MAX_COARSE + (MAX_COARSE + 1) + 3 * MAX_COARSE + 2 * PART_THREADS * (size_t)W) * sizeof(uint32_t);
-            partition_attr();
-            sc.coarse_base.ensure(B * (MAX_COARSE + 1));
-            hipLaunchKernelGGL(k_msm_partition, dim3((unsigned)B), dim3(PART_THREADS), lds2, s, scalars, mb.dense_stride, n, c, W, sc.coarse_base.p,
-                               sc.entries2.p, max_entries, 1u);
-            hipLaunchKernelGGL(k_msm_binsort, dim3(1u << (c - 1 - FINE_BITS), (unsigned)B), dim3(256), 0, s, sc.coarse_base.p, sc.entries2.p, sc.entries.p,
-                               max_entries, c, sc.bucket_start.p);
+            dense_two_level_sort(mb, scalars, B, sc, ent_p, bs_p, s);
         } else {
             ZK_HIP(hipMemsetAsync(part, 0, B * stride * sizeof(XYZZ<F>), s));
             hipLaunchKernelGGL(k_msm_sort<true>, dim3((unsigned)B), dim3(SORT_THREADS), lds, s, scalars, mb.dense_stride, (const uint32_t *)nullptr,
-                               (const uint32_t *)nullptr, (const Fr *)nullptr, n, c, W, sc.bucket_start.p, sc.entries.p, max_entries);
+                               (const uint32_t *)nullptr, (const Fr *)nullptr, n, c, W, bs_p, ent_p, max_entries);
         }
     } else {
         if (sc.gen_count.n < B || sc.gen_idx.n < B * n || sc.gen_val.n < B * n) throw ZkError("msm compact-list scratch too small");
@@ -849,7 +890,7 @@ static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, M
     const uint32_t nlanes = accumulate_lanes(max_entries, B);
     if constexpr (sizeof(F) == 32) {
         if (mb.dense && tree_enabled() && sc.treeA1.n) {
-            launch_tree_g1(mb, sc, max_entries, c, B, nlanes, part, stride, nchunks, L, s, seg_events);
+            launch_tree_g1(mb, sc, bs_p, ent_p, max_entries, c, B, nlanes, part, stride, nchunks, L, s, seg_events);
             msm_fold_parts<F>(part, stride, npart, out, B, s);
             return;
         }
@@ -858,13 +899,13 @@ static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, M
     if (SumsSel<F>::cap(sc) < B * (size_t)nb) throw ZkError("msm bucket-sum scratch too small");
     if (seg_events) ZK_HIP(hipEventRecord(seg_events[0], s));
     if (mb.dense)
-        hipLaunchKernelGGL((k_msm_accumulate<F, true>), dim3(ceil_div((size_t)nlanes * B, 64)), dim3(64), 0, s, mb.table.p, sc.bucket_start.p, sc.entries.p,
+        hipLaunchKernelGGL((k_msm_accumulate<F, true>), dim3(ceil_div((size_t)nlanes * B, 64)), dim3(64), 0, s, mb.table.p, bs_p, ent_p,
                            max_entries, c, B, nlanes, sums);
     else
         hipLaunchKernelGGL((k_msm_accumulate<F, false>), dim3(ceil_div((size_t)nlanes * B, 64)), dim3(64), 0, s, mb.table.p, sc.bucket_start.p, sc.entries.p,
                            max_entries, c, B, nlanes, sums);
     if (seg_events) ZK_HIP(hipEventRecord(seg_events[1], s));
-    hipLaunchKernelGGL(k_msm_bucket_reduce<F>, dim3(ceil_div(nseg * B, 64)), dim3(64), 0, s, sums, sc.bucket_start.p, c, B, part, stride, nchunks, L);
+    hipLaunchKernelGGL(k_msm_bucket_reduce<F>, dim3(ceil_div(nseg * B, 64)), dim3(64), 0, s, sums, bs_p, c, B, part, stride, nchunks, L);
     msm_fold_parts<F>(part, stride, npart, out, B, s);
 }
 void msm_batch(const MsmBasesG1 &mb, const Fr *sc, size_t B, MsmScratch &scr, G1XYZZ *out, hipStream_t s, hipEvent_t *ev) { msm_batch_impl<Fp>(mb, sc, B, scr, out, s, ev); }

@@ -192,10 +192,13 @@ __global__ __launch_bounds__(ZK_NTT_TILE / 8) void k_ntt_dif_lds(Fr *__restrict_
     Fr *lds = (Fr *)lds_raw;                       // [E][TI]
     const int tid = threadIdx.x;
     const int bl = tid % TI;                       // instance within the tile
-    const size_t b = (size_t)blockIdx.y * TI + bl;
+    // the instance tiles of one element tile are neighbours in the grid: workgroups resident at the same time then read
+    // adjacent 1 KiB segments of the same 2^K rows (the rows of a tile lie n / 2^K elements = tens of MiB apart in the first
+    // pass; with the element tile as the fast grid axis every resident workgroup touched 2^K pages of its own)
+    const size_t b = (size_t)blockIdx.x * TI + bl;
     const int logS = loglen - K;
     const size_t S = (size_t)1 << logS;
-    const size_t g = blockIdx.x;                   // tile index in [0, n >> K)
+    const size_t g = blockIdx.y;                   // tile index in [0, n >> K)
     const size_t blk = g >> logS, p = g & (S - 1);
     const size_t base = (blk << loglen) + p;
     const bool active = b < B;
@@ -271,9 +274,9 @@ __global__ __launch_bounds__(ZK_NTT_TILE / 8) void k_ntt_dit_lds(Fr *__restrict_
     Fr *lds = (Fr *)lds_raw;
     const int tid = threadIdx.x;
     const int bl = tid % TI;
-    const size_t b = (size_t)blockIdx.y * TI + bl;
+    const size_t b = (size_t)blockIdx.x * TI + bl;
     const size_t S = (size_t)1 << logS;
-    const size_t g = blockIdx.x;
+    const size_t g = blockIdx.y;
     const size_t blk = g >> logS, p = g & (S - 1);
     const size_t base = (blk << (logS + K)) + p;
     const bool active = b < B;
@@ -340,7 +343,7 @@ static void launch_dif_lds(Fr *data, size_t B, int logn, int loglen, const Fr *t
     using T = LdsTile<K1, K2>;
     static PerDeviceOnce attr;
     attr.run([] { ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_dif_lds<K1, K2>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES)); });
-    dim3 grid((unsigned)(((size_t)1 << logn) >> T::K), ceil_div(B, T::TI));
+    dim3 grid(ceil_div(B, T::TI), (unsigned)(((size_t)1 << logn) >> T::K));
     hipLaunchKernelGGL((k_ntt_dif_lds<K1, K2>), grid, dim3(T::THREADS), T::LDS_BYTES, s, data, B, logn, loglen, tw, postmul);
 }
 template <int K1, int K2>
@@ -348,7 +351,7 @@ static void launch_dit_lds(Fr *data, size_t B, int logn, int logS, const Fr *tw,
     using T = LdsTile<K1, K2>;
     static PerDeviceOnce attr;
     attr.run([] { ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_dit_lds<K1, K2>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES)); });
-    dim3 grid((unsigned)(((size_t)1 << logn) >> T::K), ceil_div(B, T::TI));
+    dim3 grid(ceil_div(B, T::TI), (unsigned)(((size_t)1 << logn) >> T::K));
     hipLaunchKernelGGL((k_ntt_dit_lds<K1, K2>), grid, dim3(T::THREADS), T::LDS_BYTES, s, data, B, logn, logS, tw, premul);
 }
 

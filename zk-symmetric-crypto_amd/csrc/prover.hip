@@ -121,7 +121,7 @@ struct Algorithm::Resident {
     DevBuf<G1XYZZ> f_t, f_u, f_v;
     int last_set = 0;               // the set that holds the most recent batch
     hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr, copy_stream = nullptr;
-    hipEvent_t ev[17] = {};     // [10] MSM sums of the current batch complete  [11] tail of the previous batch done  [12] A and B1 sums complete  [13] end of the G1 MSMs
+    hipEvent_t ev[19] = {};     // [17] products f ready  [18] dense list sorted     // [10] MSM sums of the current batch complete  [11] tail of the previous batch done  [12] A and B1 sums complete  [13] end of the G1 MSMs
 };
 
 Algorithm::Algorithm() {}
@@ -441,7 +441,7 @@ void Algorithm::resident_reserve(size_t B) {
     acc(pk.B2.n, pk.B2.c, pk.B2.W);
     if (has_commit) acc(pk.ped.n, pk.ped.c, pk.ped.W);
     R.ms.reserve(B, max_entries, max_nb, max_part);
-    R.ms.reserve_dense(B, pk.Z.n * (size_t)pk.Z.W);
+    R.ms.reserve_dense(B, pk.Z.n * (size_t)pk.Z.W, (size_t)1 << (pk.Z.c - 1));
     R.ms.reserve_tree(B, pk.Z.n * (size_t)pk.Z.W, (size_t)1 << (pk.Z.c - 1));
     R.ms.reserve_compact(B, std::max({pk.A.n, pk.B1.n, pk.K.n, pk.B2.n, has_commit ? pk.ped.n : (size_t)1}));
     {
@@ -563,7 +563,15 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm,
     }
     ZK_HIP(hipEventRecord(R.ev[4], st));
     if (before_msm) ZK_HIP(hipStreamWaitEvent(st, before_msm, 0));
+    bool presorted = false;
     if (!side) {
+        // the quotient MSM's scalars f = A*B are complete: its bucket sort (LDS / memory bound) runs on the copy stream beside the
+        // wire MSMs (multiplier bound) and is joined just before the accumulation
+        fr_transpose_mul(S.sb.a.p, S.sb.b.p, S.sb.c.p, N, B, N, st);
+        ZK_HIP(hipEventRecord(R.ev[17], st));
+        ZK_HIP(hipStreamWaitEvent(R.copy_stream, R.ev[17], 0));
+        presorted = msm_dense_presort(pk.Z, S.sb.c.p, B, R.ms, R.copy_stream);
+        if (presorted) ZK_HIP(hipEventRecord(R.ev[18], R.copy_stream));
         msm_batch(pk.A, S.sb.wires.p, B, R.ms, R.m_ar.p, st);
         msm_batch(pk.B1, S.sb.wires.p, B, R.ms, R.m_bs1.p, st);
         // Ar and Bs1 only need these two sums: their blinding and the two variable-base multiplications s*Ar, r*Bs1 (4 ms of
@@ -587,8 +595,11 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm,
     if (!side) msm_batch(pk.K, S.sb.wires.p, B, R.ms, R.m_k.p, st);
     // sum_k h_k Z_k = sum_i (a_i b_i) Ze_i + (a part linear in the wires that sits in K); c only serves as the buffer of the
     // instance-major products
-    if (side) ZK_HIP(hipStreamWaitEvent(st, R.ev[15], 0));      // b on the coset comes from the side stream
-    fr_transpose_mul(S.sb.a.p, S.sb.b.p, S.sb.c.p, N, B, N, st);
+    if (side) {
+        ZK_HIP(hipStreamWaitEvent(st, R.ev[15], 0));      // b on the coset comes from the side stream
+        fr_transpose_mul(S.sb.a.p, S.sb.b.p, S.sb.c.p, N, B, N, st);
+    }
+    if (presorted) ZK_HIP(hipStreamWaitEvent(st, R.ev[18], 0));
     msm_batch(pk.Z, S.sb.c.p, B, R.ms, R.m_z.p, st, &R.ev[8]);
     ZK_HIP(hipGetLastError());
     if (side) {                                                  // the batch's sums are complete only when the side streams are done too
