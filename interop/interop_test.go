@@ -1,0 +1,107 @@
+// Interoperability test for maintainers with a Go toolchain, the reference checkout and the real proving keys.
+// NOT compiled or run in this repository's image (no Go, gnark v0.14.0 / gnark-crypto v0.19.2 are not vendored) -- it is the
+// recipe that pins, against real gnark, the three conventions this repository could only restate from the published
+// sources (DESIGN.md section 5):
+//
+//   1. the ProvingKey.WriteTo layout  -- InitAlgorithm must accept resources/gnark/pk.* with its pinned SHA-256
+//      (gnark/libraries/prover/impl/library.go:35-49);
+//   2. the BSB22 commitment challenge -- hash_to_field over commitment.Marshal() with DST "bsb22-commitment", and the
+//      Pedersen proof of knowledge folding (AES circuits only);
+//   3. the compressed-point flag polarity and G2 coordinate order of proof / key points.
+//
+// If all three match, proofs made by libzkprove.so verify under the REFERENCE verifier (verifier.Verify,
+// gnark/libraries/verifier/impl/library.go:162-182 -- the check of gnark/libraries/test_helpers.go:332-339); if one does
+// not, InitAlgorithm returns 0 with a diagnostic naming the key section and offset (1, 3) or Verify returns false (2, 3).
+//
+// Place this file in <reference>/gnark/libraries/ (package libraries_test), put libzkprove.so and include/zkprove.h where
+// the cgo flags below point, then:   go test -run TestLibzkproveInterop ./libraries/
+package libraries_test
+
+/*
+#cgo CFLAGS: -I${SRCDIR}/../../../zkprove/include
+#cgo LDFLAGS: -L${SRCDIR}/../../../zkprove/zk-symmetric-crypto_amd -lzkprove -Wl,-rpath,${SRCDIR}/../../../zkprove/zk-symmetric-crypto_amd
+#include <stdlib.h>
+#include "zkprove.h"
+*/
+import "C"
+
+import (
+	"crypto/rand"
+	"encoding/json"
+	"os"
+	"testing"
+	"unsafe"
+
+	prover "github.com/reclaimprotocol/zk-symmetric-crypto/gnark/libraries/prover/impl"
+	verifier "github.com/reclaimprotocol/zk-symmetric-crypto/gnark/libraries/verifier/impl"
+)
+
+func goSlice(b []byte) C.GoSlice {
+	return C.GoSlice{data: unsafe.Pointer(&b[0]), len: C.longlong(len(b)), cap: C.longlong(len(b))}
+}
+
+func gpuInit(t *testing.T, id uint8, ext string) {
+	pk, err := os.ReadFile("../../resources/gnark/pk." + ext)
+	if err != nil {
+		t.Skipf("proving key not present: %v", err)
+	}
+	r1cs, err := os.ReadFile("../../resources/gnark/r1cs." + ext)
+	if err != nil {
+		t.Fatal(err)
+	}
+	// convention 1 (and 3 for the key points): the pinned-hash key must parse, every point must decompress onto its curve
+	if C.InitAlgorithm(C.uchar(id), goSlice(pk), goSlice(r1cs)) != 1 {
+		t.Fatalf("libzkprove InitAlgorithm(%d) refused the reference's pk.%s (see the diagnostic it printed)", id, ext)
+	}
+}
+
+func gpuProve(t *testing.T, params []byte) *prover.OutputParams {
+	r := C.Prove(goSlice(params))
+	defer C.Free(r.r0)
+	var out *prover.OutputParams
+	if err := json.Unmarshal(C.GoBytes(r.r0, C.int(r.r1)), &out); err != nil || out == nil || len(out.Proof) == 0 {
+		t.Fatalf("libzkprove Prove did not return a proof: %s", C.GoString((*C.char)(r.r0)))
+	}
+	return out
+}
+
+func runCase(t *testing.T, id uint8, ext, cipher string, keyLen, nBlocks, blockLen int) {
+	gpuInit(t, id, ext)
+	key := make([]byte, keyLen)
+	input := make([]byte, nBlocks*blockLen)
+	nonce := make([]byte, 12)
+	rand.Read(key)
+	rand.Read(input)
+	rand.Read(nonce)
+	blocks := make([]prover.Block, nBlocks)
+	for i := range blocks {
+		blocks[i] = prover.Block{Nonce: nonce, Counter: uint32(7 + i)}
+	}
+	params, _ := json.Marshal(&prover.InputParams{Cipher: cipher, Key: key, Blocks: blocks, Input: input})
+	out := gpuProve(t, params)
+
+	// conventions 2 and 3: the REFERENCE verifier (gnark's groth16.Verify with the embedded vk.*) must accept the proof
+	vblocks := make([]verifier.Block, nBlocks)
+	for i := range vblocks {
+		vblocks[i] = verifier.Block{Nonce: nonce, Counter: uint32(7 + i)}
+	}
+	signals, _ := json.Marshal(&verifier.PublicSignalsJSON{Ciphertext: out.Ciphertext, Blocks: vblocks, Input: input})
+	req, _ := json.Marshal(&verifier.InputVerifyParams{Cipher: cipher, Proof: out.Proof, PublicSignals: signals})
+	if !verifier.Verify(req) {
+		t.Fatalf("%s: reference verifier rejected a libzkprove proof", cipher)
+	}
+	// and the reference prover's own proof for the same request must verify under libzkprove's Verify export as well
+	ref := prover.Prove(params)
+	var refOut *prover.OutputParams
+	json.Unmarshal(ref, &refOut)
+	req2, _ := json.Marshal(&verifier.InputVerifyParams{Cipher: cipher, Proof: refOut.Proof, PublicSignals: signals})
+	if C.Verify(goSlice(req2)) != 1 {
+		t.Fatalf("%s: libzkprove Verify rejected a gnark proof (set ZKPROVE_VK_DIR to verifier/impl/generated)", cipher)
+	}
+}
+
+func TestLibzkproveInterop(t *testing.T) {
+	runCase(t, 0, "chacha20", "chacha20", 32, 2, 64)
+	runCase(t, 1, "aes128", "aes-128-ctr", 16, 5, 16)
+	runCase(t, 2, "aes256", "aes-256-ctr", 32, 5, 16)
+}

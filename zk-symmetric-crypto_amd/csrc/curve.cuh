@@ -83,6 +83,30 @@ struct XYZZ {
         ZZ = madd_mul<INL>(ZZ, PP);
         ZZZ = madd_mul<INL>(ZZZ, PPP);
     }
+    // this += q (affine) with the accumulator kept in WEAK form (coordinates in [0, 2M), field.cuh) and the multiplier block
+    // expanded in place: the innermost loop of the bucket accumulation.  Same formulas and special cases as madd; the caller
+    // stores canon().  Fp only (the Fp2 tower stays canonical).
+    ZK_HD void madd_w(const Affine<F> &q) {
+        if (q.is_inf()) return;
+        if (is_inf()) {                      // infinity is the exact all-zero encoding; a finite accumulator never has ZZ = 0 mod M
+            X = q.x; Y = q.y; ZZ = F::one(); ZZZ = F::one();
+            return;
+        }
+        const F U2 = F::mul_w(q.x, ZZ), S2 = F::mul_w(q.y, ZZZ);
+        const F Pv = F::sub_w(U2, X), R = F::sub_w(S2, Y);
+        if (Pv.is_zero_w()) {
+            if (R.is_zero_w()) *this = dbl_affine(q);
+            else *this = inf();
+            return;
+        }
+        const F PP = F::mul_w(Pv, Pv), PPP = F::mul_w(Pv, PP), Q = F::mul_w(X, PP);
+        const F X3 = F::sub_w(F::sub_w(F::mul_w(R, R), PPP), F::add_w(Q, Q));
+        Y = F::sub_w(F::mul_w(R, F::sub_w(Q, X3)), F::mul_w(Y, PPP));
+        X = X3;
+        ZZ = F::mul_w(ZZ, PP);
+        ZZZ = F::mul_w(ZZZ, PPP);
+    }
+    ZK_HD XYZZ canon() const { return XYZZ{X.canon(), Y.canon(), ZZ.canon(), ZZZ.canon()}; }
     // this += q (XYZZ), add-2008-s
     ZK_HD void add(const XYZZ &q) {
         if (q.is_inf()) return;

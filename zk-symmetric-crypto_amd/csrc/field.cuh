@@ -134,6 +134,50 @@ struct Field {
                 : "vcc");
         }
     }
+    // weak form: r < 4M -> r - 2M if r >= 2M
+    static ZK_D void asm_reduce_w(Field &r) {
+        uint32_t d0, d1, d2, d3, d4, d5, d6, d7;
+        if constexpr (P::ID == 0) {
+            asm(ZK_REDW_ASM_FP
+                : "+v"(r.l[0]), "+v"(r.l[1]), "+v"(r.l[2]), "+v"(r.l[3]), "+v"(r.l[4]), "+v"(r.l[5]), "+v"(r.l[6]), "+v"(r.l[7]),
+                  "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4), "=&v"(d5), "=&v"(d6), "=&v"(d7)
+                :
+                : "vcc");
+        } else {
+            asm(ZK_REDW_ASM_FR
+                : "+v"(r.l[0]), "+v"(r.l[1]), "+v"(r.l[2]), "+v"(r.l[3]), "+v"(r.l[4]), "+v"(r.l[5]), "+v"(r.l[6]), "+v"(r.l[7]),
+                  "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4), "=&v"(d5), "=&v"(d6), "=&v"(d7)
+                :
+                : "vcc");
+        }
+    }
+    // weak form: r = a - b, + 2M if that borrowed (a, b in [0, 2M) -> r in [0, 2M))
+    static ZK_D void asm_sub_w(Field &r, const Field &a, const Field &b) {
+        uint32_t m, d0, d1, d2, d3, d4, d5, d6, d7;
+        if constexpr (P::ID == 0) {
+            asm(ZK_SUB_ASM_FP
+                : "=&v"(r.l[0]), "=&v"(r.l[1]), "=&v"(r.l[2]), "=&v"(r.l[3]), "=&v"(r.l[4]), "=&v"(r.l[5]), "=&v"(r.l[6]), "=&v"(r.l[7]), "=&v"(m)
+                : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]),
+                  "v"(b.l[0]), "v"(b.l[1]), "v"(b.l[2]), "v"(b.l[3]), "v"(b.l[4]), "v"(b.l[5]), "v"(b.l[6]), "v"(b.l[7])
+                : "vcc");
+            asm(ZK_SUBFIXW_ASM_FP
+                : "+v"(r.l[0]), "+v"(r.l[1]), "+v"(r.l[2]), "+v"(r.l[3]), "+v"(r.l[4]), "+v"(r.l[5]), "+v"(r.l[6]), "+v"(r.l[7]),
+                  "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4), "=&v"(d5), "=&v"(d6), "=&v"(d7)
+                : "v"(m)
+                : "vcc");
+        } else {
+            asm(ZK_SUB_ASM_FR
+                : "=&v"(r.l[0]), "=&v"(r.l[1]), "=&v"(r.l[2]), "=&v"(r.l[3]), "=&v"(r.l[4]), "=&v"(r.l[5]), "=&v"(r.l[6]), "=&v"(r.l[7]), "=&v"(m)
+                : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]),
+                  "v"(b.l[0]), "v"(b.l[1]), "v"(b.l[2]), "v"(b.l[3]), "v"(b.l[4]), "v"(b.l[5]), "v"(b.l[6]), "v"(b.l[7])
+                : "vcc");
+            asm(ZK_SUBFIXW_ASM_FR
+                : "+v"(r.l[0]), "+v"(r.l[1]), "+v"(r.l[2]), "+v"(r.l[3]), "+v"(r.l[4]), "+v"(r.l[5]), "+v"(r.l[6]), "+v"(r.l[7]),
+                  "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4), "=&v"(d5), "=&v"(d6), "=&v"(d7)
+                : "v"(m)
+                : "vcc");
+        }
+    }
     // r = a - b mod M
     static ZK_D void asm_sub(Field &r, const Field &a, const Field &b) {
         uint32_t m, d0, d1, d2, d3, d4, d5, d6, d7;
@@ -222,6 +266,54 @@ struct Field {
     }
     ZK_HD Field dbl() const { return *this + *this; }
 
+    // ---- "weak" form: values in [0, 2M) instead of [0, M).  A Montgomery product of weak operands is weak again without
+    // the final conditional subtraction (4M < 2^256), which is 8 % of the multiplier block; additions and subtractions cost
+    // the same as in canonical form.  Only zero tests and stores need care (is_zero_w, canon).  Canonical values are weak
+    // values, so the two forms mix freely as INPUTS of the *_w operations.  Host builds simply stay canonical.
+    ZK_HD Field canon() const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        Field r = *this;
+        asm_reduce(r);
+        return r;
+#else
+        Field r = *this;
+        reduce_once(r.l);
+        return r;
+#endif
+    }
+    ZK_HD bool is_zero_w() const {
+        uint32_t o = 0, q = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { o |= l[i]; q |= l[i] ^ P::M[i]; }
+        return o == 0 || q == 0;
+    }
+    static ZK_HD Field mul_w(const Field &a, const Field &b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return mul_block_w(a, b);
+#else
+        return a.canon() * b.canon();
+#endif
+    }
+    static ZK_HD Field add_w(const Field &a, const Field &b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        Field r;
+        asm_add(r, a, b);
+        asm_reduce_w(r);
+        return r;
+#else
+        return a.canon() + b.canon();
+#endif
+    }
+    static ZK_HD Field sub_w(const Field &a, const Field &b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        Field r;
+        asm_sub_w(r, a, b);
+        return r;
+#else
+        return a.canon() - b.canon();
+#endif
+    }
+
     // Montgomery product (CIOS, 32-bit limbs). M < 2^254 => intermediate fits in 9 limbs.
     friend ZK_HD Field operator*(const Field &a, const Field &b) { return mul_impl(a, b); }
     // Out-of-line on purpose: one copy of the ~400-instruction body per field keeps kernels small
@@ -229,6 +321,26 @@ struct Field {
 #if defined(__HIP_DEVICE_COMPILE__)
     // the multiplier block itself (generated by gen_mul_asm.py): FIPS Montgomery with v_mad_u64_u32 + v_addc_co_u32 carry
     // pairs, ending with the conditional subtraction of the modulus; +44 % over the compiled CIOS loop
+    // the same without the final conditional subtraction: operands and result in [0, 2M) ("weak" form; 4M < 2^256)
+    static ZK_D Field mul_block_w(const Field &a, const Field &b) {
+        uint32_t t0, t1, t2, t3, t4, t5, t6, t7;
+        if constexpr (P::ID == 0) {
+            asm volatile(ZK_MULW_ASM_FP
+                         : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+                         : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]),
+                           "v"(b.l[0]), "v"(b.l[1]), "v"(b.l[2]), "v"(b.l[3]), "v"(b.l[4]), "v"(b.l[5]), "v"(b.l[6]), "v"(b.l[7])
+                         : "v16", "v17", "v18", "v19", "s16", "s17", "s18", "s19", "s20", "s21", "s22", "s23", "s24", "vcc");
+        } else {
+            asm volatile(ZK_MULW_ASM_FR
+                         : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+                         : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]),
+                           "v"(b.l[0]), "v"(b.l[1]), "v"(b.l[2]), "v"(b.l[3]), "v"(b.l[4]), "v"(b.l[5]), "v"(b.l[6]), "v"(b.l[7])
+                         : "v16", "v17", "v18", "v19", "s16", "s17", "s18", "s19", "s20", "s21", "s22", "s23", "s24", "vcc");
+        }
+        Field r;
+        r.l[0] = t0; r.l[1] = t1; r.l[2] = t2; r.l[3] = t3; r.l[4] = t4; r.l[5] = t5; r.l[6] = t6; r.l[7] = t7;
+        return r;
+    }
     static ZK_D Field mul_block(const Field &a, const Field &b) {
         uint32_t t0, t1, t2, t3, t4, t5, t6, t7;
         if constexpr (P::ID == 0) {

@@ -133,10 +133,21 @@ def main():
         out.append("#define ZK_MUL_ASM_%s \\" % name)
         out.append(" \\\n".join('    "%s\\n\\t"' % l for l in lines))
         out.append("")
+        # weak form: operands and result in [0, 2 mod) -- no conditional subtraction (4 mod < 2^256)
+        out.append("#define ZK_MULW_ASM_%s \\" % name)
+        out.append(" \\\n".join('    "%s\\n\\t"' % l for l in gen(mod)))
+        out.append("")
         for tag, fn in (("ADD", gen_add), ("SUB", gen_sub), ("SUBFIX", gen_subfix)):
             out.append("#define ZK_%s_ASM_%s \\" % (tag, name))
             out.append(" \\\n".join('    "%s\\n\\t"' % l for l in fn(mod)))
             out.append("")
+        # weak form ([0, 2 mod) operands): conditional subtraction of 2 mod after an addition, + 2 mod after a borrowing subtraction
+        out.append("#define ZK_REDW_ASM_%s \\" % name)
+        out.append(" \\\n".join('    "%s\\n\\t"' % l for l in gen_reduce(2 * mod, ["%%%d" % i for i in range(8)], ["%%%d" % (8 + i) for i in range(8)])))
+        out.append("")
+        out.append("#define ZK_SUBFIXW_ASM_%s \\" % name)
+        out.append(" \\\n".join('    "%s\\n\\t"' % l for l in gen_subfix(2 * mod)))
+        out.append("")
         out.append("#define ZK_RED_ASM_%s \\" % name)
         out.append(" \\\n".join('    "%s\\n\\t"' % l for l in gen_reduce(mod, ["%%%d" % i for i in range(8)], ["%%%d" % (8 + i) for i in range(8)])))
         out.append("")

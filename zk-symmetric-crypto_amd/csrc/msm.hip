@@ -449,6 +449,17 @@ __global__ __launch_bounds__(256) void k_msm_binsort(const uint32_t *__restrict_
 // sums[b * nb + k] receives the sum of bucket k when it is non-empty (empty buckets are never written;
 // the reduce kernel reads emptiness from bucket_start).
 // DENSE only names the instantiation (quotient MSM vs. wire MSMs) so that profiler summaries keep the dominant launch apart.
+// G1 accumulates in weak form with the multiplier expanded in place (madd_w); G2 uses the plain mixed addition
+template <class F>
+__device__ __forceinline__ void acc_madd(XYZZ<F> &acc, const Affine<F> &p) {
+    if constexpr (sizeof(F) == 32) acc.madd_w(p);
+    else acc.madd(p);
+}
+template <class F>
+__device__ __forceinline__ XYZZ<F> acc_store(const XYZZ<F> &acc) {
+    if constexpr (sizeof(F) == 32) return acc.canon();
+    else return acc;
+}
 template <class F, bool DENSE>
 __device__ __forceinline__ void accumulate_body(const Affine<F> *__restrict__ table, const uint32_t *__restrict__ bucket_start,
                                                 const uint32_t *__restrict__ entries, size_t max_entries, int c, size_t B,
@@ -485,7 +496,7 @@ __device__ __forceinline__ void accumulate_body(const Affine<F> *__restrict__ ta
     Affine<F> p = table[v & 0x7fffffffu];
     while (true) {
         while (e >= next_b) {              // leave bucket `cur` (also skips empty buckets)
-            if (next_b > cur_start) { out[cur] = acc; acc = XYZZ<F>::inf(); }   // every non-empty bucket is written, even if its sum is infinity
+            if (next_b > cur_start) { out[cur] = acc_store(acc); acc = XYZZ<F>::inf(); }   // every non-empty bucket is written, even if its sum is infinity
             cur++;
             cur_start = next_b;
             next_b = next_b2;
@@ -496,7 +507,7 @@ __device__ __forceinline__ void accumulate_body(const Affine<F> *__restrict__ ta
         uint32_t v_next = 0;
         if (e_next < e_end) v_next = ent[e_next];
         if (v >> 31) p.y = p.y.neg();
-        acc.template madd<true>(p);
+        acc_madd(acc, p);
         if (e_next >= e_end) break;
         e = e_next; v = v_next; p = table[v & 0x7fffffffu];
     }

@@ -12,18 +12,26 @@ static constexpr size_t SIDE_G2_MAX_B = 64;   // up to this batch size the G2 MS
 
 // ------------------------------------------------------------------------------- pk parsing
 namespace {
+// Every failure names the section of gnark's ProvingKey.WriteTo layout it happened in and the byte offset, so that the first real
+// pk.* that does not parse (the layout is restated from the published gnark source) gives an actionable message.
 struct PkCursor {
     const uint8_t *p;
     size_t len, pos = 0;
-    void need(size_t n) const { if (pos + n > len) throw ZkError("proving key: truncated"); }
+    const char *section = "domain header";
+    void need(size_t n) const {
+        if (pos + n > len)
+            throw ZkError(std::string("proving key: truncated in section '") + section + "' at offset " + std::to_string(pos) + " (needs " + std::to_string(n) +
+                          " more bytes, file has " + std::to_string(len) + ")");
+    }
     uint32_t u32be() { need(4); uint32_t v = ((uint32_t)p[pos] << 24) | ((uint32_t)p[pos + 1] << 16) | ((uint32_t)p[pos + 2] << 8) | p[pos + 3]; pos += 4; return v; }
     uint64_t u64be() { uint64_t hi = u32be(); return (hi << 32) | u32be(); }
 };
-struct Slice { size_t off = 0, n = 0; bool raw = false; };
+struct Slice { size_t off = 0, n = 0; bool raw = false; const char *name = ""; };
 
 // one point: size from the flag bits of its first byte (gnark-crypto marshal.go)
-static Slice take_points(PkCursor &c, size_t n, size_t comp_size) {
-    Slice s; s.off = c.pos; s.n = n;
+static Slice take_points(PkCursor &c, size_t n, size_t comp_size, const char *name) {
+    c.section = name;
+    Slice s; s.off = c.pos; s.n = n; s.name = name;
     if (n == 0) return s;
     c.need(1);
     s.raw = (c.p[c.pos] & 0xC0) == 0;
@@ -31,12 +39,14 @@ static Slice take_points(PkCursor &c, size_t n, size_t comp_size) {
     c.need(n * sz);
     for (size_t i = 0; i < n; i++) {
         const bool raw_i = (c.p[c.pos + i * sz] & 0xC0) == 0;
-        if (raw_i != s.raw) throw ZkError("proving key: mixed point encodings in one slice");
+        if (raw_i != s.raw)
+            throw ZkError(std::string("proving key: section '") + name + "': point " + std::to_string(i) + " at offset " + std::to_string(c.pos + i * sz) +
+                          " switches between compressed and uncompressed encoding");
     }
     c.pos += n * sz;
     return s;
 }
-static Slice take_slice(PkCursor &c, size_t comp_size) { uint32_t n = c.u32be(); return take_points(c, n, comp_size); }
+static Slice take_slice(PkCursor &c, size_t comp_size, const char *name) { c.section = name; uint32_t n = c.u32be(); return take_points(c, n, comp_size, name); }
 
 static void upload_g1(const uint8_t *base, const Slice &s, DevBuf<G1Affine> &out, hipStream_t st) {
     out.alloc(s.n ? s.n : 1);
@@ -50,7 +60,9 @@ static void upload_g1(const uint8_t *base, const Slice &s, DevBuf<G1Affine> &out
     g1_validate(out.p, s.raw ? raw.p : nullptr, s.n, bad.p, st);
     uint32_t nb = 0; bad.download(&nb, 1, st);
     ZK_HIP(hipStreamSynchronize(st));
-    if (nb) throw ZkError("proving key: invalid G1 point");
+    if (nb)
+        throw ZkError(std::string("proving key: section '") + s.name + "' (offset " + std::to_string(s.off) + ", " + std::to_string(s.n) + (s.raw ? " uncompressed" : " compressed") +
+                      " G1 points): " + std::to_string(nb) + " invalid G1 point(s) (non-reduced coordinate, bad flag bits or not on the curve)");
 }
 static void upload_g2(const uint8_t *base, const Slice &s, DevBuf<G2Affine> &out, hipStream_t st) {
     out.alloc(s.n ? s.n : 1);
@@ -64,9 +76,12 @@ static void upload_g2(const uint8_t *base, const Slice &s, DevBuf<G2Affine> &out
     g2_validate(out.p, s.raw ? raw.p : nullptr, s.n, bad.p, st);
     uint32_t nb = 0; bad.download(&nb, 1, st);
     ZK_HIP(hipStreamSynchronize(st));
-    if (nb) throw ZkError("proving key: invalid G2 point (not on the curve or not in the subgroup)");
+    if (nb)
+        throw ZkError(std::string("proving key: section '") + s.name + "' (offset " + std::to_string(s.off) + ", " + std::to_string(s.n) + (s.raw ? " uncompressed" : " compressed") +
+                      " G2 points): " + std::to_string(nb) + " invalid G2 point(s) (not on the curve or not in the subgroup)");
 }
-static std::vector<uint8_t> take_bools(PkCursor &c) {
+static std::vector<uint8_t> take_bools(PkCursor &c, const char *name) {
+    c.section = name;
     // gnark-crypto encoder []bool: u32 length, bits packed LSB-first  [gnark-mem, unpinned: SURVEY App. C]
     uint32_t n = c.u32be();
     size_t nbytes = (n + 7) / 8;
@@ -151,21 +166,26 @@ void Algorithm::load(const uint8_t *pkb, size_t pk_len, const uint8_t *r1cs_byte
 
     PkCursor c{pkb, pk_len};
     pk.domain = c.u64be();
-    if (pk.domain != N) throw ZkError("proving key: domain size does not match the constraint system");
+    if (pk.domain != N)
+        throw ZkError("proving key: domain cardinality " + std::to_string(pk.domain) + " at offset 0 does not match the constraint system (" + std::to_string(N) + ")");
     c.need(5 * 32 + 1);
     c.pos += 5 * 32 + 1;                                  // CardinalityInv, Generator, GeneratorInv, FrMultiplicativeGen(+Inv), withPrecompute
-    Slice misc1 = take_points(c, 3, 32);                  // alpha, beta, delta
-    Slice sA = take_slice(c, 32), sB = take_slice(c, 32), sZ = take_slice(c, 32), sK = take_slice(c, 32);
-    Slice misc2 = take_points(c, 2, 64);                  // beta2, delta2
-    Slice sB2 = take_slice(c, 64);
+    Slice misc1 = take_points(c, 3, 32, "G1.Alpha,Beta,Delta");
+    Slice sA = take_slice(c, 32, "G1.A"), sB = take_slice(c, 32, "G1.B"), sZ = take_slice(c, 32, "G1.Z"), sK = take_slice(c, 32, "G1.K");
+    Slice misc2 = take_points(c, 2, 64, "G2.Beta,Delta");
+    Slice sB2 = take_slice(c, 64, "G2.B");
+    c.section = "NbWires / NbInfinityA / NbInfinityB";
     uint64_t nwires = c.u64be(), ninfA = c.u64be(), ninfB = c.u64be();
-    std::vector<uint8_t> infA = take_bools(c), infB = take_bools(c);
+    std::vector<uint8_t> infA = take_bools(c, "InfinityA"), infB = take_bools(c, "InfinityB");
+    c.section = "CommitmentKeys";
     uint32_t nkeys = c.u32be();
     Slice sPed, sPedS;
-    if (nkeys > 1) throw ZkError("proving key: more than one commitment key");
-    if (nkeys == 1) { sPed = take_slice(c, 32); sPedS = take_slice(c, 32); }
-    if (c.pos != pk_len) throw ZkError("proving key: trailing bytes");
-    if (nwires != nw || infA.size() != nw || infB.size() != nw) throw ZkError("proving key: wire count does not match the constraint system");
+    if (nkeys > 1) throw ZkError("proving key: " + std::to_string(nkeys) + " commitment keys at offset " + std::to_string(c.pos - 4) + " (the circuits have at most one)");
+    if (nkeys == 1) { sPed = take_slice(c, 32, "CommitmentKeys[0].Basis"); sPedS = take_slice(c, 32, "CommitmentKeys[0].BasisExpSigma"); }
+    if (c.pos != pk_len) throw ZkError("proving key: " + std::to_string(pk_len - c.pos) + " trailing bytes after the last section (offset " + std::to_string(c.pos) + ")");
+    if (nwires != nw || infA.size() != nw || infB.size() != nw)
+        throw ZkError("proving key: NbWires " + std::to_string(nwires) + " / len(InfinityA) " + std::to_string(infA.size()) + " / len(InfinityB) " + std::to_string(infB.size()) +
+                      " do not match the constraint system's " + std::to_string(nw) + " wires");
     if ((nkeys == 1) != has_commit) throw ZkError("proving key: commitment keys do not match the constraint system");
     pk.n_wires = nw;
 
@@ -180,7 +200,9 @@ void Algorithm::load(const uint8_t *pkb, size_t pk_len, const uint8_t *r1cs_byte
         if (w >= cs.nb_public && !skip[w]) rowsK.push_back((uint32_t)w);
     }
     if (rowsA.size() != sA.n || rowsB.size() != sB.n || rowsB.size() != sB2.n || rowsK.size() != sK.n || ninfA != nw - sA.n || ninfB != nw - sB.n)
-        throw ZkError("proving key: point counts do not match the constraint system");
+        throw ZkError("proving key: point counts do not match the constraint system (G1.A " + std::to_string(sA.n) + " vs " + std::to_string(rowsA.size()) + " finite, G1.B " +
+                      std::to_string(sB.n) + " / G2.B " + std::to_string(sB2.n) + " vs " + std::to_string(rowsB.size()) + ", G1.K " + std::to_string(sK.n) + " vs " +
+                      std::to_string(rowsK.size()) + ", NbInfinityA " + std::to_string(ninfA) + ", NbInfinityB " + std::to_string(ninfB) + ")");
     if (sZ.n + 1 < N) throw ZkError("proving key: too few Z points");
     sZ.n = N - 1;
     if (has_commit) {

@@ -228,6 +228,32 @@ __global__ __launch_bounds__(256) void k_bench_mul(F *x, int iters) {
     for (int k = 0; k < iters; k++) { a = a * b; b = b * a; }
     x[i] = a + b;
 }
+// issue rate of the multiplier's two instructions: PAIRS = false -> v_mad_u64_u32 alone, true -> the v_mad_u64_u32 + v_addc_co_u32
+// carry pair of the Montgomery block; 4 independent accumulators, 64 of them per loop iteration
+template <bool PAIRS>
+__global__ __launch_bounds__(256) void k_bench_mad(uint32_t *x, int iters) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t a = x[i], b = x[i] * 2654435761u + 1u;
+    uint64_t acc0 = a, acc1 = b, acc2 = a ^ b, acc3 = a + b;
+    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    for (int k = 0; k < iters; k++) {
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            if (PAIRS) {
+                asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc" : "+v"(acc0), "+v"(c0) : "v"(a), "v"(b) : "vcc");
+                asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc" : "+v"(acc1), "+v"(c1) : "v"(a), "v"(b) : "vcc");
+                asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc" : "+v"(acc2), "+v"(c2) : "v"(a), "v"(b) : "vcc");
+                asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc" : "+v"(acc3), "+v"(c3) : "v"(a), "v"(b) : "vcc");
+            } else {
+                asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc0) : "v"(a), "v"(b) : "vcc");
+                asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc1) : "v"(a), "v"(b) : "vcc");
+                asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc2) : "v"(a), "v"(b) : "vcc");
+                asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc3) : "v"(a), "v"(b) : "vcc");
+            }
+        }
+    }
+    x[i] = (uint32_t)(acc0 ^ acc1 ^ acc2 ^ acc3) ^ (uint32_t)((acc0 ^ acc1 ^ acc2 ^ acc3) >> 32) ^ c0 ^ c1 ^ c2 ^ c3;
+}
 // iters dependent inversions per thread: GCD = false -> Fermat ladder (inv), true -> binary GCD (inv_gcd)
 template <class F, bool GCD>
 __global__ __launch_bounds__(256) void k_bench_inv(F *x, int iters) {
@@ -275,7 +301,7 @@ extern "C" int zkp_field_inv(int field, long n, const uint8_t *in, uint8_t *out)
     ZKP_CATCH(-1)
 }
 // returns milliseconds for `threads` threads x `iters` iterations; kind 0: 2 Fp mul / iter, 1: G1 madd, 2: G2 madd, 3: Fp Fermat inversion,
-// 4: Fp binary-GCD inversion
+// 4: Fp binary-GCD inversion, 5: 64 v_mad_u64_u32 per iteration, 6: 64 v_mad_u64_u32 + v_addc_co_u32 pairs per iteration
 extern "C" double zkp_microbench(int kind, long threads, int iters) {
     ZKP_TRY
     size_t T = (size_t)threads;
@@ -290,6 +316,13 @@ extern "C" double zkp_microbench(int kind, long threads, int iters) {
         hipLaunchKernelGGL(k_bench_mul<Fp>, dim3(T / 256), dim3(256), 0, 0, x.p, 4);
         ZK_HIP(hipEventRecord(e0, 0));
         hipLaunchKernelGGL(k_bench_mul<Fp>, dim3(T / 256), dim3(256), 0, 0, x.p, iters);
+        ZK_HIP(hipEventRecord(e1, 0));
+    } else if (kind == 5 || kind == 6) {
+        DevBuf<uint32_t> x(T);
+        ZK_HIP(hipMemset(x.p, 0x5a, T * 4));
+        ZK_HIP(hipEventRecord(e0, 0));
+        if (kind == 5) hipLaunchKernelGGL((k_bench_mad<false>), dim3(T / 256), dim3(256), 0, 0, x.p, iters);
+        else hipLaunchKernelGGL((k_bench_mad<true>), dim3(T / 256), dim3(256), 0, 0, x.p, iters);
         ZK_HIP(hipEventRecord(e1, 0));
     } else if (kind == 3 || kind == 4) {
         DevBuf<Fp> x(T);
