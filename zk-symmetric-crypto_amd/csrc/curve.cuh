@@ -83,28 +83,53 @@ struct XYZZ {
         ZZ = madd_mul<INL>(ZZ, PP);
         ZZZ = madd_mul<INL>(ZZZ, PPP);
     }
-    // this += q (affine) with the accumulator kept in WEAK form (coordinates in [0, 2M), field.cuh) and the multiplier block
-    // expanded in place: the innermost loop of the bucket accumulation.  Same formulas and special cases as madd; the caller
-    // stores canon().  Fp only (the Fp2 tower stays canonical).
+    // this += q with the accumulator kept in WEAK form (coordinates in [0, 2M), field.cuh).  Same formulas and special cases as
+    // madd / add; q may be canonical or weak; the caller stores canon().  INL expands the multiplier block in place (innermost
+    // loop of the bucket accumulation), otherwise the shared out-of-line weak multiplier is called.  Fp only (the Fp2 tower stays
+    // canonical).
+    template <bool INL>
+    static ZK_HD F wmul(const F &a, const F &b) {
+        if constexpr (INL) return F::mul_w(a, b);
+        else return F::mul_wc(a, b);
+    }
+    template <bool INL = true>
     ZK_HD void madd_w(const Affine<F> &q) {
         if (q.is_inf()) return;
         if (is_inf()) {                      // infinity is the exact all-zero encoding; a finite accumulator never has ZZ = 0 mod M
             X = q.x; Y = q.y; ZZ = F::one(); ZZZ = F::one();
             return;
         }
-        const F U2 = F::mul_w(q.x, ZZ), S2 = F::mul_w(q.y, ZZZ);
+        const F U2 = wmul<INL>(q.x, ZZ), S2 = wmul<INL>(q.y, ZZZ);
         const F Pv = F::sub_w(U2, X), R = F::sub_w(S2, Y);
         if (Pv.is_zero_w()) {
             if (R.is_zero_w()) *this = dbl_affine(q);
             else *this = inf();
             return;
         }
-        const F PP = F::mul_w(Pv, Pv), PPP = F::mul_w(Pv, PP), Q = F::mul_w(X, PP);
-        const F X3 = F::sub_w(F::sub_w(F::mul_w(R, R), PPP), F::add_w(Q, Q));
-        Y = F::sub_w(F::mul_w(R, F::sub_w(Q, X3)), F::mul_w(Y, PPP));
+        const F PP = wmul<INL>(Pv, Pv), PPP = wmul<INL>(Pv, PP), Q = wmul<INL>(X, PP);
+        const F X3 = F::sub_w(F::sub_w(wmul<INL>(R, R), PPP), F::add_w(Q, Q));
+        Y = F::sub_w(wmul<INL>(R, F::sub_w(Q, X3)), wmul<INL>(Y, PPP));
         X = X3;
-        ZZ = F::mul_w(ZZ, PP);
-        ZZZ = F::mul_w(ZZZ, PPP);
+        ZZ = wmul<INL>(ZZ, PP);
+        ZZZ = wmul<INL>(ZZZ, PPP);
+    }
+    // this += q (XYZZ, canonical or weak), accumulator weak
+    ZK_HD void add_w(const XYZZ &q) {
+        if (q.is_inf()) return;
+        if (is_inf()) { *this = q; return; }
+        const F U1 = F::mul_wc(X, q.ZZ), U2 = F::mul_wc(q.X, ZZ), S1 = F::mul_wc(Y, q.ZZZ), S2 = F::mul_wc(q.Y, ZZZ);
+        const F Pv = F::sub_w(U2, U1), R = F::sub_w(S2, S1);
+        if (Pv.is_zero_w()) {
+            if (R.is_zero_w()) *this = canon().dbl();
+            else *this = inf();
+            return;
+        }
+        const F PP = F::mul_wc(Pv, Pv), PPP = F::mul_wc(Pv, PP), Q = F::mul_wc(U1, PP);
+        const F X3 = F::sub_w(F::sub_w(F::mul_wc(R, R), PPP), F::add_w(Q, Q));
+        Y = F::sub_w(F::mul_wc(R, F::sub_w(Q, X3)), F::mul_wc(S1, PPP));
+        X = X3;
+        ZZ = F::mul_wc(F::mul_wc(ZZ, q.ZZ), PP);
+        ZZZ = F::mul_wc(F::mul_wc(ZZZ, q.ZZZ), PPP);
     }
     ZK_HD XYZZ canon() const { return XYZZ{X.canon(), Y.canon(), ZZ.canon(), ZZZ.canon()}; }
     // this += q (XYZZ), add-2008-s

@@ -294,6 +294,15 @@ struct Field {
         return a.canon() * b.canon();
 #endif
     }
+    // the same through one shared out-of-line copy (kernels with dozens of multiplication sites: the transforms)
+    static __host__ __device__ __attribute__((noinline)) Field mul_wc_impl(Field a, Field b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return mul_block_w(a, b);
+#else
+        return a.canon() * b.canon();
+#endif
+    }
+    static ZK_HD Field mul_wc(const Field &a, const Field &b) { return mul_wc_impl(a, b); }
     static ZK_HD Field add_w(const Field &a, const Field &b) {
 #if defined(__HIP_DEVICE_COMPILE__)
         Field r;

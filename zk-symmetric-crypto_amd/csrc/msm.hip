@@ -555,10 +555,16 @@ __global__ __launch_bounds__(64) void k_msm_bucket_reduce(const XYZZ<F> *__restr
     uint32_t hi = bs[s0 + L];
     for (int k = (int)L - 1; k >= 0; k--) {
         const uint32_t lo = bs[s0 + k];
-        if (hi > lo) run.add(in[s0 + k]);
+        if constexpr (sizeof(F) == 32) {        // G1: both running sums in weak form (curve.cuh add_w)
+            if (hi > lo) run.add_w(in[s0 + k]);
+            tot.add_w(run);
+        } else {
+            if (hi > lo) run.add(in[s0 + k]);
+            tot.add(run);
+        }
         hi = lo;
-        tot.add(run);
     }
+    if constexpr (sizeof(F) == 32) { run = run.canon(); tot = tot.canon(); }
     // contribution = tot + s0 * run   (bucket index i carries weight i+1)
     if (s0 != 0 && !run.is_inf()) {
         XYZZ<F> m = XYZZ<F>::inf();
@@ -645,10 +651,12 @@ __global__ __launch_bounds__(256, ZK_FP2_WAVES(F)) void k_msm_ones(const Affine<
         if (g + 1 < ONES_GROUPS && pat[g + 1] != TERN_CENTER) pn = fetch(g + 1, pat[g + 1]);
         if (pat[g] != TERN_CENTER) {
             if (pat[g] < TERN_CENTER) p.y = p.y.neg();
-            acc.madd(p);
+            if constexpr (sizeof(F) == 32) acc.template madd_w<false>(p);      // weak form, shared out-of-line multiplier
+            else acc.madd(p);
         }
         p = pn;
     }
+    if constexpr (sizeof(F) == 32) acc = acc.canon();
     part[b * part_stride + part_off + chunk] = acc;
 }
 

@@ -10,6 +10,9 @@
 // contiguous 64 x 32 B = 2 KiB segment and every twiddle is wave-uniform.  A thread keeps 2^K
 // elements in VGPRs and performs K butterfly stages per HBM round trip.
 //
+// All butterflies work in WEAK form (field.cuh: values in [0, 2r), no conditional subtraction in the multiplier): the passes
+// read and write weak values, and whatever consumes a transform multiplies first (products A*B, the 1/n scaling, from_mont),
+// which returns to canonical form.
 // Like gnark we never run a bit-reversal pass: inverse transforms are DIF (natural in, bit-reversed
 // out), forward transforms are DIT (bit-reversed in, natural out).  The prover only runs the pair
 // inverse + coset-forward on a and b (to_coset); the rest of computeH lives in the folded key (keyfold.hip).
@@ -106,16 +109,16 @@ __global__ __launch_bounds__(256) void k_ntt_dif(Fr *__restrict__ data, size_t B
             if ((m / half) & 1) continue;
             const size_t j = p + ((size_t)(m % half) << logS);
             Fr u = x[m], v = x[m + half];
-            x[m] = u + v;
-            Fr d = u - v;
-            x[m + half] = (j == 0) ? d : d * tw[j << twshift];
+            x[m] = Fr::add_w(u, v);
+            Fr d = Fr::sub_w(u, v);
+            x[m + half] = (j == 0) ? d : Fr::mul_wc(d, tw[j << twshift]);
         }
     }
 #pragma unroll
     for (int m = 0; m < R; m++) {
         const size_t idx = base + ((size_t)m << logS);
         Fr v = x[m];
-        if (postmul) v = v * postmul[idx];
+        if (postmul) v = Fr::mul_wc(v, postmul[idx]);
         data[idx * B + b] = v;
     }
 }
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(256) void k_ntt_dit(Fr *__restrict__ data, size_t B
     for (int m = 0; m < R; m++) {
         const size_t idx = base + ((size_t)m << logS);
         Fr v = data[idx * B + b];
-        if (premul) v = v * premul[idx];
+        if (premul) v = Fr::mul_wc(v, premul[idx]);
         x[m] = v;
     }
 #pragma unroll
@@ -151,9 +154,9 @@ __global__ __launch_bounds__(256) void k_ntt_dit(Fr *__restrict__ data, size_t B
             if ((m >> st) & 1) continue;
             const size_t j = p + ((size_t)(m & (h - 1)) << logS);
             Fr u = x[m];
-            Fr v = (j == 0) ? x[m + h] : x[m + h] * tw[j << twshift];
-            x[m] = u + v;
-            x[m + h] = u - v;
+            Fr v = (j == 0) ? x[m + h] : Fr::mul_wc(x[m + h], tw[j << twshift]);
+            x[m] = Fr::add_w(u, v);
+            x[m + h] = Fr::sub_w(u, v);
         }
     }
 #pragma unroll
@@ -221,9 +224,9 @@ __global__ __launch_bounds__(ZK_NTT_TILE / 8) void k_ntt_dif_lds(Fr *__restrict_
                     if ((m / half) & 1) continue;
                     const size_t j = p + (((size_t)q + (size_t)STR * (m % half)) << logS);
                     Fr u = x[m], v = x[m + half];
-                    x[m] = u + v;
-                    Fr d = u - v;
-                    x[m + half] = (j == 0) ? d : d * tw[j << twshift];
+                    x[m] = Fr::add_w(u, v);
+                    Fr d = Fr::sub_w(u, v);
+                    x[m + half] = (j == 0) ? d : Fr::mul_wc(d, tw[j << twshift]);
                 }
             }
 #pragma unroll
@@ -246,9 +249,9 @@ __global__ __launch_bounds__(ZK_NTT_TILE / 8) void k_ntt_dif_lds(Fr *__restrict_
                     if ((m / half) & 1) continue;
                     const size_t j = p + ((size_t)(m % half) << logS);
                     Fr u = x[m], v = x[m + half];
-                    x[m] = u + v;
-                    Fr d = u - v;
-                    x[m + half] = (j == 0) ? d : d * tw[j << twshift];
+                    x[m] = Fr::add_w(u, v);
+                    Fr d = Fr::sub_w(u, v);
+                    x[m + half] = (j == 0) ? d : Fr::mul_wc(d, tw[j << twshift]);
                 }
             }
             if (active) {
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(ZK_NTT_TILE / 8) void k_ntt_dif_lds(Fr *__restrict_
                 for (int m = 0; m < R2; m++) {
                     const size_t idx = base + (((size_t)q2 * R2 + m) << logS);
                     Fr v = x[m];
-                    if (postmul) v = v * postmul[idx];
+                    if (postmul) v = Fr::mul_wc(v, postmul[idx]);
                     data[idx * B + b] = v;
                 }
             }
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(ZK_NTT_TILE / 8) void k_ntt_dit_lds(Fr *__restrict_
             for (int m = 0; m < R1; m++) {
                 const size_t idx = base + (((size_t)q * R1 + m) << logS);
                 Fr v = active ? data[idx * B + b] : Fr::zero();
-                if (premul) v = v * premul[idx];
+                if (premul) v = Fr::mul_wc(v, premul[idx]);
                 x[m] = v;
             }
 #pragma unroll
@@ -300,9 +303,9 @@ __global__ __launch_bounds__(ZK_NTT_TILE / 8) void k_ntt_dit_lds(Fr *__restrict_
                     if ((m >> st) & 1) continue;
                     const size_t j = p + ((size_t)(m & (h - 1)) << logS);
                     Fr u = x[m];
-                    Fr v = (j == 0) ? x[m + h] : x[m + h] * tw[j << twshift];
-                    x[m] = u + v;
-                    x[m + h] = u - v;
+                    Fr v = (j == 0) ? x[m + h] : Fr::mul_wc(x[m + h], tw[j << twshift]);
+                    x[m] = Fr::add_w(u, v);
+                    x[m + h] = Fr::sub_w(u, v);
                 }
             }
 #pragma unroll
@@ -325,9 +328,9 @@ __global__ __launch_bounds__(ZK_NTT_TILE / 8) void k_ntt_dit_lds(Fr *__restrict_
                     if ((m >> st) & 1) continue;
                     const size_t j = p + (((size_t)q2 + (size_t)R1 * (m & (h - 1))) << logS);
                     Fr u = x[m];
-                    Fr v = (j == 0) ? x[m + h] : x[m + h] * tw[j << twshift];
-                    x[m] = u + v;
-                    x[m + h] = u - v;
+                    Fr v = (j == 0) ? x[m + h] : Fr::mul_wc(x[m + h], tw[j << twshift]);
+                    x[m] = Fr::add_w(u, v);
+                    x[m + h] = Fr::sub_w(u, v);
                 }
             }
             if (active) {
@@ -414,7 +417,7 @@ __global__ __launch_bounds__(256) void k_quotient_pointwise(Fr *__restrict__ a, 
                                                             const Fr *__restrict__ consts, size_t total) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    a[i] = (a[i] * b[i] - c[i]) * consts[4];
+    a[i] = (a[i] * b[i] - c[i].canon()) * consts[4];          // the transforms leave weak-form values (see below); '*' canonicalises, '-' needs it done
 }
 
 // computeH: a,b,c hold per-constraint values (rows >= nb_constraints zero), layout [n][B].
