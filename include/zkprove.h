@@ -99,6 +99,18 @@ int zkp_bench_step(int algorithmID, float *times7);
  * times8: phase times of the last pass, [6] = whole call / nsteps */
 int zkp_bench_steps(int algorithmID, int nsteps, float *times8);
 int zkp_bench_fetch(int algorithmID, uint8_t *proofs, uint32_t *errs);
+/* Split mode: ONE proof (or a small batch) over several GPUs, the north_star's "RCCL over xGMI only for the final bucket
+ * reduction" (latency mode).  One process per GPU; rank r keeps slice r of every base set of the key:
+ *   ZkpSetSplit(rank, world)  before InitAlgorithm;
+ *   zkp_bench_upload(...)     the same batch on every rank (same r, s);
+ *   zkp_split_partials(id, out)   solve + transforms (replicated) + this rank's slices of the five MSMs;
+ *                                 out = [batch][384]: partial sums Ar, Bs1, K, Z (G1 affine, 64 B each), Bs2 (G2 affine, 128 B), Montgomery LE
+ *   all_gather of the records by the caller (RCCL on the GPU box, gloo in the CPU-side test harness);
+ *   zkp_split_finish(id, world, gathered)   gathered = [world][batch][384]: sums them, blinds, finishes;
+ *   zkp_bench_fetch(...)      every rank holds the same proofs, byte-identical to the unsplit prover's. */
+int ZkpSetSplit(int rank, int world);
+int zkp_split_partials(int algorithmID, uint8_t *out384);
+int zkp_split_finish(int algorithmID, int world, const uint8_t *gathered);
 /* after a step: copy out the solved wire vectors [batch][n_wires][32] and the quotient-stage products
  * f_i = A(g w^i) * B(g w^i) [batch][N][32] (canonical LE, natural order; the scalars of the folded quotient MSM, see
  * csrc/keyfold.hip) -- parity tests only */

@@ -87,6 +87,10 @@ _sig("zkp_bench_step", _i32, [_i32, _vp])
 _sig("zkp_bench_fetch", _i32, [_i32, _vp, _vp])
 _sig("zkp_bench_steps", _i32, [_i32, _i32, _vp])
 _sig("zkp_debug_fetch", _i32, [_i32, _vp, _vp])
+_sig("ZkpSetSplit", _i32, [_i32, _i32])
+_sig("zkp_split_partials", _i32, [_i32, _vp])
+_sig("zkp_split_finish", _i32, [_i32, _i32, _vp])
+_sig("ZkpDeviceReplicas", _i32, [_i32])
 _sig("zkp_request_witness", _i32, [GoSlice, _vp, _i64, _vp, _i64, C.POINTER(C.c_long), C.POINTER(C.c_long)])
 _sig("zkp_last_panic", C.c_char_p, [])
 _sig("zkp_proof_serialize", _i64, [_vp, _i32, _vp, _i64])
@@ -189,6 +193,19 @@ class ResidentBatch:
         if lib.zkp_bench_fetch(self.alg, proofs.ctypes.data, errs.ctypes.data) != 0:
             raise RuntimeError("zkp_bench_fetch failed")
         return proofs, errs
+
+    def split_partials(self):
+        """split mode (ZkpSetSplit): this rank's partial sums, [batch][384] uint8"""
+        out = _np.zeros((self.batch, 384), _np.uint8)
+        if lib.zkp_split_partials(self.alg, out.ctypes.data) != 0:
+            raise RuntimeError("zkp_split_partials failed")
+        return out
+
+    def split_finish(self, gathered):
+        g = _np.ascontiguousarray(gathered, _np.uint8)
+        assert g.ndim == 3 and g.shape[1:] == (self.batch, 384)
+        if lib.zkp_split_finish(self.alg, int(g.shape[0]), g.ctypes.data) != 0:
+            raise RuntimeError("zkp_split_finish failed")
 
     def debug(self, n_wires, domain):
         wires = _np.zeros((self.batch, n_wires, 32), _np.uint8)

@@ -469,6 +469,13 @@ int ZkpSetDevice(int device) {
     try { bind_device(device); } catch (const std::exception &) { return -1; }
     return 0;
 }
+// Split mode (one proof over several GPUs): this process is rank `rank` of `world`; call before InitAlgorithm.
+int g_split_rank = 0, g_split_world = 1;
+int ZkpSetSplit(int rank, int world) {
+    if (world < 1 || rank < 0 || rank >= world) return -1;
+    g_split_rank = rank; g_split_world = world;
+    return 0;
+}
 int ZkpDeviceReplicas(int algorithmID) {
     if (algorithmID < 0 || algorithmID >= 3) return 0;
     return (int)get_replicas(algorithmID).size();
@@ -512,6 +519,7 @@ unsigned char InitAlgorithm(unsigned char algorithmID, GoSlice provingKey, GoSli
             try {
                 std::unique_ptr<Algorithm> a(new Algorithm());
                 a->device = devs[k];
+                a->split_rank = g_split_rank; a->split_world = g_split_world;
                 a->load((const uint8_t *)provingKey.data, (size_t)provingKey.len, (const uint8_t *)r1cs.data, (size_t)r1cs.len);
                 reps[k] = std::move(a);
             } catch (const std::exception &e) {
@@ -642,6 +650,23 @@ int zkp_bench_fetch(int id, uint8_t *proofs, uint32_t *errs) {
     Algorithm *a = (id >= 0 && id < 3) ? get_alg(id) : nullptr;
     if (!a || !a->res) throw ZkError("algorithm not initialised / nothing uploaded");
     a->resident_download((ProofPoints *)proofs, errs);
+    return 0;
+    CABI_CATCH
+}
+int zkp_split_partials(int id, uint8_t *out384) {
+    CABI_TRY
+    Algorithm *a = (id >= 0 && id < 3) ? get_alg(id) : nullptr;
+    if (!a || !a->res) throw ZkError("algorithm not initialised / nothing uploaded");
+    a->split_partials(out384);
+    return 0;
+    CABI_CATCH
+}
+int zkp_split_finish(int id, int world, const uint8_t *gathered) {
+    CABI_TRY
+    Algorithm *a = (id >= 0 && id < 3) ? get_alg(id) : nullptr;
+    if (!a || !a->res) throw ZkError("algorithm not initialised / nothing uploaded");
+    if (world != a->split_world) throw ZkError("split_finish: world size differs from ZkpSetSplit");
+    a->split_finish(world, gathered);
     return 0;
     CABI_CATCH
 }

@@ -42,6 +42,14 @@ class Algorithm {
     bool has_commit = false;
     size_t commit_level = 0;
     int device = 0;          // the HIP device that holds this replica's key and buffers; every entry below binds it on the calling thread
+    // Split mode (SURVEY 8e "single-proof latency mode"): this process is rank split_rank of split_world and keeps slice split_rank
+    // of every base set of the key (the Pedersen bases stay whole: the commitment is needed in the middle of the solve).  Every rank
+    // solves and transforms the whole batch, multiplies its slices (split_partials), the ranks exchange the five partial sums per
+    // proof (RCCL / gloo all_gather by the caller) and each finishes the proof from the gathered sums (split_finish).
+    int split_rank = 0, split_world = 1;
+    size_t z_offset = 0;     // first coset point of this rank's slice of the quotient bases
+    void split_partials(uint8_t *out384);                       // [B][384]: Ar, Bs1, K, Z (64 B each), Bs2 (128 B), affine Montgomery LE
+    void split_finish(int world, const uint8_t *gathered);      // [world][B][384] -> proofs (then resident_download)
 
     // throws ZkError
     void load(const uint8_t *pk_bytes, size_t pk_len, const uint8_t *r1cs_bytes, size_t r1cs_len);

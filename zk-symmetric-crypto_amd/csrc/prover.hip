@@ -215,16 +215,25 @@ void Algorithm::load(const uint8_t *pkb, size_t pk_len, const uint8_t *r1cs_byte
     pk.delta_tab.alloc(32 * 255); pk.delta2_tab.alloc(32 * 255);
     hipLaunchKernelGGL(k_fixed_table<Fp>, dim3(ceil_div(32 * 255, 64)), dim3(64), 0, st, pk.g1_misc.p + 2, pk.delta_tab.p);
     hipLaunchKernelGGL(k_fixed_table<Fp2>, dim3(ceil_div(32 * 255, 64)), dim3(64), 0, st, pk.g2_misc.p + 1, pk.delta2_tab.p);
-    upload_g1(pkb, sA, pts, st); msm_bases_build(pk.A, pts.p, sA.n, rowsA.data(), C_WIRE, st);
-    upload_g1(pkb, sB, pts, st); msm_bases_build(pk.B1, pts.p, sB.n, rowsB.data(), C_WIRE, st);
+    // split mode: slice [lo, hi) of a base set of n points for this rank (whole set when split_world == 1)
+    auto slice = [&](size_t n, size_t &lo, size_t &hi) {
+        const size_t base = n / (size_t)split_world, rem = n % (size_t)split_world, r = (size_t)split_rank;
+        lo = r * base + (r < rem ? r : rem);
+        hi = lo + base + (r < rem ? 1 : 0);
+    };
+    size_t lo, hi;
+    upload_g1(pkb, sA, pts, st); slice(sA.n, lo, hi); msm_bases_build(pk.A, pts.p + lo, hi - lo, rowsA.data() + lo, C_WIRE, st);
+    upload_g1(pkb, sB, pts, st); slice(sB.n, lo, hi); msm_bases_build(pk.B1, pts.p + lo, hi - lo, rowsB.data() + lo, C_WIRE, st);
     {   // quotient bases in evaluation form (keyfold.hip): Z becomes one base per coset point (dense MSM over A*B on the coset),
         // and the part of the quotient that is linear in the wires (through c = O w) moves into the bases of K.
         upload_g1(pkb, sZ, pts, st);
         const size_t ncons = cs.nb_constraints;
         DevBuf<G1Affine> ze(N), zc(ncons);
         fold_quotient_bases(pts.p, dom, ncons, ze.p, zc.p, st);
-        msm_bases_build(pk.Z, ze.p, N, nullptr, C_H, st);
+        slice(N, lo, hi);
+        msm_bases_build(pk.Z, ze.p + lo, hi - lo, nullptr, C_H, st);
         pk.Z.dense_stride = N;
+        z_offset = lo;
         std::vector<OutputTerm> terms;
         for (size_t i = 0; i < cs.nb_instructions(); i++) {
             if (cs.bp_kind[cs.blueprint_id[i]] != BP_R1C) continue;
@@ -238,7 +247,8 @@ void Algorithm::load(const uint8_t *pkb, size_t pk_len, const uint8_t *r1cs_byte
         DevBuf<G1Affine> kf;
         std::vector<uint32_t> rowsKf;
         fold_output_matrix(zc.p, pts.p, rowsK, std::move(terms), coeffs.p, kf, rowsKf, st);
-        msm_bases_build(pk.K, kf.p, rowsKf.size(), rowsKf.data(), C_WIRE, st);
+        slice(rowsKf.size(), lo, hi);
+        msm_bases_build(pk.K, kf.p + lo, hi - lo, rowsKf.data() + lo, C_WIRE, st);
     }
     pk.n_ped = 0;
     if (has_commit) {
@@ -247,7 +257,7 @@ void Algorithm::load(const uint8_t *pkb, size_t pk_len, const uint8_t *r1cs_byte
         pk.n_ped = sPed.n;
     }
     DevBuf<G2Affine> pts2;
-    upload_g2(pkb, sB2, pts2, st); msm_bases_build(pk.B2, pts2.p, sB2.n, rowsB.data(), C_WIRE, st);
+    upload_g2(pkb, sB2, pts2, st); slice(sB2.n, lo, hi); msm_bases_build(pk.B2, pts2.p + lo, hi - lo, rowsB.data() + lo, C_WIRE, st);
     ZK_HIP(hipDeviceSynchronize());
 }
 
@@ -577,7 +587,7 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm,
         msm_batch(pk.B1, S.sb.wires.p, B, R.ms, R.m_bs1.p, st);            // beside the A MSM; the main stream's own chain is the shortest
         ZK_HIP(hipEventRecord(R.ev[12], st));
         ZK_HIP(hipStreamWaitEvent(tail, R.ev[12], 0));
-        enqueue_tail_early(S, tail);
+        if (split_world == 1) enqueue_tail_early(S, tail);
         dom.dif(S.sb.a.p, B, true, nullptr, st);
         dom.dit(S.sb.a.p, B, false, dom.coset_pre.p, st);
     } else {
@@ -592,7 +602,7 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm,
         fr_transpose_mul(S.sb.a.p, S.sb.b.p, S.sb.c.p, N, B, N, st);
         ZK_HIP(hipEventRecord(R.ev[17], st));
         ZK_HIP(hipStreamWaitEvent(R.copy_stream, R.ev[17], 0));
-        presorted = msm_dense_presort(pk.Z, S.sb.c.p, B, R.ms, R.copy_stream);
+        presorted = msm_dense_presort(pk.Z, S.sb.c.p + z_offset, B, R.ms, R.copy_stream);
         if (presorted) ZK_HIP(hipEventRecord(R.ev[18], R.copy_stream));
         msm_batch(pk.A, S.sb.wires.p, B, R.ms, R.m_ar.p, st);
         msm_batch(pk.B1, S.sb.wires.p, B, R.ms, R.m_bs1.p, st);
@@ -600,7 +610,7 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm,
         // dependent doublings whatever the batch size) start now on the tail stream, under the remaining MSMs
         ZK_HIP(hipEventRecord(R.ev[12], st));
         ZK_HIP(hipStreamWaitEvent(tail, R.ev[12], 0));
-        enqueue_tail_early(S, tail);
+        if (split_world == 1) enqueue_tail_early(S, tail);
     }
     ZK_HIP(hipEventRecord(R.ev[5], st));
     // the G2 sum next, so that its blinding and affine conversion also run under the two largest MSMs.  A small batch is a chain of
@@ -613,7 +623,8 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm,
     msm_batch(pk.B2, S.sb.wires.p, B, side ? R.ms_g2 : R.ms, R.m_bs2.p, g2);
     ZK_HIP(hipEventRecord(R.ev[6], g2));
     ZK_HIP(hipStreamWaitEvent(tail, R.ev[6], 0));
-    hipLaunchKernelGGL(k_finalize_g2, dim3(ceil_div(B, 64)), dim3(64), 0, tail, R.m_bs2.p, pk.g2_misc.p, pk.delta2_tab.p, S.s.p, S.out.p, B);
+    if (split_world == 1)
+        hipLaunchKernelGGL(k_finalize_g2, dim3(ceil_div(B, 64)), dim3(64), 0, tail, R.m_bs2.p, pk.g2_misc.p, pk.delta2_tab.p, S.s.p, S.out.p, B);
     if (!side) msm_batch(pk.K, S.sb.wires.p, B, R.ms, R.m_k.p, st);
     // sum_k h_k Z_k = sum_i (a_i b_i) Ze_i + (a part linear in the wires that sits in K); c only serves as the buffer of the
     // instance-major products
@@ -622,7 +633,7 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm,
         fr_transpose_mul(S.sb.a.p, S.sb.b.p, S.sb.c.p, N, B, N, st);
     }
     if (presorted) ZK_HIP(hipStreamWaitEvent(st, R.ev[18], 0));
-    msm_batch(pk.Z, S.sb.c.p, B, R.ms, R.m_z.p, st, &R.ev[8]);
+    msm_batch(pk.Z, S.sb.c.p + z_offset, B, R.ms, R.m_z.p, st, &R.ev[8]);
     ZK_HIP(hipGetLastError());
     if (side) {                                                  // the batch's sums are complete only when the side streams are done too
         ZK_HIP(hipStreamWaitEvent(st, R.ev[6], 0));
@@ -737,6 +748,76 @@ void Algorithm::resident_prove_pipelined(int nsteps, PhaseTimes *times) {
         ZK_HIP(hipEventElapsedTime(&tot, R.ev[0], R.ev[7]));
         times->total = tot / nsteps;
     }
+}
+
+// ---- split mode -----------------------------------------------------------------------------------------------------
+// record per proof: Ar | Bs1 | K | Z partial sums as G1 affine (Montgomery, 64 B each), Bs2 partial as G2 affine (128 B)
+struct SplitRecord { G1Affine ar, bs1, k, z; G2Affine bs2; };
+static_assert(sizeof(SplitRecord) == 384, "split record layout");
+__global__ __launch_bounds__(64) void k_split_pack(const G1XYZZ *__restrict__ m_ar, const G1XYZZ *__restrict__ m_bs1, const G1XYZZ *__restrict__ m_k,
+                                                   const G1XYZZ *__restrict__ m_z, const G2XYZZ *__restrict__ m_bs2, SplitRecord *__restrict__ out, size_t B) {
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int task = blockIdx.y;
+    if (task == 0) out[b].ar = m_ar[b].to_affine();
+    else if (task == 1) out[b].bs1 = m_bs1[b].to_affine();
+    else if (task == 2) out[b].k = m_k[b].to_affine();
+    else if (task == 3) out[b].z = m_z[b].to_affine();
+    else out[b].bs2 = m_bs2[b].to_affine();
+}
+// sums of the gathered partials: in [world][B] records -> the five sums of the ordinary pipeline
+__global__ __launch_bounds__(64) void k_split_sum(const SplitRecord *__restrict__ in, int world, G1XYZZ *__restrict__ m_ar, G1XYZZ *__restrict__ m_bs1,
+                                                  G1XYZZ *__restrict__ m_k, G1XYZZ *__restrict__ m_z, G2XYZZ *__restrict__ m_bs2, size_t B) {
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int task = blockIdx.y;
+    if (task < 4) {
+        G1XYZZ acc = G1XYZZ::inf();
+        for (int r = 0; r < world; r++) {
+            const SplitRecord &rec = in[(size_t)r * B + b];
+            acc.madd(task == 0 ? rec.ar : task == 1 ? rec.bs1 : task == 2 ? rec.k : rec.z);
+        }
+        (task == 0 ? m_ar : task == 1 ? m_bs1 : task == 2 ? m_k : m_z)[b] = acc;
+    } else {
+        G2XYZZ acc = G2XYZZ::inf();
+        for (int r = 0; r < world; r++) acc.madd(in[(size_t)r * B + b].bs2);
+        m_bs2[b] = acc;
+    }
+}
+void Algorithm::split_partials(uint8_t *out384) {
+    std::lock_guard<std::mutex> lk(mu);
+    bind_device(device);
+    if (!res) throw ZkError("split_partials: nothing uploaded");
+    Resident &R = *res;
+    const size_t B = R.B;
+    hipStream_t st = R.stream;
+    R.last_set = 0;
+    enqueue_solve(R.set[0], R.ms, st);
+    enqueue_main(R.set[0], st, nullptr, R.stream3);          // split_world > 1: the tail is not started
+    // the sums are complete once the main stream AND the tail stream (which carries the A MSM of a small batch) are through
+    ZK_HIP(hipEventRecord(R.ev[10], st));
+    ZK_HIP(hipStreamWaitEvent(R.stream3, R.ev[10], 0));
+    DevBuf<SplitRecord> rec(B);
+    hipLaunchKernelGGL(k_split_pack, dim3(ceil_div(B, 64), 5), dim3(64), 0, R.stream3, R.m_ar.p, R.m_bs1.p, R.m_k.p, R.m_z.p, R.m_bs2.p, rec.p, B);
+    ZK_HIP(hipMemcpyAsync(out384, rec.p, B * sizeof(SplitRecord), hipMemcpyDeviceToHost, R.stream3));
+    ZK_HIP(hipStreamSynchronize(R.stream3));
+    ZK_HIP(hipStreamSynchronize(st));
+}
+void Algorithm::split_finish(int world, const uint8_t *gathered) {
+    std::lock_guard<std::mutex> lk(mu);
+    bind_device(device);
+    if (!res) throw ZkError("split_finish: nothing uploaded");
+    Resident &R = *res;
+    const size_t B = R.B;
+    hipStream_t st = R.stream3;
+    DevBuf<SplitRecord> rec((size_t)world * B);
+    ZK_HIP(hipMemcpyAsync(rec.p, gathered, (size_t)world * B * sizeof(SplitRecord), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_split_sum, dim3(ceil_div(B, 64), 5), dim3(64), 0, st, rec.p, world, R.m_ar.p, R.m_bs1.p, R.m_k.p, R.m_z.p, R.m_bs2.p, B);
+    SolveSet &S = R.set[0];
+    enqueue_tail_early(S, st);
+    hipLaunchKernelGGL(k_finalize_g2, dim3(ceil_div(B, 64)), dim3(64), 0, st, R.m_bs2.p, pk.g2_misc.p, pk.delta2_tab.p, S.s.p, S.out.p, B);
+    enqueue_finalize(S, st);
+    ZK_HIP(hipStreamSynchronize(st));
 }
 
 void Algorithm::resident_download(ProofPoints *out, uint32_t *errs) {
