@@ -85,8 +85,8 @@ struct XYZZ {
     }
     // this += q with the accumulator kept in WEAK form (coordinates in [0, 2M), field.cuh).  Same formulas and special cases as
     // madd / add; q may be canonical or weak; the caller stores canon().  INL expands the multiplier block in place (innermost
-    // loop of the bucket accumulation), otherwise the shared out-of-line weak multiplier is called.  Fp only (the Fp2 tower stays
-    // canonical).
+    // loop of the G1 bucket accumulation), otherwise the shared out-of-line weak multiplier is called.
+    // (Fp2 offers the same static interface with its coordinates weak; INL is ignored there.)
     template <bool INL>
     static ZK_HD F wmul(const F &a, const F &b) {
         if constexpr (INL) return F::mul_w(a, b);

@@ -602,6 +602,17 @@ struct Fp2 {
         Fp n = (a0.sqr() + a1.sqr()).inv();
         return Fp2{a0 * n, (a1 * n).neg()};
     }
+    // weak form (both coordinates in [0, 2p), see Field): same static interface as Field so that XYZZ::madd_w / add_w serve G2 too
+    ZK_HD Fp2 canon() const { return Fp2{a0.canon(), a1.canon()}; }
+    ZK_HD bool is_zero_w() const { return a0.is_zero_w() && a1.is_zero_w(); }
+    static ZK_HD Fp2 add_w(const Fp2 &a, const Fp2 &b) { return Fp2{Fp::add_w(a.a0, b.a0), Fp::add_w(a.a1, b.a1)}; }
+    static ZK_HD Fp2 sub_w(const Fp2 &a, const Fp2 &b) { return Fp2{Fp::sub_w(a.a0, b.a0), Fp::sub_w(a.a1, b.a1)}; }
+    static ZK_HD Fp2 mul_wc(const Fp2 &a, const Fp2 &b) {
+        const Fp t0 = Fp::mul_wc(a.a0, b.a0), t1 = Fp::mul_wc(a.a1, b.a1);
+        const Fp m = Fp::mul_wc(Fp::add_w(a.a0, a.a1), Fp::add_w(b.a0, b.a1));
+        return Fp2{Fp::sub_w(t0, t1), Fp::sub_w(Fp::sub_w(m, t0), t1)};
+    }
+    static ZK_HD Fp2 mul_w(const Fp2 &a, const Fp2 &b) { return mul_wc(a, b); }      // the tower never expands the block in place
     ZK_HD Fp2 to_mont() const { return Fp2{a0.to_mont(), a1.to_mont()}; }
     ZK_HD Fp2 from_mont() const { return Fp2{a0.from_mont(), a1.from_mont()}; }
 };

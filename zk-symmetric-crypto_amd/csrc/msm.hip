@@ -449,17 +449,14 @@ __global__ __launch_bounds__(256) void k_msm_binsort(const uint32_t *__restrict_
 // sums[b * nb + k] receives the sum of bucket k when it is non-empty (empty buckets are never written;
 // the reduce kernel reads emptiness from bucket_start).
 // DENSE only names the instantiation (quotient MSM vs. wire MSMs) so that profiler summaries keep the dominant launch apart.
-// G1 accumulates in weak form with the multiplier expanded in place (madd_w); G2 uses the plain mixed addition
+// both groups accumulate in weak form (madd_w); G1 with the multiplier expanded in place, G2 through the shared out-of-line copy
 template <class F>
 __device__ __forceinline__ void acc_madd(XYZZ<F> &acc, const Affine<F> &p) {
-    if constexpr (sizeof(F) == 32) acc.madd_w(p);
-    else acc.madd(p);
+    if constexpr (sizeof(F) == 32) acc.template madd_w<true>(p);
+    else acc.template madd_w<false>(p);
 }
 template <class F>
-__device__ __forceinline__ XYZZ<F> acc_store(const XYZZ<F> &acc) {
-    if constexpr (sizeof(F) == 32) return acc.canon();
-    else return acc;
-}
+__device__ __forceinline__ XYZZ<F> acc_store(const XYZZ<F> &acc) { return acc.canon(); }
 template <class F, bool DENSE>
 __device__ __forceinline__ void accumulate_body(const Affine<F> *__restrict__ table, const uint32_t *__restrict__ bucket_start,
                                                 const uint32_t *__restrict__ entries, size_t max_entries, int c, size_t B,
@@ -555,16 +552,11 @@ __global__ __launch_bounds__(64) void k_msm_bucket_reduce(const XYZZ<F> *__restr
     uint32_t hi = bs[s0 + L];
     for (int k = (int)L - 1; k >= 0; k--) {
         const uint32_t lo = bs[s0 + k];
-        if constexpr (sizeof(F) == 32) {        // G1: both running sums in weak form (curve.cuh add_w)
-            if (hi > lo) run.add_w(in[s0 + k]);
-            tot.add_w(run);
-        } else {
-            if (hi > lo) run.add(in[s0 + k]);
-            tot.add(run);
-        }
+        if (hi > lo) run.add_w(in[s0 + k]);     // both running sums in weak form (curve.cuh add_w)
+        tot.add_w(run);
         hi = lo;
     }
-    if constexpr (sizeof(F) == 32) { run = run.canon(); tot = tot.canon(); }
+    run = run.canon(); tot = tot.canon();
     // contribution = tot + s0 * run   (bucket index i carries weight i+1)
     if (s0 != 0 && !run.is_inf()) {
         XYZZ<F> m = XYZZ<F>::inf();
@@ -651,12 +643,11 @@ __global__ __launch_bounds__(256, ZK_FP2_WAVES(F)) void k_msm_ones(const Affine<
         if (g + 1 < ONES_GROUPS && pat[g + 1] != TERN_CENTER) pn = fetch(g + 1, pat[g + 1]);
         if (pat[g] != TERN_CENTER) {
             if (pat[g] < TERN_CENTER) p.y = p.y.neg();
-            if constexpr (sizeof(F) == 32) acc.template madd_w<false>(p);      // weak form, shared out-of-line multiplier
-            else acc.madd(p);
+            acc.template madd_w<false>(p);      // weak form, shared out-of-line multiplier
         }
         p = pn;
     }
-    if constexpr (sizeof(F) == 32) acc = acc.canon();
+    acc = acc.canon();
     part[b * part_stride + part_off + chunk] = acc;
 }
 
