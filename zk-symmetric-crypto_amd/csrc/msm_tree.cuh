@@ -289,7 +289,7 @@ ZK_HD void tree_piece(const Affine<F> *__restrict__ table, const uint32_t *bs, c
             if (used == 0) break;                                // wave-uniform: the longest lane
             if (dbg & 32) { if (used < TREE_CH) break; continue; }      // timing experiment: forward pass only (results are garbage)
             // ---- one inversion per thread and chunk
-            const F inv = (dbg & 1) ? cprod.inv() : field_inv_shared<F>(cprod);
+            const F inv = field_inv_shared<F>(cprod);
             if (r == 1) TreeBwd<F, true>::run(table, in, out, out_final, pref, desc, stride, inv, used, cnt);
             else TreeBwd<F, false>::run(table, in, out, out_final, pref, desc, stride, inv, used, cnt);
             if (used < TREE_CH) break;                           // every lane ran out of pairs inside this chunk

@@ -259,7 +259,7 @@ template <class F, bool GCD>
 __global__ __launch_bounds__(256) void k_bench_inv(F *x, int iters) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     F a = x[i];
-    for (int k = 0; k < iters; k++) a = (GCD ? a.inv_gcd() : a.inv()) + F::one();
+    for (int k = 0; k < iters; k++) a = (GCD ? a.inv_gcd() : a.inv_fermat()) + F::one();
     x[i] = a;
 }
 // out[i] = in[i]^-1 by the binary-GCD inversion (Montgomery form in and out)
