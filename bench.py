@@ -196,16 +196,24 @@ def run_rank(args):
     import numpy as np
     import torch
     dist = None
+    # ZKP_BENCH_BACKEND=gloo + ZKP_BENCH_ONE_DEVICE=1: every rank on device 0 and the collectives over gloo (CPU tensors) -- lets a
+    # 1-GPU box run the real N-rank path (tests/test_gpu_configs.py); the default is one GPU per rank and RCCL
+    backend = os.environ.get("ZKP_BENCH_BACKEND", "nccl")
+    device_index = 0 if os.environ.get("ZKP_BENCH_ONE_DEVICE") else local_rank
     if world > 1 or os.environ.get("ZKP_BENCH_FORCE_DIST"):       # the env switch exercises the RCCL path on a 1-GPU box
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            torch.cuda.set_device(device_index)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
 
     zk = importlib.import_module("zk-symmetric-crypto_amd")
     if zk.device_count() < 1:
         raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
-    if zk.lib.ZkpSetDevice(local_rank) != 0:
-        raise SystemExit("ZkpSetDevice(%d) failed" % local_rank)
+    if zk.lib.ZkpSetDevice(device_index) != 0:
+        raise SystemExit("ZkpSetDevice(%d) failed" % device_index)
     zk.lib.ZkpAllowUnpinnedKeys(1)
     H = zk.synth
     B, K = args.batch, args.steps
@@ -228,7 +236,7 @@ def run_rank(args):
         dt = dt_local
         per_rank = [dt_local]
         if dist is not None:
-            t = torch.tensor([dt_local], dtype=torch.float64, device="cuda")
+            t = torch.tensor([dt_local], dtype=torch.float64, device=coll_dev)
             every = [torch.zeros_like(t) for _ in range(world)]
             dist.all_gather(every, t)
             per_rank = [float(x.item()) for x in every]
@@ -239,10 +247,11 @@ def run_rank(args):
         gathered = proofs[None]
         oks = [ok]
         if dist is not None:
-            mine = torch.from_numpy(proofs).cuda()
-            allp = torch.empty((world,) + tuple(mine.shape), dtype=torch.uint8, device="cuda")
-            dist.all_gather_into_tensor(allp, mine)
-            okt = torch.tensor([ok], dtype=torch.int64, device="cuda")
+            mine = torch.from_numpy(proofs).to(coll_dev)
+            parts = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine)
+            allp = torch.stack(parts)
+            okt = torch.tensor([ok], dtype=torch.int64, device=coll_dev)
             okall = [torch.zeros_like(okt) for _ in range(world)]
             dist.all_gather(okall, okt)
             oks = [int(x.item()) for x in okall]
@@ -298,7 +307,7 @@ def run_rank(args):
             "ms_per_step": h["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32x8 (254-bit Montgomery, integer)", "data": "synthetic",
             "config": {"workload": h["workload"], "algorithm_id": args.alg, "batch_per_gpu": B, "pipelined_steps": pipeline,
-                       "parallelism": "dp%d (independent proofs per rank, no data-path collective; RCCL: barrier, timing, all_gather of proof records)" % world,
+                       "parallelism": "dp%d (independent proofs per rank, no data-path collective; %s: barrier, timing, all_gather of proof records)" % (world, "RCCL" if backend == "nccl" else backend),
                        "proofs_total": B * world * K, "blocks_per_s": h["blocks_per_s"],
                        "aes256_ctr_proofs_per_s": lines[2]["value"] if 2 in lines and args.alg != 2 else None},
             "phases_ms": h["phases_ms"],

@@ -169,3 +169,24 @@ def test_in_library_sharding_over_two_device_replicas(alg):
     assert out["replicas"] == 2
     assert out["verified"] == out["n"] == 300
     assert out["thread_proof_matches_oracle"]
+
+
+def test_bench_two_real_ranks_prove_gather_and_verify():
+    """`python bench.py --gpus 2` end to end with two PROVING ranks: the launcher starts them, each proves its own batch, the proof
+    records are gathered and rank 0 verifies instance 0 of EVERY rank's slice against that rank's seed stream.  The box has one GPU, so
+    both ranks use device 0 and the collectives run over gloo (ZKP_BENCH_BACKEND / ZKP_BENCH_ONE_DEVICE); on a multi-GPU node the same
+    code path runs with one GPU per rank over RCCL."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(ZKP_BENCH_BACKEND="gloo", ZKP_BENCH_ONE_DEVICE="1")
+    res = subprocess.run([sys.executable, os.path.join(H.ROOT, "bench.py"), "--gpus", "2", "--batch", "96", "--steps", "2", "--warmup", "1",
+                          "--cpu-proofs", "0", "--master-port", str(31500 + os.getpid() % 2000)], env=env, capture_output=True, text=True, timeout=1500)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["proofs_total"] == 2 * 96 * 2
+    assert out["gathered_proof_records"] == 2 * 96 and out["solver_ok"] == 2 * 96
+    assert out["gather_spot_check_verified"] == "2/2"                 # one verified proof from each rank's slice
+    assert len(out["per_rank_proofs_per_s"]) == 2 and out["value"] > 0
+    aes = out["aes256_ctr"]
+    assert aes["gathered_proof_records"] == 2 * 96 and aes["gather_spot_check_verified"] == "2/2" and aes["solver_ok"] == 2 * 96
