@@ -393,7 +393,9 @@ __global__ __launch_bounds__(PART_THREADS) void k_msm_partition(const Fr *__rest
 
 // grid (nbin, B), 256 threads.  Bins that fit BIN_CAP entries (the normal case: ~4096 +- 64) are sorted entirely in LDS and
 // written back as one linear run; larger bins (adversarial scalar sets) fall back to scattering inside the bin's window.
-static constexpr uint32_t BIN_CAP = 6144;
+// 9 472 = the 8 192 entries per bin of the AES circuits' quotient MSM (2^17 scalars x 16 windows / 256 bins) + 14 sigma; 74 KiB of
+// LDS per workgroup, two workgroups per CU
+static constexpr uint32_t BIN_CAP = 9472;
 __global__ __launch_bounds__(256) void k_msm_binsort(const uint32_t *__restrict__ coarse_base, const uint32_t *__restrict__ part_entries,
                                                      uint32_t *__restrict__ entries, size_t max_entries, int c,
                                                      uint32_t *__restrict__ bucket_start) {
@@ -847,7 +849,7 @@ static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, M
     const uint32_t nb = 1u << (c - 1);
     const uint32_t L = seg_len(nb, B);
     const size_t nseg = nb / L;
-    const size_t nchunks = (n + ONES_CHUNK - 1) / ONES_CHUNK;
+    const size_t nchunks = mb.dense ? 0 : (n + ONES_CHUNK - 1) / ONES_CHUNK;      // the dense MSM has no conditional-sum partials
     const size_t max_entries = n * W;
     const size_t npart = nchunks + nseg;
     const size_t stride = msm_part_stride(n, c);      // level-0 partials followed by the fold levels
@@ -874,7 +876,6 @@ static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, M
         if (sc.presorted) {
             if (ent_p != sc.entries_z.p || split != 1) throw ZkError("msm: presorted dense list without its buffers");
             sc.presorted = false;                        // sorted on another stream; the caller has joined it into s
-            ZK_HIP(hipMemsetAsync(part, 0, B * stride * sizeof(XYZZ<F>), s));
         } else if (split >= 1) {
             // small batch: split every instance into `split` virtual instances (see reserve_dense); everything downstream just sees
             // B * split instances of n / split scalars, and the split results are added at the end
@@ -882,10 +883,8 @@ static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, M
                 msm_dense_split(mb, scalars, B, sc, out, s, seg_events, split);
                 return;
             }
-            ZK_HIP(hipMemsetAsync(part, 0, B * stride * sizeof(XYZZ<F>), s));
             dense_two_level_sort(mb, scalars, B, sc, ent_p, bs_p, s);
         } else {
-            ZK_HIP(hipMemsetAsync(part, 0, B * stride * sizeof(XYZZ<F>), s));
             hipLaunchKernelGGL(k_msm_sort<true>, dim3((unsigned)B), dim3(SORT_THREADS), lds, s, scalars, mb.dense_stride, (const uint32_t *)nullptr,
                                (const uint32_t *)nullptr, (const Fr *)nullptr, n, c, W, bs_p, ent_p, max_entries);
         }
