@@ -1,0 +1,10 @@
+# usage: ab.sh ENVVAR   -> bench with ENVVAR unset, then ENVVAR=1, on the same box
+for v in "" 1; do
+  if [ -n "$v" ]; then export $1=$v; fi
+  python bench.py --cpu-proofs 0 --steps 8 2>/dev/null > /tmp/ab_$v.json
+  python -c "
+import json
+d=json.load(open('/tmp/ab_$v.json')); a=d['aes256_ctr']
+print('$1=$v', round(d['value']), round(d['ms_per_step'],1), 'z', round(d['phases_ms']['z_segments'],1), 'g1', round(d['phases_ms']['msm_g1'],1), d['gather_spot_check_verified'], '| aes', round(a['value']), round(a['ms_per_step'],1), 'g1', round(a['phases_ms']['msm_g1'],1), a['gather_spot_check_verified'])
+"
+done

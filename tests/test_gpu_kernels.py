@@ -286,3 +286,38 @@ def test_msm_affine_tree_production_cut_matches_oracle(piece, cases):
     assert res.returncode == 0, res.stderr[-3000:]
     out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
     assert all(out.values()), out
+
+
+@pytest.mark.parametrize("group", ["g1_dense", "g1_sparse", "g2_sparse"])
+def test_msm_doubling_and_cancellation_inside_a_bucket(zk, oracle, group):
+    """The accumulation loops keep their sums in weak form (field.cuh: coordinates in [0, 2M)), where "x1 == x2" is a test against
+    0 AND M.  Two equal bases with equal scalars meet in the same bucket in every window (P + P: the doubling branch), with
+    opposite scalars they cancel (P - P: infinity in the middle of a bucket), and an infinity base is skipped -- all three inside
+    otherwise random buckets, for the dense path, the sparse bucket path and G2.  Bit-exact against the oracle."""
+    rng = np.random.default_rng(4242)
+    n, batch, c = 600, 3, 9
+    g2 = group.startswith("g2")
+    pts = (oracle.g2_fixed_base if g2 else oracle.g1_fixed_base)(_rand_fr(rng, n))
+    pts[9] = pts[8]
+    pts[21] = pts[20]
+    pts[5] = 0
+    sc = np.stack([_rand_fr(rng, n) for _ in range(batch)])
+    sc[0, 9] = sc[0, 8]                                                                    # P + P in every window
+    neg = lambda row: np.frombuffer(((R - int.from_bytes(row.tobytes(), "little")) % R).to_bytes(32, "little"), np.uint8)
+    sc[1, 9] = neg(sc[1, 8])                                                                # P - P in every window
+    sc[2, 21] = sc[2, 20]; sc[2, 9] = neg(sc[2, 8])                                         # both in one instance
+    if group == "g1_dense":
+        exp = np.stack([oracle.msm_g1(pts, sc[b]) for b in range(batch)])
+        got = np.zeros((batch, 64), np.uint8)
+        assert zk.lib.zkp_msm_g1_dense(n, batch, pts.ctypes.data, sc.ctypes.data, got.ctypes.data, c) == 0
+    elif group == "g1_sparse":
+        sc[:, 100:400] = 0; sc[:, 400:500, :] = 0; sc[:, 400:500, 0] = 1                    # mixed classes: zeros, ones, wide
+        exp = np.stack([oracle.msm_g1(pts, sc[b]) for b in range(batch)])
+        got = np.zeros((batch, 64), np.uint8)
+        assert zk.lib.zkp_msm_g1(n, batch, pts.ctypes.data, sc.ctypes.data, got.ctypes.data, c) == 0
+    else:
+        sc[:, 100:400] = 0
+        exp = np.stack([oracle.msm_g2(pts, sc[b]) for b in range(batch)])
+        got = np.zeros((batch, 128), np.uint8)
+        assert zk.lib.zkp_msm_g2(n, batch, pts.ctypes.data, sc.ctypes.data, got.ctypes.data, c) == 0
+    assert np.array_equal(got, exp)
