@@ -104,10 +104,9 @@ void set_default_device(int dev) {
     g_device_list.clear();
 }
 void bind_device(int dev) {
-    thread_local int bound = -1;            // hipSetDevice is thread-local state; skip the call when this thread already sits on dev
-    if (bound == dev) return;
+    // unconditionally: the calling thread's current device is state this library does not own (the host application -- torch,
+    // another HIP user -- may have changed it since our last call on this thread), and the call is a thread-local store
     ZK_HIP(hipSetDevice(dev));
-    bound = dev;
 }
 }  // namespace zk
 
