@@ -34,6 +34,35 @@ __global__ __launch_bounds__(256) void k(uint64_t *out, uint32_t a0, uint32_t b0
         } else if (MODE == 7) { // v_mov_b32
 #define V(d, e) asm volatile("v_mov_b32 %0, %1" : "=v"(d) : "v"(e));
             V(d0, d1) V(d1, d2) V(d2, d3) V(d3, d4) V(d4, d5) V(d5, d6) V(d6, d7) V(d7, a)
+        } else if (MODE == 8) { // v_mad_i64_i32
+#define MI(c) asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b) : "vcc");
+            MI(c0) MI(c1) MI(c2) MI(c3) MI(c4) MI(c5) MI(c6) MI(c7)
+        } else if (MODE == 9) { // v_alignbit_b32
+#define AB(d, e) asm volatile("v_alignbit_b32 %0, %1, %0, 29" : "+v"(d) : "v"(e));
+            AB(d0, d1) AB(d1, d2) AB(d2, d3) AB(d3, d4) AB(d4, d5) AB(d5, d6) AB(d6, d7) AB(d7, a)
+        } else if (MODE == 10) { // v_ashrrev_i32
+#define AS(d) asm volatile("v_ashrrev_i32 %0, 3, %0" : "+v"(d));
+            AS(d0) AS(d1) AS(d2) AS(d3) AS(d4) AS(d5) AS(d6) AS(d7)
+        } else if (MODE == 11) { // v_lshrrev_b64
+#define LS(c) asm volatile("v_lshrrev_b64 %0, 1, %0" : "+v"(c));
+            LS(c0) LS(c1) LS(c2) LS(c3) LS(c4) LS(c5) LS(c6) LS(c7)
+        } else if (MODE == 12) { // v_and_b32 with literal
+#define AN(d) asm volatile("v_and_b32 %0, 0x1fffffff, %0" : "+v"(d));
+            AN(d0) AN(d1) AN(d2) AN(d3) AN(d4) AN(d5) AN(d6) AN(d7)
+        } else if (MODE == 13) { // ONE dependent mad_u64_u32 chain (latency probe)
+            M(c0) M(c0) M(c0) M(c0) M(c0) M(c0) M(c0) M(c0)
+        } else if (MODE == 14) { // mad with an SGPR multiplicand
+#define MS(c) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(c) : "v"(a), "s"(b0) : "vcc");
+            MS(c0) MS(c1) MS(c2) MS(c3) MS(c4) MS(c5) MS(c6) MS(c7)
+        } else if (MODE == 15) { // v_sub_u32
+#define SB(d) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(d) : "v"(a));
+            SB(d0) SB(d1) SB(d2) SB(d3) SB(d4) SB(d5) SB(d6) SB(d7)
+        } else if (MODE == 16) { // v_mul_u32_u24
+#define MU(d) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(d) : "v"(a));
+            MU(d0) MU(d1) MU(d2) MU(d3) MU(d4) MU(d5) MU(d6) MU(d7)
+        } else if (MODE == 17) { // v_bfe_u32
+#define BF(d) asm volatile("v_bfe_u32 %0, %0, 3, 29" : "+v"(d));
+            BF(d0) BF(d1) BF(d2) BF(d3) BF(d4) BF(d5) BF(d6) BF(d7)
         }
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7 + d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7;
@@ -59,6 +88,9 @@ int main() {
     for (int w : {1, 2, 4}) {
         run<0>("v_mad_u64_u32", w); run<1>("v_mul_lo_u32", w); run<2>("v_mul_hi_u32", w); run<3>("v_add_u32", w);
         run<4>("v_lshl_add_u64", w); run<5>("v_mad_u32_u24", w); run<6>("v_addc_co_u32", w); run<7>("v_mov_b32", w);
+        run<8>("v_mad_i64_i32", w); run<9>("v_alignbit_b32", w); run<10>("v_ashrrev_i32", w); run<11>("v_lshrrev_b64", w);
+        run<12>("v_and_b32 lit", w); run<13>("mad_u64 dep chain", w); run<14>("mad_u64 sgpr", w); run<15>("v_sub_u32", w);
+        run<16>("v_mul_u32_u24", w); run<17>("v_bfe_u32", w);
     }
     return 0;
 }

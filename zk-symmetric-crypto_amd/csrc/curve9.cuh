@@ -1,0 +1,125 @@
+// XYZZ accumulators over the 9 x 29-bit field (field9.cuh): the mixed / general additions of the bucket accumulation and reduction.
+// Same formulas, special cases and results (mod M) as XYZZ<F> in curve.cuh -- madd-2008-s / add-2008-s / dbl-2008-s-1, replacing
+// gnark-crypto v0.19.2 g1JacExtended.addMixed / add / double --, coordinates in the 2^261-Montgomery form.
+// Per mixed addition: 8 products + ONE fused pair (Y3 = R*(Q - X3) - Y1*PPP shares a reduction) = 1 539 multiply-adds, three
+// carry-free subtractions and one carry propagation (X3, which becomes state); the 8 x 32 form needs 1 280 multiply-adds + 1 280
+// carry instructions + seven ~28-instruction modular additions.
+#pragma once
+#include "curve.cuh"
+#include "field9.cuh"
+
+namespace zk {
+
+template <class F9>
+struct alignas(16) XYZZ9 {         // 144 bytes: bucket sums travel between the accumulation and the reduction as the raw strict limbs
+    using W = typename F9::Words;
+    F9 X, Y, ZZ, ZZZ;      // strict between operations; infinity = ZZ exactly zero (a finite point never has ZZ = 0 mod M ... see is_inf)
+
+    // a finite accumulator's ZZ is a product of non-zero values mod M, but its strict integer may be M itself; only the all-zero
+    // limbs written by inf() mean infinity
+    ZK_HD bool is_inf() const { return ZZ.is_zero_exact(); }
+    static ZK_HD XYZZ9 inf() { return XYZZ9{F9::zero(), F9::zero(), F9::zero(), F9::zero()}; }
+
+    // 2 * (x, y), affine, strict inputs (mdbl-2008-s-1).  Rare path: every lazy intermediate is normalised before it is multiplied.
+    static __host__ __device__ __noinline__ XYZZ9 dbl_affine(F9 x, F9 y) {
+        const F9 U = F9::norm(F9::add(y, y)), V = F9::mul(U, U), Wv = F9::mul(U, V), S = F9::mul(x, V);
+        const F9 t = F9::mul(x, x);
+        const F9 Mm = F9::norm(F9::add(F9::add(t, t), t));
+        XYZZ9 r;
+        r.X = F9::norm(F9::sub(F9::sub(F9::mul(Mm, Mm), S), S));
+        r.Y = F9::mulsub(Mm, F9::norm(F9::sub(S, r.X)), Wv, y);
+        r.ZZ = V;
+        r.ZZZ = Wv;
+        return r;
+    }
+    // The out-of-line helpers of the rare paths take and return VALUES: a member function called through `this` would pin the
+    // caller's accumulator in scratch memory for the whole walk.
+    // 2 * p (dbl-2008-s-1), rare path
+    static __host__ __device__ __noinline__ XYZZ9 dbl_of(XYZZ9 p) {
+        if (p.is_inf()) return p;
+        const F9 U = F9::norm(F9::add(p.Y, p.Y)), V = F9::mul(U, U), Wv = F9::mul(U, V), S = F9::mul(p.X, V);
+        const F9 t = F9::mul(p.X, p.X);
+        const F9 Mm = F9::norm(F9::add(F9::add(t, t), t));
+        XYZZ9 r;
+        r.X = F9::norm(F9::sub(F9::sub(F9::mul(Mm, Mm), S), S));
+        r.Y = F9::mulsub(Mm, F9::norm(F9::sub(S, r.X)), Wv, p.Y);
+        r.ZZ = F9::mul(V, p.ZZ);
+        r.ZZZ = F9::mul(Wv, p.ZZZ);
+        return r;
+    }
+    ZK_HD XYZZ9 dbl() const { return dbl_of(*this); }
+    // P == 0 mod M in a mixed addition: doubling (R == 0) or cancellation
+    static __host__ __device__ __noinline__ XYZZ9 madd_special(F9 x2, F9 y2, F9 R) {
+        if (F9::mul(R, R).is_zero_mod()) return dbl_affine(x2, y2);
+        return inf();
+    }
+    // this += (x2, y2): affine point that is NOT infinity, coordinates strict, or y2 the limb-wise negation of a strict value
+    // (a negated base point).  Limb bounds: Pv, R = strict - strict (1-lazy; R up to 2-lazy with a negated y2... no: y2 only enters
+    // the product y2 * ZZZ, whose result is strict), X3 before norm() is 4-lazy and normalised because it becomes state and an
+    // operand; T = Q - X3 is 1-lazy; the fused Y3 takes (1-lazy x 1-lazy) + (strict x strict).
+    ZK_HD void madd(const F9 &x2, const F9 &y2) {
+        if (is_inf()) {
+            X = x2; Y = F9::norm(y2); ZZ = F9::one(); ZZZ = F9::one();
+            return;
+        }
+        const F9 U2 = F9::mul(x2, ZZ), S2 = F9::mul(y2, ZZZ);
+        const F9 Pv = F9::sub(U2, X), R = F9::sub(S2, Y);
+        const F9 PP = F9::mul(Pv, Pv);
+        if (PP.is_zero_mod()) {          // M is prime: P^2 == 0 <=> P == 0
+            *this = madd_special(x2, F9::norm(y2), R);
+            return;
+        }
+        const F9 PPP = F9::mul(Pv, PP), Q = F9::mul(X, PP), RR = F9::mul(R, R);
+        F9 X3;
+#pragma unroll
+        for (int i = 0; i < 9; i++) X3.l[i] = RR.l[i] - PPP.l[i] - 2 * Q.l[i];
+        X3 = F9::norm(X3);
+        Y = F9::mulsub(R, F9::sub(Q, X3), Y, PPP);
+        X = X3;
+        ZZ = F9::mul(ZZ, PP);
+        ZZZ = F9::mul(ZZZ, PPP);
+    }
+    // this += q (add-2008-s); both in the 2^261 form, strict
+    ZK_HD void add(const XYZZ9 &q) {
+        if (q.is_inf()) return;
+        if (is_inf()) { *this = q; return; }
+        const F9 U1 = F9::mul(X, q.ZZ), U2 = F9::mul(q.X, ZZ), S1 = F9::mul(Y, q.ZZZ), S2 = F9::mul(q.Y, ZZZ);
+        const F9 Pv = F9::sub(U2, U1), R = F9::sub(S2, S1);
+        const F9 PP = F9::mul(Pv, Pv);
+        if (PP.is_zero_mod()) {
+            const XYZZ9 self = *this;
+            if (F9::mul(R, R).is_zero_mod()) *this = dbl_of(self);
+            else *this = inf();
+            return;
+        }
+        const F9 PPP = F9::mul(Pv, PP), Q = F9::mul(U1, PP), RR = F9::mul(R, R);
+        F9 X3;
+#pragma unroll
+        for (int i = 0; i < 9; i++) X3.l[i] = RR.l[i] - PPP.l[i] - 2 * Q.l[i];
+        X3 = F9::norm(X3);
+        Y = F9::mulsub(R, F9::sub(Q, X3), S1, PPP);
+        X = X3;
+        ZZ = F9::mul(F9::mul(ZZ, q.ZZ), PP);
+        ZZZ = F9::mul(F9::mul(ZZZ, q.ZZZ), PPP);
+    }
+    // canonical 2^256-Montgomery words (what the rest of the pipeline reads); infinity -> all zero
+    static __host__ __device__ __noinline__ XYZZ<W> to_xyzz_of(XYZZ9 p) {
+        if (p.is_inf()) return XYZZ<W>::inf();
+        return XYZZ<W>{F9::to_field(p.X), F9::to_field(p.Y), F9::to_field(p.ZZ), F9::to_field(p.ZZZ)};
+    }
+    ZK_HD XYZZ<W> to_xyzz() const { return to_xyzz_of(*this); }
+    // canonical words of the 2^261 form (bucket sums that the 9-limb reduction reads back)
+    ZK_HD XYZZ<W> to_words() const {
+        if (is_inf()) return XYZZ<W>::inf();
+        XYZZ<W> r{F9::to_words(X), F9::to_words(Y), F9::to_words(ZZ), F9::to_words(ZZZ)};
+        // a finite point whose ZZ is M as an integer would read back as infinity: ZZ != 0 mod M for finite points, so to_words
+        // (which reduces into [0, M)) can only give 0 for v == 0 or v == M ... both impossible for a finite ZZ
+        return r;
+    }
+    static ZK_HD XYZZ9 from_words(const XYZZ<W> &p) {
+        return XYZZ9{F9::from_words(p.X), F9::from_words(p.Y), F9::from_words(p.ZZ), F9::from_words(p.ZZZ)};
+    }
+};
+using G1X9 = XYZZ9<Fp9>;
+
+}  // namespace zk

@@ -123,7 +123,27 @@ def gen_subfix(mod):
     return L
 
 
+def limbs9(v):
+    return [(v >> (29 * i)) & ((1 << 29) - 1) for i in range(9)]
+
+
+def gen_field9():
+    """field9_consts.inc: constants of the 9 x 29-bit signed-limb representation (field9.cuh), Montgomery radix 2^261"""
+    out = ["// GENERATED by gen_mul_asm.py -- do not edit.  Constants of field9.cuh (9 x 29-bit limbs, Montgomery radix 2^261)."]
+    fmt = lambda v: "{ " + ", ".join("0x%08x" % x for x in limbs9(v)) + " }"
+    for name, mod in (("FP", P), ("FR", R)):
+        out.append("#define ZK_F9_%s_M %s" % (name, fmt(mod)))
+        out.append("#define ZK_F9_%s_PINV 0x%08xu                  /* -M^-1 mod 2^29 */" % (name, (-pow(mod, -1, 1 << 29)) % (1 << 29)))
+        out.append("#define ZK_F9_%s_CIN %s    /* 2^266 mod M: 2^256-Montgomery words -> 2^261-Montgomery limbs */" % (name, fmt(pow(2, 266, mod))))
+        out.append("#define ZK_F9_%s_COUT %s   /* 2^256 mod M: and back */" % (name, fmt(pow(2, 256, mod))))
+        out.append("#define ZK_F9_%s_ONE %s    /* 2^261 mod M */" % (name, fmt(pow(2, 261, mod))))
+        out.append("#define ZK_F9_%s_SCALE32 { %s }   /* 32 in 2^256-Montgomery words: x -> 2^5 x moves a stored value to the 2^261 form */"
+                   % (name, ", ".join("0x%08xu" % x for x in limbs((32 << 256) % mod))))
+    open("field9_consts.inc", "w").write("\n".join(out) + "\n")
+
+
 def main():
+    gen_field9()
     out = ["// GENERATED by gen_mul_asm.py -- do not edit.",
            "// ZK_MUL_ASM_*: clobbers v16-v27, s16-s24, vcc; the product leaves the block fully reduced",
            "// ZK_ADD_ASM_* + ZK_RED_ASM_* = modular addition, ZK_SUB_ASM_* + ZK_SUBFIX_ASM_* = modular subtraction (two statements each:",

@@ -35,6 +35,7 @@ struct MsmBases {
     DevBuf<Affine<F>> table;
     DevBuf<Affine<F>> tern;        // conditional-sum path: signed subset sums of every group of 6 bases (msm.hip, TERN_*)
     DevBuf<uint32_t> scalar_row;   // row index of the scalar of point j in the [row][B] scalar matrix
+    bool f9 = false;               // G1: table coordinates are in the 2^261-Montgomery form of field9.cuh (accumulated by k_msm_accumulate9)
     bool dense = false;            // quotient MSM: all scalars wide, read from an instance-major copy [B][dense_stride]
     size_t dense_stride = 0;
 };

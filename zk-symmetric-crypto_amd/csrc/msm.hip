@@ -24,6 +24,7 @@
 #include <algorithm>
 #include "kernels.h"
 #include "msm_tree.cuh"
+#include "curve9.cuh"
 
 namespace zk {
 
@@ -46,6 +47,14 @@ static constexpr int ONES_GROUPS = 20;                     // groups per conditi
 static constexpr int ONES_CHUNK = TERN_G * ONES_GROUPS;    // base points per conditional-sum thread
 static constexpr int SORT_THREADS = 1024;
 
+static bool tree_enabled();
+// G1 bucket accumulation on the 9 x 29-bit field (field9.cuh): on unless ZKPROVE_MSM_F9=0 (A/B runs) or the affine-tree experiment,
+// which reads the table in the 2^256 form, is selected
+static bool f9_enabled() {
+    static const bool on = [] { const char *e = getenv("ZKPROVE_MSM_F9"); return !(e && e[0] == '0'); }();
+    return on && !tree_enabled();
+}
+
 // ------------------------------------------------------------------------------ table precompute
 template <class F>
 __global__ __launch_bounds__(256) void k_window_multiples(const Affine<F> *__restrict__ pts, size_t n, int c, int W, XYZZ<F> *__restrict__ out) {
@@ -63,6 +72,16 @@ __global__ __launch_bounds__(256) void k_xyzz_to_affine(const XYZZ<F> *__restric
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     out[i] = in[i].to_affine();
+}
+
+// table *= 2^5 per coordinate: 2^256-Montgomery words -> 2^261-Montgomery words (infinity (0, 0) stays)
+__global__ __launch_bounds__(256) void k_table_to_f9(Fp *__restrict__ coords, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fp k;
+#pragma unroll
+    for (int j = 0; j < 8; j++) k.l[j] = Fp9Params::SCALE32[j];
+    coords[i] = coords[i] * k;
 }
 
 // tern[g * TERN_ENTRIES + e] = sum_i t_i * P_{6g+i} for the pattern e + TERN_CENTER + 1
@@ -103,6 +122,10 @@ static void bases_build(MsmBases<F> &mb, const Affine<F> *d_points, size_t n, co
         size_t m = n - off < CH ? n - off : CH;
         hipLaunchKernelGGL(k_window_multiples<F>, dim3(ceil_div(m, 256)), dim3(256), 0, s, d_points + off, m, c, mb.W, tmp.p);
         hipLaunchKernelGGL(k_xyzz_to_affine<F>, dim3(ceil_div(m * mb.W, 256)), dim3(256), 0, s, tmp.p, mb.table.p + off * mb.W, m * mb.W);
+    }
+    if constexpr (sizeof(F) == 32) {
+        mb.f9 = f9_enabled();
+        if (mb.f9) hipLaunchKernelGGL(k_table_to_f9, dim3(ceil_div(tot * 2, 256)), dim3(256), 0, s, (Fp *)mb.table.p, tot * 2);
     }
     ZK_HIP(hipGetLastError());
     ZK_HIP(hipStreamSynchronize(s));
@@ -159,7 +182,7 @@ void MsmScratch::reserve_compact(size_t B_, size_t max_sparse_n) {
     gen_val.ensure(B_ * max_sparse_n + 1);
 }
 void MsmScratch::reserve_sums(size_t B_, size_t nb_g1, size_t nb_g2) {
-    sums1.ensure((B_ > VIRT_MIN ? B_ : VIRT_MIN) * nb_g1 + 1);
+    sums1.ensure(((B_ > VIRT_MIN ? B_ : VIRT_MIN) * nb_g1 + 1) * sizeof(G1X9) / sizeof(G1XYZZ) + 1);      // G1 bucket records are G1X9 (144 bytes) on the 9-limb path
     sums2.ensure(B_ * nb_g2 + 1);
 }
 void MsmScratch::reserve(size_t B_, size_t max_entries, size_t max_nb, size_t max_part) {
@@ -452,17 +475,36 @@ __global__ __launch_bounds__(256) void k_msm_binsort(const uint32_t *__restrict_
 // the reduce kernel reads emptiness from bucket_start).
 // DENSE only names the instantiation (quotient MSM vs. wire MSMs) so that profiler summaries keep the dominant launch apart.
 // both groups accumulate in weak form (madd_w); G1 with the multiplier expanded in place, G2 through the shared out-of-line copy
+// Accumulator policies of the walk below.  AccWords: XYZZ<F> in weak form on the 8 x 32 field (G2; G1 when the 9-limb path is off).
+// Acc9: G1 on the 9 x 29-bit field (field9.cuh / curve9.cuh) -- the table then holds the 2^261-Montgomery form (bases_build), the
+// bucket sums are G1X9 records read by k_msm_bucket_reduce9, which hands the canonical 2^256 form to the rest of the pipeline.
 template <class F>
-__device__ __forceinline__ void acc_madd(XYZZ<F> &acc, const Affine<F> &p) {
-    if constexpr (sizeof(F) == 32) acc.template madd_w<true>(p);
-    else acc.template madd_w<false>(p);
-}
-template <class F>
-__device__ __forceinline__ XYZZ<F> acc_store(const XYZZ<F> &acc) { return acc.canon(); }
-template <class F, bool DENSE>
+struct AccWords {
+    using Out = XYZZ<F>;
+    XYZZ<F> a;
+    __device__ __forceinline__ void reset() { a = XYZZ<F>::inf(); }
+    __device__ __forceinline__ void add(Affine<F> p, bool negate) {
+        if (negate) p.y = p.y.neg();
+        if constexpr (sizeof(F) == 32) a.template madd_w<true>(p);     // multiplier expanded in place
+        else a.template madd_w<false>(p);                              // G2: shared out-of-line weak multiplier
+    }
+    __device__ __forceinline__ XYZZ<F> result() const { return a.canon(); }
+};
+struct Acc9 {
+    using Out = G1X9;              // raw strict limbs (144 bytes): leaving a bucket costs no arithmetic -- a wavefront leaves some bucket in
+                                   // almost every iteration, so whatever a store costs is paid by all 64 lanes nearly every time
+    G1X9 a;
+    __device__ __forceinline__ void reset() { a = G1X9::inf(); }
+    __device__ __forceinline__ void add(const Affine<Fp> &p, bool negate) {
+        if (p.is_inf()) return;
+        a.madd(Fp9::from_words(p.x), Fp9::cneg(Fp9::from_words(p.y), negate ? -1 : 0));
+    }
+    __device__ __forceinline__ G1X9 result() const { return a; }
+};
+template <class F, bool DENSE, class ACC>
 __device__ __forceinline__ void accumulate_body(const Affine<F> *__restrict__ table, const uint32_t *__restrict__ bucket_start,
                                                 const uint32_t *__restrict__ entries, size_t max_entries, int c, size_t B,
-                                                uint32_t nlanes, XYZZ<F> *__restrict__ sums) {
+                                                uint32_t nlanes, typename ACC::Out *__restrict__ sums) {
     const uint32_t nb = 1u << (c - 1);
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (size_t)nlanes * B) return;
@@ -470,7 +512,7 @@ __device__ __forceinline__ void accumulate_body(const Affine<F> *__restrict__ ta
     const uint32_t lane = (uint32_t)(t % nlanes);
     const uint32_t *bs = bucket_start + b * (nb + 1);
     const uint32_t *ent = entries + b * max_entries;
-    XYZZ<F> *out = sums + b * nb;
+    typename ACC::Out *out = sums + b * nb;
     const uint32_t total = bs[nb];
     // first bucket k with bs[k] >= target
     auto first_bucket = [&](uint32_t target) -> uint32_t {
@@ -490,12 +532,13 @@ __device__ __forceinline__ void accumulate_body(const Affine<F> *__restrict__ ta
     // bucket boundaries are prefetched one ahead: leaving a bucket then costs no dependent memory round trip
     uint32_t cur = k0, cur_start = e, next_b = bs[k0 + 1];
     uint32_t next_b2 = bs[(k0 + 2 <= nb) ? k0 + 2 : nb];
-    XYZZ<F> acc = XYZZ<F>::inf();
+    ACC acc;
+    acc.reset();
     uint32_t v = ent[e];
     Affine<F> p = table[v & 0x7fffffffu];
     while (true) {
         while (e >= next_b) {              // leave bucket `cur` (also skips empty buckets)
-            if (next_b > cur_start) { out[cur] = acc_store(acc); acc = XYZZ<F>::inf(); }   // every non-empty bucket is written, even if its sum is infinity
+            if (next_b > cur_start) { out[cur] = acc.result(); acc.reset(); }   // every non-empty bucket is written, even if its sum is infinity
             cur++;
             cur_start = next_b;
             next_b = next_b2;
@@ -505,12 +548,11 @@ __device__ __forceinline__ void accumulate_body(const Affine<F> *__restrict__ ta
         const uint32_t e_next = e + 1;
         uint32_t v_next = 0;
         if (e_next < e_end) v_next = ent[e_next];
-        if (v >> 31) p.y = p.y.neg();
-        acc_madd(acc, p);
+        acc.add(p, (v >> 31) != 0);
         if (e_next >= e_end) break;
         e = e_next; v = v_next; p = table[v & 0x7fffffffu];
     }
-    out[cur] = acc;
+    out[cur] = acc.result();
 }
 // Fp2 kernels: 2 wavefronts per SIMD (the unconstrained allocation takes 256 VGPRs plus a few AGPRs = 1 wavefront per SIMD, with
 // nothing to hide a 128-byte gather behind)
@@ -519,7 +561,7 @@ template <class F, bool DENSE>
 __global__ __launch_bounds__(64, ZK_FP2_WAVES(F)) void k_msm_accumulate(const Affine<F> *__restrict__ table, const uint32_t *__restrict__ bucket_start,
                                                        const uint32_t *__restrict__ entries, size_t max_entries, int c, size_t B,
                                                        uint32_t nlanes, XYZZ<F> *__restrict__ sums) {
-    accumulate_body<F, DENSE>(table, bucket_start, entries, max_entries, c, B, nlanes, sums);
+    accumulate_body<F, DENSE, AccWords<F>>(table, bucket_start, entries, max_entries, c, B, nlanes, sums);
 }
 // G1: 3 wavefronts per SIMD (168 VGPRs, 64 B of scratch) hide the multiplier's dependent chains better than 2 at 190 VGPRs
 // (measured 111 vs 115 ms for the quotient MSM; 4 wavefronts at 128 VGPRs spill too much: 120 ms).  G2 needs all 256.
@@ -531,11 +573,21 @@ __global__ __launch_bounds__(64, ZK_FP2_WAVES(F)) void k_msm_accumulate(const Af
     __global__ __launch_bounds__(64, ZK_ACC_WAVES) void k_msm_accumulate<Fp, DENSE>(const Affine<Fp> *__restrict__ table, const uint32_t *__restrict__ bucket_start, \
                                                                          const uint32_t *__restrict__ entries, size_t max_entries, int c, size_t B,       \
                                                                          uint32_t nlanes, XYZZ<Fp> *__restrict__ sums) {                                  \
-        accumulate_body<Fp, DENSE>(table, bucket_start, entries, max_entries, c, B, nlanes, sums);                                       \
+        accumulate_body<Fp, DENSE, AccWords<Fp>>(table, bucket_start, entries, max_entries, c, B, nlanes, sums);                         \
     }
 ZK_ACC_G1(true)
 ZK_ACC_G1(false)
 #undef ZK_ACC_G1
+// G1 on the 9-limb field (the default; ZKPROVE_MSM_F9=0 keeps the 8 x 32 walk above for comparison)
+#ifndef ZK_ACC9_WAVES
+#define ZK_ACC9_WAVES 4
+#endif
+template <bool DENSE>
+__global__ __launch_bounds__(64, ZK_ACC9_WAVES) void k_msm_accumulate9(const Affine<Fp> *__restrict__ table, const uint32_t *__restrict__ bucket_start,
+                                                                        const uint32_t *__restrict__ entries, size_t max_entries, int c, size_t B,
+                                                                        uint32_t nlanes, G1X9 *__restrict__ sums) {
+    accumulate_body<Fp, DENSE, Acc9>(table, bucket_start, entries, max_entries, c, B, nlanes, sums);
+}
 
 // thread (b, seg): running-sum reduction of buckets [seg*L, seg*L + L) of instance b
 template <class F>
@@ -562,6 +614,40 @@ __global__ __launch_bounds__(64) void k_msm_bucket_reduce(const XYZZ<F> *__restr
     // contribution = tot + s0 * run   (bucket index i carries weight i+1)
     if (s0 != 0 && !run.is_inf()) {
         XYZZ<F> m = XYZZ<F>::inf();
+        for (int bit = 31 - __clz(s0); bit >= 0; bit--) {
+            m = m.dbl();
+            if ((s0 >> bit) & 1) m.add(run);
+        }
+        tot.add(m);
+    }
+    part[b * part_stride + part_off + seg] = tot;
+}
+
+// the same running-sum reduction over the G1X9 bucket records of k_msm_accumulate9; the segment total leaves in the canonical
+// 2^256 form, the rare s0 * run correction is done there as above
+__global__ __launch_bounds__(64) void k_msm_bucket_reduce9(const G1X9 *__restrict__ sums, const uint32_t *__restrict__ bucket_start, int c, size_t B,
+                                                           G1XYZZ *__restrict__ part, size_t part_stride, size_t part_off, uint32_t L) {
+    const uint32_t nb = 1u << (c - 1);
+    const uint32_t nseg = nb / L;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)nseg * B) return;
+    const size_t b = t / nseg;
+    const uint32_t seg = (uint32_t)(t % nseg);
+    const uint32_t *bs = bucket_start + b * (nb + 1);
+    const G1X9 *in = sums + b * nb;
+    G1X9 run9 = G1X9::inf(), tot9 = G1X9::inf();
+    const uint32_t s0 = seg * L;
+    uint32_t hi = bs[s0 + L];
+    for (int k = (int)L - 1; k >= 0; k--) {
+        const uint32_t lo = bs[s0 + k];
+        if (hi > lo) run9.add(in[s0 + k]);
+        tot9.add(run9);
+        hi = lo;
+    }
+    const G1XYZZ run = run9.to_xyzz();
+    G1XYZZ tot = tot9.to_xyzz();
+    if (s0 != 0 && !run.is_inf()) {
+        G1XYZZ m = G1XYZZ::inf();
         for (int bit = 31 - __clz(s0); bit >= 0; bit--) {
             m = m.dbl();
             if ((s0 >> bit) & 1) m.add(run);
@@ -721,6 +807,32 @@ static void launch_tree_g1(const MsmBasesG1 &mb, MsmScratch &sc, const uint32_t 
                        bs_p, c, Bv, part, stride, part_off, L);
 }
 
+// accumulation + bucket reduction of one sorted MSM: buckets -> nseg segment totals in part[part_off ..]
+template <class F, bool DENSE>
+static void launch_accumulate_reduce(const MsmBases<F> &mb, const uint32_t *bs_p, const uint32_t *ent_p, size_t max_entries, int c, size_t B, uint32_t nlanes,
+                                     XYZZ<F> *sums, size_t sums_cap, XYZZ<F> *part, size_t stride, size_t part_off, uint32_t L, hipStream_t s,
+                                     hipEvent_t *seg_events) {
+    const uint32_t nb = 1u << (c - 1);
+    const size_t nseg = nb / L;
+    const dim3 grid(ceil_div((size_t)nlanes * B, 64)), rgrid(ceil_div(nseg * B, 64));
+    if constexpr (sizeof(F) == 32) {
+        if (mb.f9) {
+            if (sums_cap * sizeof(XYZZ<F>) < B * (size_t)nb * sizeof(G1X9)) throw ZkError("msm bucket-sum scratch too small");
+            G1X9 *sums9 = reinterpret_cast<G1X9 *>(sums);
+            if (seg_events) ZK_HIP(hipEventRecord(seg_events[0], s));
+            hipLaunchKernelGGL((k_msm_accumulate9<DENSE>), grid, dim3(64), 0, s, mb.table.p, bs_p, ent_p, max_entries, c, B, nlanes, sums9);
+            if (seg_events) ZK_HIP(hipEventRecord(seg_events[1], s));
+            hipLaunchKernelGGL(k_msm_bucket_reduce9, rgrid, dim3(64), 0, s, sums9, bs_p, c, B, part, stride, part_off, L);
+            return;
+        }
+    }
+    if (sums_cap < B * (size_t)nb) throw ZkError("msm bucket-sum scratch too small");
+    if (seg_events) ZK_HIP(hipEventRecord(seg_events[0], s));
+    hipLaunchKernelGGL((k_msm_accumulate<F, DENSE>), grid, dim3(64), 0, s, mb.table.p, bs_p, ent_p, max_entries, c, B, nlanes, sums);
+    if (seg_events) ZK_HIP(hipEventRecord(seg_events[1], s));
+    hipLaunchKernelGGL(k_msm_bucket_reduce<F>, rgrid, dim3(64), 0, s, sums, bs_p, c, B, part, stride, part_off, L);
+}
+
 template <class F>
 struct PartSel;
 template <>
@@ -766,11 +878,8 @@ static void msm_dense_split(const MsmBases<F> &mb, const Fr *scalars, size_t B, 
         if (tree_enabled() && sc.treeA1.n) {
             launch_tree_g1(mb, sc, sc.bucket_start.p, sc.entries.p, max_entries, c, Bv, nlanes, part, stride, (size_t)0, L, s, seg_events);
         } else {
-            if (seg_events) ZK_HIP(hipEventRecord(seg_events[0], s));
-            hipLaunchKernelGGL((k_msm_accumulate<F, true>), dim3(ceil_div((size_t)nlanes * Bv, 64)), dim3(64), 0, s, mb.table.p, sc.bucket_start.p, sc.entries.p,
-                               max_entries, c, Bv, nlanes, sums);
-            if (seg_events) ZK_HIP(hipEventRecord(seg_events[1], s));
-            hipLaunchKernelGGL(k_msm_bucket_reduce<F>, dim3(ceil_div(nseg * Bv, 64)), dim3(64), 0, s, sums, sc.bucket_start.p, c, Bv, part, stride, (size_t)0, L);
+            launch_accumulate_reduce<F, true>(mb, sc.bucket_start.p, sc.entries.p, max_entries, c, Bv, nlanes, sums, SumsSel<F>::cap(sc), part, stride, (size_t)0, L, s,
+                                              seg_events);
         }
         size_t off = 0, cnt = npart;
         do {
@@ -905,16 +1014,9 @@ static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, M
         }
     }
     XYZZ<F> *sums = SumsSel<F>::get(sc);
-    if (SumsSel<F>::cap(sc) < B * (size_t)nb) throw ZkError("msm bucket-sum scratch too small");
-    if (seg_events) ZK_HIP(hipEventRecord(seg_events[0], s));
-    if (mb.dense)
-        hipLaunchKernelGGL((k_msm_accumulate<F, true>), dim3(ceil_div((size_t)nlanes * B, 64)), dim3(64), 0, s, mb.table.p, bs_p, ent_p,
-                           max_entries, c, B, nlanes, sums);
-    else
-        hipLaunchKernelGGL((k_msm_accumulate<F, false>), dim3(ceil_div((size_t)nlanes * B, 64)), dim3(64), 0, s, mb.table.p, sc.bucket_start.p, sc.entries.p,
-                           max_entries, c, B, nlanes, sums);
-    if (seg_events) ZK_HIP(hipEventRecord(seg_events[1], s));
-    hipLaunchKernelGGL(k_msm_bucket_reduce<F>, dim3(ceil_div(nseg * B, 64)), dim3(64), 0, s, sums, bs_p, c, B, part, stride, nchunks, L);
+    if (mb.dense) launch_accumulate_reduce<F, true>(mb, bs_p, ent_p, max_entries, c, B, nlanes, sums, SumsSel<F>::cap(sc), part, stride, nchunks, L, s, seg_events);
+    else launch_accumulate_reduce<F, false>(mb, sc.bucket_start.p, sc.entries.p, max_entries, c, B, nlanes, sums, SumsSel<F>::cap(sc), part, stride, nchunks, L, s,
+                                            seg_events);
     msm_fold_parts<F>(part, stride, npart, out, B, s);
 }
 void msm_batch(const MsmBasesG1 &mb, const Fr *sc, size_t B, MsmScratch &scr, G1XYZZ *out, hipStream_t s, hipEvent_t *ev) { msm_batch_impl<Fp>(mb, sc, B, scr, out, s, ev); }
