@@ -1,0 +1,91 @@
+// Host-side check of the 9 x 29-bit field and its XYZZ arithmetic (csrc/field9.cuh, csrc/curve9.cuh) against the 8 x 32 field
+// (csrc/field.cuh, itself pinned to the oracle by the GPU parity tests): the host build of both headers runs the same C++ with
+// plain int64 arithmetic in place of v_mad_i64_i32.  Prints "ok" or the first mismatches; tests/test_field9_host.py runs it.
+#include "curve9.cuh"
+#include <stdio.h>
+#include <random>
+#include <vector>
+using namespace zk;
+
+static Fp rnd(std::mt19937_64 &rng, int kind) {
+    Fp r;
+    for (int i = 0; i < 8; i++) r.l[i] = (uint32_t)rng();
+    if (kind == 1) for (int i = 0; i < 8; i++) r.l[i] = 0xffffffffu;
+    if (kind == 2) for (int i = 0; i < 8; i++) r.l[i] = 0;
+    if (kind == 3) { for (int i = 0; i < 8; i++) r.l[i] = FpParams::M[i]; r.l[0] -= 1; }
+    if (kind == 4) { for (int i = 1; i < 8; i++) r.l[i] = 0; r.l[0] = 1; }
+    r.l[7] &= 0x3fffffffu;
+    while (Fp::geq_mod(r.l)) Fp::reduce_once(r.l);
+    return r;
+}
+int main() {
+    std::mt19937_64 rng(7);
+    int bad = 0;
+    // field: products, squares, fused pairs with lazy operands, conversions
+    for (int it = 0; it < 20000; it++) {
+        const Fp a = rnd(rng, it % 7), b = rnd(rng, (it / 7) % 7), c = rnd(rng, 0), d = rnd(rng, (it / 49) % 7);
+        const Fp9 A = Fp9::from_field(a), B = Fp9::from_field(b), C = Fp9::from_field(c), D = Fp9::from_field(d);
+        const Fp9 u = Fp9::sub(A, C), v = Fp9::sub(B, D);       // 1-lazy, possibly negative
+        bool ok = Fp9::to_field(A) == a;
+        ok &= Fp9::to_field(Fp9::mul(u, v)) == (a - c) * (b - d);
+        ok &= Fp9::to_field(Fp9::sqr(u)) == (a - c) * (a - c);
+        ok &= Fp9::to_field(Fp9::mulsub(u, B, C, v)) == (a - c) * b - c * (b - d);
+        ok &= Fp9::to_field(Fp9::muladd(u, v, C, D)) == (a - c) * (b - d) + c * d;
+        Fp9 r0, r1, r2;
+        Fp9::mul3(r0, A, B, r1, u, D, r2, C, v);
+        ok &= Fp9::to_field(r0) == a * b && Fp9::to_field(r1) == (a - c) * d && Fp9::to_field(r2) == c * (b - d);
+        Fp9::sqr2(r0, v, r1, A);
+        ok &= Fp9::to_field(r0) == (b - d) * (b - d) && Fp9::to_field(r1) == a * a;
+        Fp9::mulsub_mul(r0, A, v, u, D, r1, C, C);
+        ok &= Fp9::to_field(r0) == a * (b - d) - (a - c) * d && Fp9::to_field(r1) == c * c;
+        // to_words over its whole input range (-4M, 4M): sums / differences of up to 3 strict values
+        const Fp9 w3 = Fp9::norm(Fp9::add(Fp9::add(A, B), C)), wn = Fp9::norm(Fp9::sub(Fp9::sub(Fp9::neg(A), B), C));
+        ok &= Fp9::to_field(w3) == a + b + c && Fp9::to_field(wn) == (a + b + c).neg();
+        ok &= Fp9::mul(u, Fp9::zero()).is_zero_mod() && (a == c) == Fp9::sqr(u).is_zero_mod();
+        if (!ok && bad++ < 5) printf("field mismatch at iteration %d\n", it);
+    }
+    // curve: chains of mixed additions with negated points, repeated points (doubling), cancellations, then general additions
+    G1Affine g{Fp::one(), Fp::one() + Fp::one()};
+    std::vector<G1Affine> pts;
+    for (int i = 0; i < 48; i++) { uint32_t k[8] = {(uint32_t)rng(), (uint32_t)rng(), 0, 0, 0, 0, 0, 0}; pts.push_back(scalar_mul(g, k, 64).to_affine()); }
+    Fp k32;
+    for (int j = 0; j < 8; j++) k32.l[j] = Fp9Params::SCALE32[j];
+    auto chain = [&](int trial, int len, G1XYZZ &a, G1X9 &b) {
+        a = G1XYZZ::inf(); b = G1X9::inf();
+        for (int s = 0; s < len; s++) {
+            G1Affine p = pts[rng() % 48];
+            bool neg = rng() & 1;
+            if (trial % 5 == 3 && s == 2) p = pts[0];
+            if (trial % 5 == 3 && s == 3) { p = pts[0]; neg = (trial / 5) & 1; }        // twice the same point in a row: doubling or cancellation
+            G1Affine q = p;
+            if (neg) q.y = q.y.neg();
+            a.madd(q);
+            b.madd(Fp9::from_words(p.x * k32), Fp9::cneg(Fp9::from_words(p.y * k32), neg ? -1 : 0));
+        }
+    };
+    auto same = [](const G1XYZZ &a, const G1X9 &b) {
+        const G1XYZZ r = b.to_xyzz();
+        return r.X == a.X && r.Y == a.Y && r.ZZ == a.ZZ && r.ZZZ == a.ZZZ;
+    };
+    for (int trial = 0; trial < 300; trial++) {
+        G1XYZZ a1, a2; G1X9 b1, b2;
+        chain(trial, 1 + rng() % 24, a1, b1);
+        chain(trial + 1, trial % 11 == 0 ? 0 : 1 + rng() % 24, a2, b2);
+        bool ok = same(a1, b1) && same(a2, b2);
+        // record format of the bucket sums: raw limbs, and the canonical 2^261 words
+        ok &= same(a1, G1X9::from_words(b1.to_words()));
+        G1XYZZ s = a1; s.add(a2);
+        G1X9 t = b1; t.add(b2);
+        ok &= same(s, t);
+        G1XYZZ d = a1; d.add(a1);                  // P + P through the general addition
+        G1X9 e = b1; e.add(b1);
+        ok &= same(d, e);
+        G1XYZZ z = a1; z.add(a1.neg());            // P - P
+        G1X9 y = b1; G1X9 nb = b1; nb.Y = Fp9::norm(Fp9::neg(b1.Y)); y.add(nb);
+        ok &= z.is_inf() && y.is_inf();
+        ok &= same(a1.dbl(), b1.dbl());
+        if (!ok && bad++ < 10) printf("curve mismatch in trial %d\n", trial);
+    }
+    printf(bad ? "FAILED %d\n" : "ok\n", bad);
+    return bad != 0;
+}

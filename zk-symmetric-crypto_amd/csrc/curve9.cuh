@@ -1,9 +1,9 @@
 // XYZZ accumulators over the 9 x 29-bit field (field9.cuh): the mixed / general additions of the bucket accumulation and reduction.
 // Same formulas, special cases and results (mod M) as XYZZ<F> in curve.cuh -- madd-2008-s / add-2008-s / dbl-2008-s-1, replacing
 // gnark-crypto v0.19.2 g1JacExtended.addMixed / add / double --, coordinates in the 2^261-Montgomery form.
-// Per mixed addition: 8 products + ONE fused pair (Y3 = R*(Q - X3) - Y1*PPP shares a reduction) = 1 539 multiply-adds, three
-// carry-free subtractions and one carry propagation (X3, which becomes state); the 8 x 32 form needs 1 280 multiply-adds + 1 280
-// carry instructions + seven ~28-instruction modular additions.
+// Per mixed addition: 6 products, 2 squarings and ONE fused pair (Y3 = R*(Q - X3) - Y1*PPP shares a reduction) = 1 467 multiply-adds,
+// three carry-free subtractions and one carry propagation (X3, which becomes state); independent products run in lockstep.  The
+// 8 x 32 form needs 1 280 multiply-adds + 1 280 carry instructions + seven ~28-instruction modular additions.
 #pragma once
 #include "curve.cuh"
 #include "field9.cuh"
@@ -50,7 +50,7 @@ struct alignas(16) XYZZ9 {         // 144 bytes: bucket sums travel between the 
     ZK_HD XYZZ9 dbl() const { return dbl_of(*this); }
     // P == 0 mod M in a mixed addition: doubling (R == 0) or cancellation
     static __host__ __device__ __noinline__ XYZZ9 madd_special(F9 x2, F9 y2, F9 R) {
-        if (F9::mul(R, R).is_zero_mod()) return dbl_affine(x2, y2);
+        if (F9::sqr(R).is_zero_mod()) return dbl_affine(x2, y2);
         return inf();
     }
     // this += (x2, y2): affine point that is NOT infinity, coordinates strict, or y2 the limb-wise negation of a strict value
@@ -62,45 +62,46 @@ struct alignas(16) XYZZ9 {         // 144 bytes: bucket sums travel between the 
             X = x2; Y = F9::norm(y2); ZZ = F9::one(); ZZZ = F9::one();
             return;
         }
-        const F9 U2 = F9::mul(x2, ZZ), S2 = F9::mul(y2, ZZZ);
+        F9 U2, S2, PP, RR, PPP, Q, ZZ3;
+        F9::mul2(U2, x2, ZZ, S2, y2, ZZZ);
         const F9 Pv = F9::sub(U2, X), R = F9::sub(S2, Y);
-        const F9 PP = F9::mul(Pv, Pv);
+        F9::sqr2(PP, Pv, RR, R);
         if (PP.is_zero_mod()) {          // M is prime: P^2 == 0 <=> P == 0
             *this = madd_special(x2, F9::norm(y2), R);
             return;
         }
-        const F9 PPP = F9::mul(Pv, PP), Q = F9::mul(X, PP), RR = F9::mul(R, R);
+        F9::mul3(PPP, Pv, PP, Q, X, PP, ZZ3, ZZ, PP);
         F9 X3;
 #pragma unroll
         for (int i = 0; i < 9; i++) X3.l[i] = RR.l[i] - PPP.l[i] - 2 * Q.l[i];
         X3 = F9::norm(X3);
-        Y = F9::mulsub(R, F9::sub(Q, X3), Y, PPP);
+        F9::mulsub_mul(Y, R, F9::sub(Q, X3), Y, PPP, ZZZ, ZZZ, PPP);
         X = X3;
-        ZZ = F9::mul(ZZ, PP);
-        ZZZ = F9::mul(ZZZ, PPP);
+        ZZ = ZZ3;
     }
     // this += q (add-2008-s); both in the 2^261 form, strict
     ZK_HD void add(const XYZZ9 &q) {
         if (q.is_inf()) return;
         if (is_inf()) { *this = q; return; }
-        const F9 U1 = F9::mul(X, q.ZZ), U2 = F9::mul(q.X, ZZ), S1 = F9::mul(Y, q.ZZZ), S2 = F9::mul(q.Y, ZZZ);
+        F9 U1, U2, S1, S2, PP, RR, PPP, Q, Za, Zb;
+        F9::mul2(U1, X, q.ZZ, U2, q.X, ZZ);
+        F9::mul3(S1, Y, q.ZZZ, S2, q.Y, ZZZ, Za, ZZ, q.ZZ);
         const F9 Pv = F9::sub(U2, U1), R = F9::sub(S2, S1);
-        const F9 PP = F9::mul(Pv, Pv);
+        F9::sqr2(PP, Pv, RR, R);
         if (PP.is_zero_mod()) {
             const XYZZ9 self = *this;
-            if (F9::mul(R, R).is_zero_mod()) *this = dbl_of(self);
+            if (RR.is_zero_mod()) *this = dbl_of(self);
             else *this = inf();
             return;
         }
-        const F9 PPP = F9::mul(Pv, PP), Q = F9::mul(U1, PP), RR = F9::mul(R, R);
+        F9::mul3(PPP, Pv, PP, Q, U1, PP, Zb, ZZZ, q.ZZZ);
         F9 X3;
 #pragma unroll
         for (int i = 0; i < 9; i++) X3.l[i] = RR.l[i] - PPP.l[i] - 2 * Q.l[i];
         X3 = F9::norm(X3);
-        Y = F9::mulsub(R, F9::sub(Q, X3), S1, PPP);
+        F9::mulsub_mul(Y, R, F9::sub(Q, X3), S1, PPP, ZZ, Za, PP);
         X = X3;
-        ZZ = F9::mul(F9::mul(ZZ, q.ZZ), PP);
-        ZZZ = F9::mul(F9::mul(ZZZ, q.ZZZ), PPP);
+        ZZZ = F9::mul(Zb, PPP);
     }
     // canonical 2^256-Montgomery words (what the rest of the pipeline reads); infinity -> all zero
     static __host__ __device__ __noinline__ XYZZ<W> to_xyzz_of(XYZZ9 p) {

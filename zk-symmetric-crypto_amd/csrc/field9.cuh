@@ -13,9 +13,9 @@
 // Value model.  An element is an integer v = sum l[i] * 2^(29 i) taken mod M; it is NOT kept in [0, M):
 //   strict : l[0..7] in [0, 2^29), l[8] signed and small -- what every product returns; unique per integer v
 //   lazy   : any limbs, |l[i]| < k * 2^29 -- what add / sub return (k = sum of the operands' k)
-// mont<NP>() needs, per column, 9 * sum_t A_t * B_t + 9 * 2^58 < 2^63 where A_t, B_t bound the limb magnitudes of the t-th
-// product's operands: one product may take (strict or 1-lazy) x (2-lazy), two fused products (1-lazy x 1-lazy) each.  Callers
-// state their bounds where they use lazy operands.  Values: the result of mont() lies in (S / 2^261, S / 2^261 + M) for the
+// A reduction (mont_lockstep) needs, per column, 9 * sum_t A_t * B_t + 9 * 2^58 < 2^63 where A_t, B_t bound the limb magnitudes of
+// the t-th product's operands: one product may take (strict or 1-lazy) x (2-lazy), two fused products (1-lazy x 1-lazy) each.  Callers
+// state their bounds where they use lazy operands.  Values: the result of a reduction lies in (S / 2^261, S / 2^261 + M) for the
 // integer S = sum of products; all call sites keep |S| < 20 M^2, so results stay within (-M/8, M + M/8) (M / 2^261 < 2^-7.4),
 // sums of a few of them within (-4M, 4M), and |v| < 2^258 everywhere (the top limb never leaves 32 bits).
 //
@@ -67,56 +67,133 @@ struct Field9 {
         acc += (int64_t)a * (int64_t)b;
 #endif
     }
-    // (sum over t < NP of a[t] * b[t]) / 2^261 mod M, strict.  Product scanning: column k collects its products and the
-    // multiples m_i * M_j of the reduction in one 64-bit accumulator, m_k clears the column's low 29 bits, the rest carries on.
-    template <int NP>
-    static ZK_HD Field9 mont(const Field9 *const (&a)[NP], const Field9 *const (&b)[NP]) {
-        int64_t acc = 0;
-        int32_t m[9];
-        Field9 r;
+    // One term of a reduction: a * b, or a^2 when b == nullptr (45 instead of 81 multiply-adds: the cross products are taken once
+    // against 2a; same column sums, so the same limb bounds as a * a).
+    struct Term {
+        const Field9 *a, *b;
+    };
+    // K independent Montgomery reductions in lockstep; reduction j = (sum of its np[j] <= 2 terms) / 2^261 mod M, strict.
+    // Product scanning: column k of reduction j collects its products and the multiples m_i * M_(k-i) in one 64-bit accumulator,
+    // m_k clears the column's low 29 bits, the rest carries into column k+1.  The K accumulator chains are independent and are
+    // issued interleaved (a v_mad_i64_i32 that reads the result of the one just before it costs a wait state on gfx950).
+    template <int K>
+    static ZK_HD void mont_lockstep(const Term (&tm)[K][2], const int (&np)[K], Field9 (&r)[K]) {
+        int64_t acc[K];
+        int32_t m[K][9];
+        Field9 a2[K][2];
 #pragma unroll
-        for (int k = 0; k < 9; k++) {
+        for (int j = 0; j < K; j++) {
+            acc[j] = 0;
 #pragma unroll
-            for (int t = 0; t < NP; t++)
-#pragma unroll
-                for (int i = 0; i <= k; i++) mac(acc, a[t]->l[i], b[t]->l[k - i]);
-#pragma unroll
-            for (int i = 0; i < k; i++) mac_const(acc, m[i], Q::M[k - i]);
-            m[k] = (int32_t)(((uint32_t)acc * Q::PINV) & MASK);
-            mac_const(acc, m[k], Q::M[0]);
-            acc >>= 29;
+            for (int t = 0; t < 2; t++)
+                if (t < np[j] && tm[j][t].b == nullptr) a2[j][t] = add(*tm[j][t].a, *tm[j][t].a);
         }
 #pragma unroll
-        for (int k = 9; k < 17; k++) {
+        for (int k = 0; k < 17; k++) {
+            const int lo = k > 8 ? k - 8 : 0, hi = k < 8 ? k : 8;
 #pragma unroll
-            for (int t = 0; t < NP; t++)
+            for (int i = lo; i <= hi; i++) {
+                const int jj = k - i;
 #pragma unroll
-                for (int i = k - 8; i < 9; i++) mac(acc, a[t]->l[i], b[t]->l[k - i]);
+                for (int t = 0; t < 2; t++)
 #pragma unroll
-            for (int i = k - 8; i < 9; i++) mac_const(acc, m[i], Q::M[k - i]);
-            r.l[k - 9] = (int32_t)((uint32_t)acc & MASK);
-            acc >>= 29;
+                    for (int j = 0; j < K; j++) {
+                        if (t >= np[j]) continue;
+                        const Term &T = tm[j][t];
+                        if (T.b != nullptr) mac(acc[j], T.a->l[i], T.b->l[jj]);
+                        else if (i < jj) mac(acc[j], a2[j][t].l[i], T.a->l[jj]);
+                        else if (i == jj) mac(acc[j], T.a->l[i], T.a->l[i]);
+                    }
+            }
+            if (k < 9) {
+#pragma unroll
+                for (int i = 0; i < k; i++)
+#pragma unroll
+                    for (int j = 0; j < K; j++) mac_const(acc[j], m[j][i], Q::M[k - i]);
+#pragma unroll
+                for (int j = 0; j < K; j++) m[j][k] = (int32_t)(((uint32_t)acc[j] * Q::PINV) & MASK);
+#pragma unroll
+                for (int j = 0; j < K; j++) {
+                    mac_const(acc[j], m[j][k], Q::M[0]);
+                    acc[j] >>= 29;
+                }
+            } else {
+#pragma unroll
+                for (int i = k - 8; i < 9; i++)
+#pragma unroll
+                    for (int j = 0; j < K; j++) mac_const(acc[j], m[j][i], Q::M[k - i]);
+#pragma unroll
+                for (int j = 0; j < K; j++) {
+                    r[j].l[k - 9] = (int32_t)((uint32_t)acc[j] & MASK);
+                    acc[j] >>= 29;
+                }
+            }
         }
-        r.l[8] = (int32_t)acc;
-        return r;
+#pragma unroll
+        for (int j = 0; j < K; j++) r[j].l[8] = (int32_t)acc[j];
     }
     static ZK_HD Field9 mul(const Field9 &a, const Field9 &b) {
-        const Field9 *const pa[1] = {&a};
-        const Field9 *const pb[1] = {&b};
-        return mont<1>(pa, pb);
+        const Term t[1][2] = {{{&a, &b}, {nullptr, nullptr}}};
+        const int np[1] = {1};
+        Field9 r[1];
+        mont_lockstep<1>(t, np, r);
+        return r[0];
+    }
+    static ZK_HD Field9 sqr(const Field9 &a) {
+        const Term t[1][2] = {{{&a, nullptr}, {nullptr, nullptr}}};
+        const int np[1] = {1};
+        Field9 r[1];
+        mont_lockstep<1>(t, np, r);
+        return r[0];
     }
     // a*b - c*d with ONE reduction
     static ZK_HD Field9 mulsub(const Field9 &a, const Field9 &b, const Field9 &c, const Field9 &d) {
         const Field9 nc = neg(c);
-        const Field9 *const pa[2] = {&a, &nc};
-        const Field9 *const pb[2] = {&b, &d};
-        return mont<2>(pa, pb);
+        const Term t[1][2] = {{{&a, &b}, {&nc, &d}}};
+        const int np[1] = {2};
+        Field9 r[1];
+        mont_lockstep<1>(t, np, r);
+        return r[0];
     }
     // a*b + c*d with ONE reduction
     static ZK_HD Field9 muladd(const Field9 &a, const Field9 &b, const Field9 &c, const Field9 &d) {
-        const Field9 *const pa[2] = {&a, &c};
-        const Field9 *const pb[2] = {&b, &d};
-        return mont<2>(pa, pb);
+        const Term t[1][2] = {{{&a, &b}, {&c, &d}}};
+        const int np[1] = {2};
+        Field9 r[1];
+        mont_lockstep<1>(t, np, r);
+        return r[0];
+    }
+    // two / three independent products in lockstep
+    static ZK_HD void mul2(Field9 &r0, const Field9 &a0, const Field9 &b0, Field9 &r1, const Field9 &a1, const Field9 &b1) {
+        const Term t[2][2] = {{{&a0, &b0}, {nullptr, nullptr}}, {{&a1, &b1}, {nullptr, nullptr}}};
+        const int np[2] = {1, 1};
+        Field9 r[2];
+        mont_lockstep<2>(t, np, r);
+        r0 = r[0]; r1 = r[1];
+    }
+    static ZK_HD void sqr2(Field9 &r0, const Field9 &a0, Field9 &r1, const Field9 &a1) {
+        const Term t[2][2] = {{{&a0, nullptr}, {nullptr, nullptr}}, {{&a1, nullptr}, {nullptr, nullptr}}};
+        const int np[2] = {1, 1};
+        Field9 r[2];
+        mont_lockstep<2>(t, np, r);
+        r0 = r[0]; r1 = r[1];
+    }
+    static ZK_HD void mul3(Field9 &r0, const Field9 &a0, const Field9 &b0, Field9 &r1, const Field9 &a1, const Field9 &b1, Field9 &r2, const Field9 &a2,
+                           const Field9 &b2) {
+        const Term t[3][2] = {{{&a0, &b0}, {nullptr, nullptr}}, {{&a1, &b1}, {nullptr, nullptr}}, {{&a2, &b2}, {nullptr, nullptr}}};
+        const int np[3] = {1, 1, 1};
+        Field9 r[3];
+        mont_lockstep<3>(t, np, r);
+        r0 = r[0]; r1 = r[1]; r2 = r[2];
+    }
+    // r0 = a*b - c*d (one reduction), r1 = e*f, in lockstep
+    static ZK_HD void mulsub_mul(Field9 &r0, const Field9 &a, const Field9 &b, const Field9 &c, const Field9 &d, Field9 &r1, const Field9 &e, const Field9 &f) {
+        const Field9 nc = neg(c);
+        const Term t[2][2] = {{{&a, &b}, {&nc, &d}}, {{&e, &f}, {nullptr, nullptr}}};
+        const int np[2] = {2, 1};
+        Field9 r[2];
+        mont_lockstep<2>(t, np, r);
+        r0 = r[0]; r1 = r[1];
     }
     // lazy limb-wise operations: no carries, the limb bounds add up
     static ZK_HD Field9 add(const Field9 &a, const Field9 &b) {
