@@ -86,6 +86,54 @@ int main() {
         ok &= same(a1.dbl(), b1.dbl());
         if (!ok && bad++ < 10) printf("curve mismatch in trial %d\n", trial);
     }
+    // the quadratic extension and G2: the formulas are identities in the coordinates, so arbitrary (x, y) pairs exercise them
+    for (int it = 0; it < 4000; it++) {
+        const Fp2 a{rnd(rng, it % 7), rnd(rng, (it / 7) % 7)}, b{rnd(rng, 0), rnd(rng, (it / 49) % 7)}, c{rnd(rng, 0), rnd(rng, 0)};
+        const Fp29 A = Fp29::from_field(a), B = Fp29::from_field(b), C = Fp29::from_field(c);
+        const Fp29 u = Fp29::sub(A, C);                         // 1-lazy
+        bool ok = Fp29::to_field(A) == a;
+        ok &= Fp29::to_field(Fp29::mul(u, B)) == (a - c) * b;
+        ok &= Fp29::to_field(Fp29::mul(u, Fp29::sub(B, C))) == (a - c) * (b - c);
+        ok &= Fp29::to_field(Fp29::sqr(u)) == (a - c).sqr();
+        ok &= Fp29::to_field(Fp29::mulsub(u, B, C, Fp29::sub(B, A))) == (a - c) * b - c * (b - a);
+        ok &= Fp29::to_field(Fp29::x3(A, B, C)) == a - b - c.dbl();
+        if (!ok && bad++ < 5) printf("Fp2 mismatch at iteration %d\n", it);
+    }
+    {
+        std::vector<G2Affine> q2;
+        for (int i = 0; i < 24; i++) q2.push_back(G2Affine{Fp2{rnd(rng, 0), rnd(rng, 0)}, Fp2{rnd(rng, 0), rnd(rng, 0)}});
+        const Fp2 k2{k32, Fp::zero()};
+        auto chain2 = [&](int trial, int len, G2XYZZ &a, G2X9 &b) {
+            a = G2XYZZ::inf(); b = G2X9::inf();
+            for (int s = 0; s < len; s++) {
+                G2Affine p = q2[rng() % 24];
+                bool neg = rng() & 1;
+                if (trial % 5 == 3 && s == 2) p = q2[0];
+                if (trial % 5 == 3 && s == 3) { p = q2[0]; neg = (trial / 5) & 1; }
+                G2Affine q = p;
+                if (neg) q.y = q.y.neg();
+                a.madd(q);
+                b.madd(Fp29::from_words(p.x * k2), Fp29::cneg(Fp29::from_words(p.y * k2), neg ? -1 : 0));
+            }
+        };
+        auto same2 = [](const G2XYZZ &a, const G2X9 &b) {
+            const G2XYZZ r = b.to_xyzz();
+            return r.X == a.X && r.Y == a.Y && r.ZZ == a.ZZ && r.ZZZ == a.ZZZ;
+        };
+        for (int trial = 0; trial < 120; trial++) {
+            G2XYZZ a1, a2; G2X9 b1, b2;
+            chain2(trial, 1 + rng() % 16, a1, b1);
+            chain2(trial + 1, trial % 11 == 0 ? 0 : 1 + rng() % 16, a2, b2);
+            bool ok = same2(a1, b1) && same2(a2, b2) && same2(a1, G2X9::from_words(b1.to_words()));
+            G2XYZZ s2 = a1; s2.add(a2);
+            G2X9 t2 = b1; t2.add(b2);
+            ok &= same2(s2, t2);
+            G2XYZZ d = a1; d.add(a1);
+            G2X9 e = b1; e.add(b1);
+            ok &= same2(d, e) && same2(a1.dbl(), b1.dbl());
+            if (!ok && bad++ < 10) printf("G2 mismatch in trial %d\n", trial);
+        }
+    }
     printf(bad ? "FAILED %d\n" : "ok\n", bad);
     return bad != 0;
 }

@@ -321,3 +321,18 @@ def test_msm_doubling_and_cancellation_inside_a_bucket(zk, oracle, group):
         got = np.zeros((batch, 128), np.uint8)
         assert zk.lib.zkp_msm_g2(n, batch, pts.ctypes.data, sc.ctypes.data, got.ctypes.data, c) == 0
     assert np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("env,select", [
+    ({"ZKPROVE_NTT_F9": "1"}, "test_ntt_matches_oracle or test_compute_h_matches_oracle or test_full_size_ntt"),
+    ({"ZKPROVE_MSM_F9": "0"}, "test_msm_g1_matches_oracle or test_msm_g2_matches_oracle or doubling"),
+], ids=["transforms_9limb", "buckets_8x32"])
+def test_alternative_field_paths_stay_bit_exact(env, select):
+    """The paths an environment switch selects at library load are parity-tested too: the opt-in 9-limb butterflies of the transforms
+    (ZKPROVE_NTT_F9=1, slower, see csrc/ntt.hip) and the 8 x 32 bucket walk kept for A/B runs (ZKPROVE_MSM_F9=0).  Same tests,
+    own process (the switches are read once)."""
+    import os, subprocess, sys
+    import helpers as H
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(H.ROOT, "tests", "test_gpu_kernels.py"), "-x", "-q", "-m", "gpu", "-k", "(%s) and not alternative_field_paths" % select,      # never itself: the child would spawn a child
+                          "-p", "no:cacheprovider"], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600, cwd=H.ROOT)
+    assert res.returncode == 0 and " passed" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]

@@ -71,10 +71,7 @@ struct alignas(16) XYZZ9 {         // 144 bytes: bucket sums travel between the 
             return;
         }
         F9::mul3(PPP, Pv, PP, Q, X, PP, ZZ3, ZZ, PP);
-        F9 X3;
-#pragma unroll
-        for (int i = 0; i < 9; i++) X3.l[i] = RR.l[i] - PPP.l[i] - 2 * Q.l[i];
-        X3 = F9::norm(X3);
+        const F9 X3 = F9::x3(RR, PPP, Q);
         F9::mulsub_mul(Y, R, F9::sub(Q, X3), Y, PPP, ZZZ, ZZZ, PPP);
         X = X3;
         ZZ = ZZ3;
@@ -95,10 +92,7 @@ struct alignas(16) XYZZ9 {         // 144 bytes: bucket sums travel between the 
             return;
         }
         F9::mul3(PPP, Pv, PP, Q, U1, PP, Zb, ZZZ, q.ZZZ);
-        F9 X3;
-#pragma unroll
-        for (int i = 0; i < 9; i++) X3.l[i] = RR.l[i] - PPP.l[i] - 2 * Q.l[i];
-        X3 = F9::norm(X3);
+        const F9 X3 = F9::x3(RR, PPP, Q);
         F9::mulsub_mul(Y, R, F9::sub(Q, X3), S1, PPP, ZZ, Za, PP);
         X = X3;
         ZZZ = F9::mul(Zb, PPP);
@@ -122,5 +116,6 @@ struct alignas(16) XYZZ9 {         // 144 bytes: bucket sums travel between the 
     }
 };
 using G1X9 = XYZZ9<Fp9>;
+using G2X9 = XYZZ9<Fp29>;
 
 }  // namespace zk

@@ -35,6 +35,7 @@ struct Fp9Params {
     static constexpr int32_t COUT[9] = ZK_F9_FP_COUT;
     static constexpr int32_t ONE[9] = ZK_F9_FP_ONE;
     static constexpr uint32_t SCALE32[8] = ZK_F9_FP_SCALE32;
+    static constexpr int32_t M2[9] = ZK_F9_FP_2M, M4[9] = ZK_F9_FP_4M, M5[9] = ZK_F9_FP_5M;      // strict limbs of 2M, 4M, 5M
 };
 struct Fr9Params {
     using Base = FrParams;
@@ -44,6 +45,7 @@ struct Fr9Params {
     static constexpr int32_t COUT[9] = ZK_F9_FR_COUT;
     static constexpr int32_t ONE[9] = ZK_F9_FR_ONE;
     static constexpr uint32_t SCALE32[8] = ZK_F9_FR_SCALE32;
+    static constexpr int32_t M2[9] = ZK_F9_FR_2M, M4[9] = ZK_F9_FR_4M, M5[9] = ZK_F9_FR_5M;
 };
 
 template <class Q>
@@ -67,10 +69,12 @@ struct Field9 {
         acc += (int64_t)a * (int64_t)b;
 #endif
     }
-    // One term of a reduction: a * b, or a^2 when b == nullptr (45 instead of 81 multiply-adds: the cross products are taken once
-    // against 2a; same column sums, so the same limb bounds as a * a).
+    // One term of a reduction: a * b.  sym promises a_i * b_j == a_j * b_i for all i, j (a == b: a square; a == -b: a negated
+    // square); the cross products are then taken once against 2a -- 45 instead of 81 multiply-adds, same column sums and therefore
+    // the same limb bounds as the full product.  a == nullptr: unused slot.
     struct Term {
         const Field9 *a, *b;
+        bool sym;
     };
     // K independent Montgomery reductions in lockstep; reduction j = (sum of its np[j] <= 2 terms) / 2^261 mod M, strict.
     // Product scanning: column k of reduction j collects its products and the multiples m_i * M_(k-i) in one 64-bit accumulator,
@@ -86,7 +90,7 @@ struct Field9 {
             acc[j] = 0;
 #pragma unroll
             for (int t = 0; t < 2; t++)
-                if (t < np[j] && tm[j][t].b == nullptr) a2[j][t] = add(*tm[j][t].a, *tm[j][t].a);
+                if (t < np[j] && tm[j][t].sym) a2[j][t] = add(*tm[j][t].a, *tm[j][t].a);
         }
 #pragma unroll
         for (int k = 0; k < 17; k++) {
@@ -100,9 +104,9 @@ struct Field9 {
                     for (int j = 0; j < K; j++) {
                         if (t >= np[j]) continue;
                         const Term &T = tm[j][t];
-                        if (T.b != nullptr) mac(acc[j], T.a->l[i], T.b->l[jj]);
-                        else if (i < jj) mac(acc[j], a2[j][t].l[i], T.a->l[jj]);
-                        else if (i == jj) mac(acc[j], T.a->l[i], T.a->l[i]);
+                        if (!T.sym) mac(acc[j], T.a->l[i], T.b->l[jj]);
+                        else if (i < jj) mac(acc[j], a2[j][t].l[i], T.b->l[jj]);
+                        else if (i == jj) mac(acc[j], T.a->l[i], T.b->l[i]);
                     }
             }
             if (k < 9) {
@@ -133,14 +137,14 @@ struct Field9 {
         for (int j = 0; j < K; j++) r[j].l[8] = (int32_t)acc[j];
     }
     static ZK_HD Field9 mul(const Field9 &a, const Field9 &b) {
-        const Term t[1][2] = {{{&a, &b}, {nullptr, nullptr}}};
+        const Term t[1][2] = {{{&a, &b, false}, {nullptr, nullptr, false}}};
         const int np[1] = {1};
         Field9 r[1];
         mont_lockstep<1>(t, np, r);
         return r[0];
     }
     static ZK_HD Field9 sqr(const Field9 &a) {
-        const Term t[1][2] = {{{&a, nullptr}, {nullptr, nullptr}}};
+        const Term t[1][2] = {{{&a, &a, true}, {nullptr, nullptr, false}}};
         const int np[1] = {1};
         Field9 r[1];
         mont_lockstep<1>(t, np, r);
@@ -149,7 +153,7 @@ struct Field9 {
     // a*b - c*d with ONE reduction
     static ZK_HD Field9 mulsub(const Field9 &a, const Field9 &b, const Field9 &c, const Field9 &d) {
         const Field9 nc = neg(c);
-        const Term t[1][2] = {{{&a, &b}, {&nc, &d}}};
+        const Term t[1][2] = {{{&a, &b, false}, {&nc, &d, false}}};
         const int np[1] = {2};
         Field9 r[1];
         mont_lockstep<1>(t, np, r);
@@ -157,7 +161,7 @@ struct Field9 {
     }
     // a*b + c*d with ONE reduction
     static ZK_HD Field9 muladd(const Field9 &a, const Field9 &b, const Field9 &c, const Field9 &d) {
-        const Term t[1][2] = {{{&a, &b}, {&c, &d}}};
+        const Term t[1][2] = {{{&a, &b, false}, {&c, &d, false}}};
         const int np[1] = {2};
         Field9 r[1];
         mont_lockstep<1>(t, np, r);
@@ -165,14 +169,14 @@ struct Field9 {
     }
     // two / three independent products in lockstep
     static ZK_HD void mul2(Field9 &r0, const Field9 &a0, const Field9 &b0, Field9 &r1, const Field9 &a1, const Field9 &b1) {
-        const Term t[2][2] = {{{&a0, &b0}, {nullptr, nullptr}}, {{&a1, &b1}, {nullptr, nullptr}}};
+        const Term t[2][2] = {{{&a0, &b0, false}, {nullptr, nullptr, false}}, {{&a1, &b1, false}, {nullptr, nullptr, false}}};
         const int np[2] = {1, 1};
         Field9 r[2];
         mont_lockstep<2>(t, np, r);
         r0 = r[0]; r1 = r[1];
     }
     static ZK_HD void sqr2(Field9 &r0, const Field9 &a0, Field9 &r1, const Field9 &a1) {
-        const Term t[2][2] = {{{&a0, nullptr}, {nullptr, nullptr}}, {{&a1, nullptr}, {nullptr, nullptr}}};
+        const Term t[2][2] = {{{&a0, &a0, true}, {nullptr, nullptr, false}}, {{&a1, &a1, true}, {nullptr, nullptr, false}}};
         const int np[2] = {1, 1};
         Field9 r[2];
         mont_lockstep<2>(t, np, r);
@@ -180,7 +184,7 @@ struct Field9 {
     }
     static ZK_HD void mul3(Field9 &r0, const Field9 &a0, const Field9 &b0, Field9 &r1, const Field9 &a1, const Field9 &b1, Field9 &r2, const Field9 &a2,
                            const Field9 &b2) {
-        const Term t[3][2] = {{{&a0, &b0}, {nullptr, nullptr}}, {{&a1, &b1}, {nullptr, nullptr}}, {{&a2, &b2}, {nullptr, nullptr}}};
+        const Term t[3][2] = {{{&a0, &b0, false}, {nullptr, nullptr, false}}, {{&a1, &b1, false}, {nullptr, nullptr, false}}, {{&a2, &b2, false}, {nullptr, nullptr, false}}};
         const int np[3] = {1, 1, 1};
         Field9 r[3];
         mont_lockstep<3>(t, np, r);
@@ -189,11 +193,18 @@ struct Field9 {
     // r0 = a*b - c*d (one reduction), r1 = e*f, in lockstep
     static ZK_HD void mulsub_mul(Field9 &r0, const Field9 &a, const Field9 &b, const Field9 &c, const Field9 &d, Field9 &r1, const Field9 &e, const Field9 &f) {
         const Field9 nc = neg(c);
-        const Term t[2][2] = {{{&a, &b}, {&nc, &d}}, {{&e, &f}, {nullptr, nullptr}}};
+        const Term t[2][2] = {{{&a, &b, false}, {&nc, &d, false}}, {{&e, &f, false}, {nullptr, nullptr, false}}};
         const int np[2] = {2, 1};
         Field9 r[2];
         mont_lockstep<2>(t, np, r);
         r0 = r[0]; r1 = r[1];
+    }
+    // rr - ppp - 2q, normalised (the X3 of the addition formulas: three strict operands, a 4-lazy difference)
+    static ZK_HD Field9 x3(const Field9 &rr, const Field9 &ppp, const Field9 &q) {
+        Field9 r;
+#pragma unroll
+        for (int i = 0; i < 9; i++) r.l[i] = rr.l[i] - ppp.l[i] - 2 * q.l[i];
+        return norm(r);
     }
     // lazy limb-wise operations: no carries, the limb bounds add up
     static ZK_HD Field9 add(const Field9 &a, const Field9 &b) {
@@ -322,5 +333,67 @@ struct Field9 {
 };
 using Fp9 = Field9<Fp9Params>;
 using Fr9 = Field9<Fr9Params>;
+
+// Fp2 = Fp[u] / (u^2 + 1) over the 9-limb Fp: same static interface as Field9, so that XYZZ9 (curve9.cuh) serves G2 as well.
+// A product is FOUR limb products and TWO reductions (c0 = a0 b0 - a1 b1 and c1 = a0 b1 + a1 b0 each share one; the two
+// reductions run in lockstep) = 486 multiply-adds, against three full 8 x 32 products + five modular additions for Karatsuba
+// on the saturated field; a square is 369.  Every reduction here sums TWO products, so operands may be 1-lazy at most
+// (strict - strict), never 2-lazy; results are strict.
+struct Fp29 {
+    using Words = Fp2;
+    using T = Fp9::Term;
+    Fp9 c0, c1;
+    static ZK_HD Fp29 zero() { return Fp29{Fp9::zero(), Fp9::zero()}; }
+    static ZK_HD Fp29 one() { return Fp29{Fp9::one(), Fp9::zero()}; }
+    ZK_HD bool is_zero_exact() const { return c0.is_zero_exact() && c1.is_zero_exact(); }
+    ZK_HD bool is_zero_mod() const { return c0.is_zero_mod() && c1.is_zero_mod(); }
+    static ZK_HD Fp29 add(const Fp29 &a, const Fp29 &b) { return Fp29{Fp9::add(a.c0, b.c0), Fp9::add(a.c1, b.c1)}; }
+    static ZK_HD Fp29 sub(const Fp29 &a, const Fp29 &b) { return Fp29{Fp9::sub(a.c0, b.c0), Fp9::sub(a.c1, b.c1)}; }
+    static ZK_HD Fp29 neg(const Fp29 &a) { return Fp29{Fp9::neg(a.c0), Fp9::neg(a.c1)}; }
+    static ZK_HD Fp29 cneg(const Fp29 &a, int32_t s) { return Fp29{Fp9::cneg(a.c0, s), Fp9::cneg(a.c1, s)}; }
+    static ZK_HD Fp29 norm(const Fp29 &a) { return Fp29{Fp9::norm(a.c0), Fp9::norm(a.c1)}; }
+    static ZK_HD Fp29 x3(const Fp29 &rr, const Fp29 &ppp, const Fp29 &q) { return Fp29{Fp9::x3(rr.c0, ppp.c0, q.c0), Fp9::x3(rr.c1, ppp.c1, q.c1)}; }
+    static ZK_HD Fp29 from_words(const Fp2 &x) { return Fp29{Fp9::from_words(x.a0), Fp9::from_words(x.a1)}; }
+    static ZK_HD Fp2 to_words(const Fp29 &x) { return Fp2{Fp9::to_words(x.c0), Fp9::to_words(x.c1)}; }
+    static ZK_HD Fp29 from_field(const Fp2 &x) { return Fp29{Fp9::from_field(x.a0), Fp9::from_field(x.a1)}; }
+    static ZK_HD Fp2 to_field(const Fp29 &x) { return Fp2{Fp9::to_field(x.c0), Fp9::to_field(x.c1)}; }
+    static ZK_HD Fp29 mul(const Fp29 &a, const Fp29 &b) {
+        const Fp9 na1 = Fp9::neg(a.c1);
+        const T t[2][2] = {{{&a.c0, &b.c0, false}, {&na1, &b.c1, false}}, {{&a.c0, &b.c1, false}, {&a.c1, &b.c0, false}}};
+        const int np[2] = {2, 2};
+        Fp9 r[2];
+        Fp9::mont_lockstep<2>(t, np, r);
+        return Fp29{r[0], r[1]};
+    }
+    // (a0^2 - a1^2) + (2 a0 a1) u: two symmetric terms (45 products each) and one product against 2 a0 (2-lazy x 1-lazy)
+    static ZK_HD Fp29 sqr(const Fp29 &a) {
+        const Fp9 na1 = Fp9::neg(a.c1), d0 = Fp9::add(a.c0, a.c0);
+        const T t[2][2] = {{{&a.c0, &a.c0, true}, {&na1, &a.c1, true}}, {{&d0, &a.c1, false}, {nullptr, nullptr, false}}};
+        const int np[2] = {2, 1};
+        Fp9 r[2];
+        Fp9::mont_lockstep<2>(t, np, r);
+        return Fp29{r[0], r[1]};
+    }
+    // the tower cannot fuse a*b - c*d (four products per coordinate would overflow a column): two products, a carry propagation
+    static ZK_HD Fp29 mulsub(const Fp29 &a, const Fp29 &b, const Fp29 &c, const Fp29 &d) { return norm(sub(mul(a, b), mul(c, d))); }
+    static ZK_HD void mul2(Fp29 &r0, const Fp29 &a0, const Fp29 &b0, Fp29 &r1, const Fp29 &a1, const Fp29 &b1) {
+        r0 = mul(a0, b0);
+        r1 = mul(a1, b1);
+    }
+    static ZK_HD void sqr2(Fp29 &r0, const Fp29 &a0, Fp29 &r1, const Fp29 &a1) {
+        r0 = sqr(a0);
+        r1 = sqr(a1);
+    }
+    static ZK_HD void mul3(Fp29 &r0, const Fp29 &a0, const Fp29 &b0, Fp29 &r1, const Fp29 &a1, const Fp29 &b1, Fp29 &r2, const Fp29 &a2, const Fp29 &b2) {
+        r0 = mul(a0, b0);
+        r1 = mul(a1, b1);
+        r2 = mul(a2, b2);
+    }
+    static ZK_HD void mulsub_mul(Fp29 &r0, const Fp29 &a, const Fp29 &b, const Fp29 &c, const Fp29 &d, Fp29 &r1, const Fp29 &e, const Fp29 &f) {
+        const Fp29 t = mulsub(a, b, c, d);      // r0 may alias c (the accumulator's Y): read everything first
+        r1 = mul(e, f);
+        r0 = t;
+    }
+};
 
 }  // namespace zk

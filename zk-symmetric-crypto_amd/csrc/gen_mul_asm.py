@@ -137,6 +137,8 @@ def gen_field9():
         out.append("#define ZK_F9_%s_CIN %s    /* 2^266 mod M: 2^256-Montgomery words -> 2^261-Montgomery limbs */" % (name, fmt(pow(2, 266, mod))))
         out.append("#define ZK_F9_%s_COUT %s   /* 2^256 mod M: and back */" % (name, fmt(pow(2, 256, mod))))
         out.append("#define ZK_F9_%s_ONE %s    /* 2^261 mod M */" % (name, fmt(pow(2, 261, mod))))
+        for k in (2, 4, 5):
+            out.append("#define ZK_F9_%s_%dM %s    /* %d M, strict limbs */" % (name, k, "{ " + ", ".join("0x%08x" % ((k * mod >> (29 * i)) & ((1 << 29) - 1) if i < 8 else (k * mod) >> 232) for i in range(9)) + " }", k))
         out.append("#define ZK_F9_%s_SCALE32 { %s }   /* 32 in 2^256-Montgomery words: x -> 2^5 x moves a stored value to the 2^261 form */"
                    % (name, ", ".join("0x%08xu" % x for x in limbs((32 << 256) % mod))))
     open("field9_consts.inc", "w").write("\n".join(out) + "\n")

@@ -11,6 +11,9 @@ struct NttDomain {
     int logn = 0;
     size_t n = 0;
     DevBuf<Fr> consts, tw_fwd, tw_inv, coset_pre, coset_post;
+    bool f9 = false;                                           // butterflies on the 9 x 29-bit field (ntt.hip, Ntt9): opt-in experiment, ZKPROVE_NTT_F9=1
+    DevBuf<Fr> tw_fwd9, tw_inv9, coset_pre9, coset_post9;      // the same multiplier tables in the 2^261-Montgomery form
+    const Fr *table9(const Fr *t) const;
     void init(int logn, hipStream_t s);
     // data layout [n][B]; see ntt.hip
     void dif(Fr *data, size_t B, bool inverse, const Fr *postmul, hipStream_t s) const;
@@ -35,7 +38,7 @@ struct MsmBases {
     DevBuf<Affine<F>> table;
     DevBuf<Affine<F>> tern;        // conditional-sum path: signed subset sums of every group of 6 bases (msm.hip, TERN_*)
     DevBuf<uint32_t> scalar_row;   // row index of the scalar of point j in the [row][B] scalar matrix
-    bool f9 = false;               // G1: table coordinates are in the 2^261-Montgomery form of field9.cuh (accumulated by k_msm_accumulate9)
+    bool f9 = false;               // table / tern coordinates are in the 2^261-Montgomery form of field9.cuh (walked by the *9 kernels of msm.hip)
     bool dense = false;            // quotient MSM: all scalars wide, read from an instance-major copy [B][dense_stride]
     size_t dense_stride = 0;
 };

@@ -32,8 +32,9 @@ namespace zk {
 // (one Prove() call) is pure latency of dependent additions, and 4x more threads cut it 4x
 static constexpr int SEG_LOG = 6, SEG_LOG_SMALL = 4;
 static inline uint32_t seg_len(uint32_t nb, size_t B) {
+    static const size_t min_threads = [] { const char *e = getenv("ZKPROVE_SEG_THREADS"); return e ? (size_t)atol(e) : (size_t)32768; }();
     uint32_t L = nb < (1u << SEG_LOG) ? nb : (1u << SEG_LOG);
-    if ((size_t)(nb / L) * B < 32768 && nb > (1u << SEG_LOG_SMALL)) L = 1u << SEG_LOG_SMALL;
+    if ((size_t)(nb / L) * B < min_threads && nb > (1u << SEG_LOG_SMALL)) L = 1u << SEG_LOG_SMALL;
     return L;
 }
 static constexpr size_t FOLD_GROUP = 8;      // partial sums are folded 8 at a time, level by level
@@ -53,6 +54,12 @@ static bool tree_enabled();
 static bool f9_enabled() {
     static const bool on = [] { const char *e = getenv("ZKPROVE_MSM_F9"); return !(e && e[0] == '0'); }();
     return on && !tree_enabled();
+}
+// the same for G2 (the tower Fp29), with a switch of its own for A/B runs: ZKPROVE_MSM_F9_G2=0
+static bool f9_g2_enabled() {
+    static const bool on = [] { const char *e = getenv("ZKPROVE_MSM_F9_G2"); return !(e && e[0] == '0'); }();
+    static const bool all = [] { const char *e = getenv("ZKPROVE_MSM_F9"); return !(e && e[0] == '0'); }();
+    return on && all;
 }
 
 // ------------------------------------------------------------------------------ table precompute
@@ -123,9 +130,12 @@ static void bases_build(MsmBases<F> &mb, const Affine<F> *d_points, size_t n, co
         hipLaunchKernelGGL(k_window_multiples<F>, dim3(ceil_div(m, 256)), dim3(256), 0, s, d_points + off, m, c, mb.W, tmp.p);
         hipLaunchKernelGGL(k_xyzz_to_affine<F>, dim3(ceil_div(m * mb.W, 256)), dim3(256), 0, s, tmp.p, mb.table.p + off * mb.W, m * mb.W);
     }
-    if constexpr (sizeof(F) == 32) {
-        mb.f9 = f9_enabled();
-        if (mb.f9) hipLaunchKernelGGL(k_table_to_f9, dim3(ceil_div(tot * 2, 256)), dim3(256), 0, s, (Fp *)mb.table.p, tot * 2);
+    mb.f9 = sizeof(F) == 32 ? f9_enabled() : f9_g2_enabled();
+    if (mb.f9) {
+        const size_t per = sizeof(Affine<F>) / sizeof(Fp);           // Fp coordinates per point: 2 (G1) / 4 (G2)
+        hipLaunchKernelGGL(k_table_to_f9, dim3(ceil_div(tot * per, 256)), dim3(256), 0, s, (Fp *)mb.table.p, tot * per);
+        const size_t tn = ngroups * TERN_ENTRIES * per;
+        if (tn) hipLaunchKernelGGL(k_table_to_f9, dim3(ceil_div(tn, 256)), dim3(256), 0, s, (Fp *)mb.tern.p, tn);
     }
     ZK_HIP(hipGetLastError());
     ZK_HIP(hipStreamSynchronize(s));
@@ -183,7 +193,7 @@ void MsmScratch::reserve_compact(size_t B_, size_t max_sparse_n) {
 }
 void MsmScratch::reserve_sums(size_t B_, size_t nb_g1, size_t nb_g2) {
     sums1.ensure(((B_ > VIRT_MIN ? B_ : VIRT_MIN) * nb_g1 + 1) * sizeof(G1X9) / sizeof(G1XYZZ) + 1);      // G1 bucket records are G1X9 (144 bytes) on the 9-limb path
-    sums2.ensure(B_ * nb_g2 + 1);
+    sums2.ensure((B_ * nb_g2 + 1) * sizeof(G2X9) / sizeof(G2XYZZ) + 1);
 }
 void MsmScratch::reserve(size_t B_, size_t max_entries, size_t max_nb, size_t max_part) {
     B = B_;
@@ -476,8 +486,16 @@ __global__ __launch_bounds__(256) void k_msm_binsort(const uint32_t *__restrict_
 // DENSE only names the instantiation (quotient MSM vs. wire MSMs) so that profiler summaries keep the dominant launch apart.
 // both groups accumulate in weak form (madd_w); G1 with the multiplier expanded in place, G2 through the shared out-of-line copy
 // Accumulator policies of the walk below.  AccWords: XYZZ<F> in weak form on the 8 x 32 field (G2; G1 when the 9-limb path is off).
-// Acc9: G1 on the 9 x 29-bit field (field9.cuh / curve9.cuh) -- the table then holds the 2^261-Montgomery form (bases_build), the
-// bucket sums are G1X9 records read by k_msm_bucket_reduce9, which hands the canonical 2^256 form to the rest of the pipeline.
+// Acc9: the 9 x 29-bit field (field9.cuh / curve9.cuh; Fp9 for G1, the tower Fp29 for G2) -- the table then holds the 2^261-Montgomery
+// form (bases_build), the bucket sums are XYZZ9 records read by k_msm_bucket_reduce9, which hands the canonical 2^256 form on.
+// 9-limb counterparts of the coordinate fields
+template <class F>
+struct Nine;
+template <>
+struct Nine<Fp> { using F9 = Fp9; using X9 = G1X9; };
+template <>
+struct Nine<Fp2> { using F9 = Fp29; using X9 = G2X9; };
+
 template <class F>
 struct AccWords {
     using Out = XYZZ<F>;
@@ -490,16 +508,19 @@ struct AccWords {
     }
     __device__ __forceinline__ XYZZ<F> result() const { return a.canon(); }
 };
+template <class F>
 struct Acc9 {
-    using Out = G1X9;              // raw strict limbs (144 bytes): leaving a bucket costs no arithmetic -- a wavefront leaves some bucket in
-                                   // almost every iteration, so whatever a store costs is paid by all 64 lanes nearly every time
-    G1X9 a;
-    __device__ __forceinline__ void reset() { a = G1X9::inf(); }
-    __device__ __forceinline__ void add(const Affine<Fp> &p, bool negate) {
+    using F9 = typename Nine<F>::F9;
+    using X9 = typename Nine<F>::X9;
+    using Out = X9;                // raw strict limbs (144 / 288 bytes): leaving a bucket costs no arithmetic -- a wavefront leaves some bucket
+                                   // in almost every iteration, so whatever a store costs is paid by all 64 lanes nearly every time
+    X9 a;
+    __device__ __forceinline__ void reset() { a = X9::inf(); }
+    __device__ __forceinline__ void add(const Affine<F> &p, bool negate) {
         if (p.is_inf()) return;
-        a.madd(Fp9::from_words(p.x), Fp9::cneg(Fp9::from_words(p.y), negate ? -1 : 0));
+        a.madd(F9::from_words(p.x), F9::cneg(F9::from_words(p.y), negate ? -1 : 0));
     }
-    __device__ __forceinline__ G1X9 result() const { return a; }
+    __device__ __forceinline__ X9 result() const { return a; }
 };
 template <class F, bool DENSE, class ACC>
 __device__ __forceinline__ void accumulate_body(const Affine<F> *__restrict__ table, const uint32_t *__restrict__ bucket_start,
@@ -578,15 +599,16 @@ __global__ __launch_bounds__(64, ZK_FP2_WAVES(F)) void k_msm_accumulate(const Af
 ZK_ACC_G1(true)
 ZK_ACC_G1(false)
 #undef ZK_ACC_G1
-// G1 on the 9-limb field (the default; ZKPROVE_MSM_F9=0 keeps the 8 x 32 walk above for comparison)
+// the 9-limb walks (the default; ZKPROVE_MSM_F9=0 keeps the 8 x 32 ones above for comparison)
 #ifndef ZK_ACC9_WAVES
 #define ZK_ACC9_WAVES 4
 #endif
-template <bool DENSE>
-__global__ __launch_bounds__(64, ZK_ACC9_WAVES) void k_msm_accumulate9(const Affine<Fp> *__restrict__ table, const uint32_t *__restrict__ bucket_start,
-                                                                        const uint32_t *__restrict__ entries, size_t max_entries, int c, size_t B,
-                                                                        uint32_t nlanes, G1X9 *__restrict__ sums) {
-    accumulate_body<Fp, DENSE, Acc9>(table, bucket_start, entries, max_entries, c, B, nlanes, sums);
+#define ZK_ACC9_BOUNDS(F) (sizeof(F) == 64 ? 2 : ZK_ACC9_WAVES)
+template <class F, bool DENSE>
+__global__ __launch_bounds__(64, ZK_ACC9_BOUNDS(F)) void k_msm_accumulate9(const Affine<F> *__restrict__ table, const uint32_t *__restrict__ bucket_start,
+                                                                          const uint32_t *__restrict__ entries, size_t max_entries, int c, size_t B,
+                                                                          uint32_t nlanes, typename Nine<F>::X9 *__restrict__ sums) {
+    accumulate_body<F, DENSE, Acc9<F>>(table, bucket_start, entries, max_entries, c, B, nlanes, sums);
 }
 
 // thread (b, seg): running-sum reduction of buckets [seg*L, seg*L + L) of instance b
@@ -625,8 +647,11 @@ __global__ __launch_bounds__(64) void k_msm_bucket_reduce(const XYZZ<F> *__restr
 
 // the same running-sum reduction over the G1X9 bucket records of k_msm_accumulate9; the segment total leaves in the canonical
 // 2^256 form, the rare s0 * run correction is done there as above
-__global__ __launch_bounds__(64) void k_msm_bucket_reduce9(const G1X9 *__restrict__ sums, const uint32_t *__restrict__ bucket_start, int c, size_t B,
-                                                           G1XYZZ *__restrict__ part, size_t part_stride, size_t part_off, uint32_t L) {
+template <class F>
+__global__ __launch_bounds__(64, ZK_FP2_WAVES(F)) void k_msm_bucket_reduce9(const typename Nine<F>::X9 *__restrict__ sums, const uint32_t *__restrict__ bucket_start,
+                                                                           int c, size_t B, XYZZ<F> *__restrict__ part, size_t part_stride, size_t part_off,
+                                                                           uint32_t L) {
+    using X9 = typename Nine<F>::X9;
     const uint32_t nb = 1u << (c - 1);
     const uint32_t nseg = nb / L;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -634,8 +659,8 @@ __global__ __launch_bounds__(64) void k_msm_bucket_reduce9(const G1X9 *__restric
     const size_t b = t / nseg;
     const uint32_t seg = (uint32_t)(t % nseg);
     const uint32_t *bs = bucket_start + b * (nb + 1);
-    const G1X9 *in = sums + b * nb;
-    G1X9 run9 = G1X9::inf(), tot9 = G1X9::inf();
+    const X9 *in = sums + b * nb;
+    X9 run9 = X9::inf(), tot9 = X9::inf();
     const uint32_t s0 = seg * L;
     uint32_t hi = bs[s0 + L];
     for (int k = (int)L - 1; k >= 0; k--) {
@@ -644,17 +669,17 @@ __global__ __launch_bounds__(64) void k_msm_bucket_reduce9(const G1X9 *__restric
         tot9.add(run9);
         hi = lo;
     }
-    const G1XYZZ run = run9.to_xyzz();
-    G1XYZZ tot = tot9.to_xyzz();
-    if (s0 != 0 && !run.is_inf()) {
-        G1XYZZ m = G1XYZZ::inf();
+    // contribution = tot + s0 * run   (bucket index i carries weight i+1), double-and-add on the same field
+    if (s0 != 0 && !run9.is_inf()) {
+        X9 m = X9::inf();
+#pragma unroll 1
         for (int bit = 31 - __clz(s0); bit >= 0; bit--) {
-            m = m.dbl();
-            if ((s0 >> bit) & 1) m.add(run);
+            m = X9::dbl_of(m);
+            if ((s0 >> bit) & 1) m.add(run9);
         }
-        tot.add(m);
+        tot9.add(m);
     }
-    part[b * part_stride + part_off + seg] = tot;
+    part[b * part_stride + part_off + seg] = tot9.to_xyzz();
 }
 
 // thread (chunk, b): lanes = consecutive instances.  Scalars +-1 are summed here; scalars that are neither 0 nor
@@ -739,6 +764,82 @@ __global__ __launch_bounds__(256, ZK_FP2_WAVES(F)) void k_msm_ones(const Affine<
     part[b * part_stride + part_off + chunk] = acc;
 }
 
+// k_msm_ones on the 9-limb field (field9.cuh): same classification, the group patterns are parked in LDS so that the
+// additions are ONE rolled loop around one expanded mixed addition (twenty unrolled copies would be 300 KB of code); tern holds the
+// 2^261-Montgomery form (bases_build), the chunk total leaves in the canonical 2^256 form
+template <class F>
+__global__ __launch_bounds__(256, ZK_FP2_WAVES(F)) void k_msm_ones9(const Affine<F> *__restrict__ tern, const Fr *__restrict__ scalars, size_t B,
+                                                                    const uint32_t *__restrict__ rows, size_t n, XYZZ<F> *__restrict__ part,
+                                                                    size_t part_stride, size_t part_off, uint32_t *__restrict__ gen_count,
+                                                                    uint32_t *__restrict__ gen_idx, Fr *__restrict__ gen_val) {
+    using F9 = typename Nine<F>::F9;
+    using X9 = typename Nine<F>::X9;
+    __shared__ uint16_t spat[ONES_GROUPS][256];
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nchunks = (n + ONES_CHUNK - 1) / ONES_CHUNK;
+    if (t >= nchunks * B) return;
+    const size_t b = t % B, chunk = t / B;
+    const size_t j0 = chunk * ONES_CHUNK;
+    const size_t j1 = j0 + ONES_CHUNK < n ? j0 + ONES_CHUNK : n;
+    const Fr one = Fr::one(), mone = fr_minus_one();
+    uint32_t gen[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int g = 0; g < ONES_GROUPS; g++) {
+        const size_t jb = j0 + (size_t)g * TERN_G;
+        uint32_t idx = TERN_CENTER;
+        if (jb < j1) {
+            Fr sv[TERN_G];
+#pragma unroll
+            for (int q = 0; q < TERN_G; q++) {
+                const size_t j = jb + q < j1 ? jb + q : j1 - 1;
+                sv[q] = scalars[(size_t)rows[j] * B + b];
+            }
+            uint32_t p3 = 1;
+#pragma unroll
+            for (int q = 0; q < TERN_G; q++, p3 *= 3) {
+                if (jb + q >= j1) break;
+                const Fr &sc = sv[q];
+                if (sc.is_zero()) continue;
+                if (sc == one) idx += p3;
+                else if (sc == mone) idx -= p3;
+                else { const uint32_t k = (uint32_t)(g * TERN_G + q); gen[k >> 5] |= 1u << (k & 31); }
+            }
+        }
+        spat[g][threadIdx.x] = (uint16_t)idx;          // own column only: no barrier needed
+    }
+#pragma unroll
+    for (int wd = 0; wd < 4; wd++) {
+        uint32_t m = gen[wd];
+        while (m) {
+            const int bit = __ffs((int)m) - 1;
+            m &= m - 1;
+            const size_t j = j0 + wd * 32 + bit;
+            const uint32_t q = atomicAdd(&gen_count[b], 1u);
+            gen_idx[b * n + q] = (uint32_t)j;
+            gen_val[b * n + q] = scalars[(size_t)rows[j] * B + b].from_mont();
+        }
+    }
+    X9 acc = X9::inf();
+    const Affine<F> *tg = tern + chunk * ONES_GROUPS * (size_t)TERN_ENTRIES;
+    auto fetch = [&](int g, uint32_t pt) -> Affine<F> {
+        const uint32_t e = pt > TERN_CENTER ? pt - TERN_CENTER - 1 : TERN_CENTER - 1 - pt;
+        return tg[(size_t)g * TERN_ENTRIES + e];
+    };
+    uint32_t pt = spat[0][threadIdx.x];
+    Affine<F> p = Affine<F>::inf();
+    if (pt != TERN_CENTER) p = fetch(0, pt);
+#pragma unroll 1
+    for (int g = 0; g < ONES_GROUPS; g++) {
+        const uint32_t ptn = g + 1 < ONES_GROUPS ? spat[g + 1][threadIdx.x] : (uint32_t)TERN_CENTER;
+        Affine<F> pn = Affine<F>::inf();
+        if (ptn != TERN_CENTER) pn = fetch(g + 1, ptn);          // the next group's addend is loaded under the addition
+        if (pt != TERN_CENTER && !p.is_inf()) acc.madd(F9::from_words(p.x), F9::cneg(F9::from_words(p.y), pt < TERN_CENTER ? -1 : 0));
+        p = pn;
+        pt = ptn;
+    }
+    part[b * part_stride + part_off + chunk] = acc.to_xyzz();
+}
+
 // instance-major copy of the element-wise product of two [rows][B] matrices (tiled through LDS):
 // out[b * stride + i] = x[i * B + b] * y[i * B + b]   (quotient stage: f = A*B on the coset)
 __global__ __launch_bounds__(256) void k_transpose_mul_fr(const Fr *__restrict__ x, const Fr *__restrict__ y, Fr *__restrict__ out, size_t rows, size_t B, size_t stride) {
@@ -815,16 +916,15 @@ static void launch_accumulate_reduce(const MsmBases<F> &mb, const uint32_t *bs_p
     const uint32_t nb = 1u << (c - 1);
     const size_t nseg = nb / L;
     const dim3 grid(ceil_div((size_t)nlanes * B, 64)), rgrid(ceil_div(nseg * B, 64));
-    if constexpr (sizeof(F) == 32) {
-        if (mb.f9) {
-            if (sums_cap * sizeof(XYZZ<F>) < B * (size_t)nb * sizeof(G1X9)) throw ZkError("msm bucket-sum scratch too small");
-            G1X9 *sums9 = reinterpret_cast<G1X9 *>(sums);
-            if (seg_events) ZK_HIP(hipEventRecord(seg_events[0], s));
-            hipLaunchKernelGGL((k_msm_accumulate9<DENSE>), grid, dim3(64), 0, s, mb.table.p, bs_p, ent_p, max_entries, c, B, nlanes, sums9);
-            if (seg_events) ZK_HIP(hipEventRecord(seg_events[1], s));
-            hipLaunchKernelGGL(k_msm_bucket_reduce9, rgrid, dim3(64), 0, s, sums9, bs_p, c, B, part, stride, part_off, L);
-            return;
-        }
+    if (mb.f9) {
+        using X9 = typename Nine<F>::X9;
+        if (sums_cap * sizeof(XYZZ<F>) < B * (size_t)nb * sizeof(X9)) throw ZkError("msm bucket-sum scratch too small");
+        X9 *sums9 = reinterpret_cast<X9 *>(sums);
+        if (seg_events) ZK_HIP(hipEventRecord(seg_events[0], s));
+        hipLaunchKernelGGL((k_msm_accumulate9<F, DENSE>), grid, dim3(64), 0, s, mb.table.p, bs_p, ent_p, max_entries, c, B, nlanes, sums9);
+        if (seg_events) ZK_HIP(hipEventRecord(seg_events[1], s));
+        hipLaunchKernelGGL(k_msm_bucket_reduce9<F>, rgrid, dim3(64), 0, s, sums9, bs_p, c, B, part, stride, part_off, L);
+        return;
     }
     if (sums_cap < B * (size_t)nb) throw ZkError("msm bucket-sum scratch too small");
     if (seg_events) ZK_HIP(hipEventRecord(seg_events[0], s));
@@ -1000,8 +1100,12 @@ static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, M
     } else {
         if (sc.gen_count.n < B || sc.gen_idx.n < B * n || sc.gen_val.n < B * n) throw ZkError("msm compact-list scratch too small");
         ZK_HIP(hipMemsetAsync(sc.gen_count.p, 0, B * sizeof(uint32_t), s));
-        hipLaunchKernelGGL(k_msm_ones<F>, dim3(ceil_div(nchunks * B, 256)), dim3(256), 0, s, mb.tern.p, scalars, B, mb.scalar_row.p, n, part,
-                           stride, (size_t)0, sc.gen_count.p, sc.gen_idx.p, sc.gen_val.p);
+        if (mb.f9)
+            hipLaunchKernelGGL(k_msm_ones9<F>, dim3(ceil_div(nchunks * B, 256)), dim3(256), 0, s, mb.tern.p, scalars, B, mb.scalar_row.p, n, part, stride,
+                               (size_t)0, sc.gen_count.p, sc.gen_idx.p, sc.gen_val.p);
+        else
+            hipLaunchKernelGGL(k_msm_ones<F>, dim3(ceil_div(nchunks * B, 256)), dim3(256), 0, s, mb.tern.p, scalars, B, mb.scalar_row.p, n, part,
+                               stride, (size_t)0, sc.gen_count.p, sc.gen_idx.p, sc.gen_val.p);
         hipLaunchKernelGGL(k_msm_sort<false>, dim3((unsigned)B), dim3(SORT_THREADS), lds, s, (const Fr *)nullptr, (size_t)0, sc.gen_count.p, sc.gen_idx.p,
                            sc.gen_val.p, n, c, W, sc.bucket_start.p, sc.entries.p, max_entries);
     }

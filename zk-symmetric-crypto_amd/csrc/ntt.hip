@@ -18,6 +18,7 @@
 // inverse + coset-forward on a and b (to_coset); the rest of computeH lives in the folded key (keyfold.hip).
 // compute_h (all 7 transforms) is kept as the kernel-level entry point zkp_compute_h for parity tests.
 #include "kernels.h"
+#include "field9.cuh"
 
 namespace zk {
 
@@ -67,6 +68,16 @@ __global__ void k_ntt_tables(const Fr *consts, int logn, Fr *tw_fwd, Fr *tw_inv,
     coset_post[i] = fr_pow_u64(consts[2], r) * consts[3];
 }
 
+// out = 2^5 * in: the 2^261-Montgomery form of a multiplier table (canonical words)
+__global__ void k_ntt_table9(const Fr *__restrict__ in, Fr *__restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr k;
+#pragma unroll
+    for (int j = 0; j < 8; j++) k.l[j] = Fr9Params::SCALE32[j];
+    out[i] = in[i] * k;
+}
+
 void NttDomain::init(int logn_, hipStream_t s) {
     logn = logn_;
     n = (size_t)1 << logn;
@@ -77,15 +88,139 @@ void NttDomain::init(int logn_, hipStream_t s) {
     coset_post.alloc(n);
     hipLaunchKernelGGL(k_ntt_consts, dim3(1), dim3(64), 0, s, consts.p, logn);
     hipLaunchKernelGGL(k_ntt_tables, dim3(ceil_div(n, 256)), dim3(256), 0, s, consts.p, logn, tw_fwd.p, tw_inv.p, coset_pre.p, coset_post.p);
+    // Opt-in experiment (ZKPROVE_NTT_F9=1): bit-exact, but measured SLOWER than the weak 8 x 32 butterflies (27.5 vs 24.3 ms per 1024-batch
+    // of 2^16, 58.7 vs 52.0 ms at 2^17): a butterfly is one product and two additions, and what the 9-limb product saves (162
+    // multiply-adds against 256 multiply-add / carry instructions) the additions give back -- a sum has to be brought back under 4M
+    // and re-normalised (44 instructions against 32), the table entry re-limbed (17), and the tile holds 2 wavefronts per SIMD, where
+    // the single dependent accumulator chain of a lone product is not hidden.  The bucket kernels (msm.hip), which are products
+    // almost only, gain 25 % from the same field.
+    static const bool want9 = [] { const char *e = getenv("ZKPROVE_NTT_F9"); return e && e[0] == '1'; }();
+    f9 = want9;
+    if (f9) {
+        tw_fwd9.alloc(n / 2 + 1); tw_inv9.alloc(n / 2 + 1); coset_pre9.alloc(n); coset_post9.alloc(n);
+        const size_t h = n / 2 ? n / 2 : 1;
+        hipLaunchKernelGGL(k_ntt_table9, dim3(ceil_div(h, 256)), dim3(256), 0, s, tw_fwd.p, tw_fwd9.p, h);
+        hipLaunchKernelGGL(k_ntt_table9, dim3(ceil_div(h, 256)), dim3(256), 0, s, tw_inv.p, tw_inv9.p, h);
+        hipLaunchKernelGGL(k_ntt_table9, dim3(ceil_div(n, 256)), dim3(256), 0, s, coset_pre.p, coset_pre9.p, n);
+        hipLaunchKernelGGL(k_ntt_table9, dim3(ceil_div(n, 256)), dim3(256), 0, s, coset_post.p, coset_post9.p, n);
+    }
     ZK_HIP(hipGetLastError());
 }
 
 // ---------------------------------------------------------------------------------------------
+// Element policies of the butterfly kernels.
+//   NttWords : 8 x 32 weak form (field.cuh), carry-chain add / sub, out-of-line weak multiplier.
+//   Ntt9     : 9 x 29-bit signed limbs (field9.cuh).  The DATA keep their 2^256-Montgomery form -- only the twiddle / coset
+//              tables are stored in the 2^261 form (x * 2^256 * w * 2^261 / 2^261 = xw * 2^256) --, so HBM holds ordinary words.
+//              Invariant between butterflies: strict limbs, value in [0, 4M + eps).  A product returns [0, 1.06M) because its
+//              left operand is made non-negative first (u - v + 4M); a sum is followed by a conditional - 4M decided on the top
+//              limbs (exact up to one unit of 2^232, i.e. eps = 2^-21 M) and one carry propagation.  Everything < 5.29M = 2^256
+//              fits the 8 words of an intermediate pass as it is; the last pass of a transform stores the canonical value.
+struct NttWords {
+    using E = Fr;
+    static constexpr bool F9 = false;
+    static __device__ __forceinline__ E load(const Fr &w) { return w; }
+    static __device__ __forceinline__ Fr store(const E &x, bool) { return x; }
+    static __device__ __forceinline__ E zero() { return Fr::zero(); }
+    static __device__ __forceinline__ E mul(const E &x, const Fr &t) { return Fr::mul_wc(x, t); }
+    static __device__ __forceinline__ void dif(E &u, E &v, const Fr *t) {
+        const E s = Fr::add_w(u, v), d = Fr::sub_w(u, v);
+        u = s;
+        v = t ? Fr::mul_wc(d, *t) : d;
+    }
+    static __device__ __forceinline__ void dit(E &u, E &v, const Fr *t) {
+        const E w = t ? Fr::mul_wc(v, *t) : v;
+        const E a = Fr::add_w(u, w);
+        v = Fr::sub_w(u, w);
+        u = a;
+    }
+};
+struct Ntt9 {
+    using E = Fr9;
+    static constexpr bool F9 = true;
+    static __device__ __forceinline__ E load(const Fr &w) { return Fr9::from_words(w); }
+    static __device__ __forceinline__ E zero() { return Fr9::zero(); }
+    // x in [0, 4M + eps), strict -> words; the last pass of a transform writes the canonical value
+    static __device__ __forceinline__ Fr store(const E &x, bool last) {
+        if (last) return Fr9::to_words(x);
+        Fr r;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int lo = (32 * j) / 29, sh = 32 * j - 29 * lo;
+            uint32_t v = (uint32_t)x.l[lo] >> sh;
+            if (lo + 1 < 9) v |= (uint32_t)x.l[lo + 1] << (29 - sh);
+            r.l[j] = v;
+        }
+        return r;
+    }
+    // s - 4M when the top limbs say s > 4M, then carry propagation.  s = lazy sum of strict values; the test reads the
+    // un-normalised top limb (the lower limbs carry at most 2 units into it), so the result is < 4M + 3 * 2^232 when nothing is
+    // subtracted and < (bound of s) - 4M otherwise: eps at most doubles per stage from 2^-19.6 M, < 0.06 M after the 16 stages of
+    // a transform (a product resets it)
+    static __device__ __forceinline__ E fold(E s) {
+        const int32_t mask = (Fr9Params::M4[8] - s.l[8]) >> 31;          // all ones <=> top limb > that of 4M
+#pragma unroll
+        for (int i = 0; i < 9; i++) s.l[i] -= Fr9Params::M4[i] & mask;
+        return Fr9::norm(s);
+    }
+    // x * t, t = a table entry (words of the 2^261 form).  ONE out-of-line copy: a radix-8 group has 12 products, two groups per
+    // kernel -- expanded in place they make 150 KB of code per kernel, far beyond the instruction cache
+    // (operands and result as vectors: a struct of more than 32 bytes would travel through scratch memory, vectors use VGPRs)
+    typedef int32_t v9i __attribute__((ext_vector_type(9)));
+    typedef uint32_t v8u __attribute__((ext_vector_type(8)));
+    static __device__ __noinline__ v9i mul_v(v9i xv, v8u tv) {
+        E x;
+        Fr t;
+#pragma unroll
+        for (int i = 0; i < 9; i++) x.l[i] = xv[i];
+#pragma unroll
+        for (int i = 0; i < 8; i++) t.l[i] = tv[i];
+        const E r = Fr9::mul(x, Fr9::from_words(t));
+        v9i rv;
+#pragma unroll
+        for (int i = 0; i < 9; i++) rv[i] = r.l[i];
+        return rv;
+    }
+    static __device__ __forceinline__ E mul(const E &x, const Fr &t) {
+        v9i xv;
+        v8u tv;
+#pragma unroll
+        for (int i = 0; i < 9; i++) xv[i] = x.l[i];
+#pragma unroll
+        for (int i = 0; i < 8; i++) tv[i] = t.l[i];
+        const v9i rv = mul_v(xv, tv);
+        E r;
+#pragma unroll
+        for (int i = 0; i < 9; i++) r.l[i] = rv[i];
+        return r;
+    }
+    // (u, v) -> (u + v, (u - v) * t); t is never null here (the twiddle 1 is multiplied like any other: the product is what
+    // brings the difference back into range)
+    static __device__ __forceinline__ void dif(E &u, E &v, const Fr *t) {
+        E d;
+#pragma unroll
+        for (int i = 0; i < 9; i++) d.l[i] = u.l[i] - v.l[i] + Fr9Params::M5[i];     // u - v + 5M in (M - eps, 9M + eps): positive; limbs within (-2^29, 2^30)
+        u = fold(Fr9::add(u, v));
+        v = mul(d, *t);                                                             // [0, 1.06 M)
+    }
+    // (u, v) -> (u + v t, u - v t)
+    static __device__ __forceinline__ void dit(E &u, E &v, const Fr *t) {
+        const E w = mul(v, *t);                                                     // [0, 1.03 M)
+        E d;
+#pragma unroll
+        for (int i = 0; i < 9; i++) d.l[i] = u.l[i] - w.l[i] + Fr9Params::M2[i];     // u - w + 2M in (0.9 M, 6M + eps)
+        u = fold(Fr9::add(u, w));
+        v = fold(d);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
 // DIF pass: K stages starting at block length `len` (natural -> towards bit-reversed).
 // thread (g, b): g in [0, n >> K), b in [0, B)
-template <int K>
+template <class P, int K>
 __global__ __launch_bounds__(256) void k_ntt_dif(Fr *__restrict__ data, size_t B, int logn, int loglen,
-                                                 const Fr *__restrict__ tw, const Fr *__restrict__ postmul) {
+                                                 const Fr *__restrict__ tw, const Fr *__restrict__ postmul, int last) {
+    using E = typename P::E;
     constexpr int R = 1 << K;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t b = t % B;
@@ -96,9 +231,9 @@ __global__ __launch_bounds__(256) void k_ntt_dif(Fr *__restrict__ data, size_t B
     const size_t S = (size_t)1 << logS;
     const size_t blk = g >> logS, p = g & (S - 1);
     const size_t base = (blk << loglen) + p;
-    Fr x[R];
+    E x[R];
 #pragma unroll
-    for (int m = 0; m < R; m++) x[m] = data[(base + ((size_t)m << logS)) * B + b];
+    for (int m = 0; m < R; m++) x[m] = P::load(data[(base + ((size_t)m << logS)) * B + b]);
 #pragma unroll
     for (int st = 0; st < K; st++) {
         const int half = 1 << (K - 1 - st);          // pair distance in m units
@@ -108,25 +243,23 @@ __global__ __launch_bounds__(256) void k_ntt_dif(Fr *__restrict__ data, size_t B
         for (int m = 0; m < R; m++) {
             if ((m / half) & 1) continue;
             const size_t j = p + ((size_t)(m % half) << logS);
-            Fr u = x[m], v = x[m + half];
-            x[m] = Fr::add_w(u, v);
-            Fr d = Fr::sub_w(u, v);
-            x[m + half] = (j == 0) ? d : Fr::mul_wc(d, tw[j << twshift]);
+            P::dif(x[m], x[m + half], (j == 0 && !P::F9) ? nullptr : &tw[j << twshift]);
         }
     }
 #pragma unroll
     for (int m = 0; m < R; m++) {
         const size_t idx = base + ((size_t)m << logS);
-        Fr v = x[m];
-        if (postmul) v = Fr::mul_wc(v, postmul[idx]);
-        data[idx * B + b] = v;
+        E v = x[m];
+        if (postmul) v = P::mul(v, postmul[idx]);
+        data[idx * B + b] = P::store(v, last != 0);
     }
 }
 
 // DIT pass: K stages starting at half-distance S = 2^logS (bit-reversed -> natural).
-template <int K>
+template <class P, int K>
 __global__ __launch_bounds__(256) void k_ntt_dit(Fr *__restrict__ data, size_t B, int logn, int logS,
-                                                 const Fr *__restrict__ tw, const Fr *__restrict__ premul) {
+                                                 const Fr *__restrict__ tw, const Fr *__restrict__ premul, int last) {
+    using E = typename P::E;
     constexpr int R = 1 << K;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t b = t % B;
@@ -136,12 +269,12 @@ __global__ __launch_bounds__(256) void k_ntt_dit(Fr *__restrict__ data, size_t B
     const size_t S = (size_t)1 << logS;
     const size_t blk = g >> logS, p = g & (S - 1);
     const size_t base = (blk << (logS + K)) + p;
-    Fr x[R];
+    E x[R];
 #pragma unroll
     for (int m = 0; m < R; m++) {
         const size_t idx = base + ((size_t)m << logS);
-        Fr v = data[idx * B + b];
-        if (premul) v = Fr::mul_wc(v, premul[idx]);
+        E v = P::load(data[idx * B + b]);
+        if (premul) v = P::mul(v, premul[idx]);
         x[m] = v;
     }
 #pragma unroll
@@ -153,14 +286,11 @@ __global__ __launch_bounds__(256) void k_ntt_dit(Fr *__restrict__ data, size_t B
         for (int m = 0; m < R; m++) {
             if ((m >> st) & 1) continue;
             const size_t j = p + ((size_t)(m & (h - 1)) << logS);
-            Fr u = x[m];
-            Fr v = (j == 0) ? x[m + h] : Fr::mul_wc(x[m + h], tw[j << twshift]);
-            x[m] = Fr::add_w(u, v);
-            x[m + h] = Fr::sub_w(u, v);
+            P::dit(x[m], x[m + h], (j == 0 && !P::F9) ? nullptr : &tw[j << twshift]);
         }
     }
 #pragma unroll
-    for (int m = 0; m < R; m++) data[(base + ((size_t)m << logS)) * B + b] = x[m];
+    for (int m = 0; m < R; m++) data[(base + ((size_t)m << logS)) * B + b] = P::store(x[m], last != 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -173,26 +303,27 @@ __global__ __launch_bounds__(256) void k_ntt_dit(Fr *__restrict__ data, size_t B
 #ifndef ZK_NTT_TILE
 #define ZK_NTT_TILE 2048
 #endif
-template <int K1, int K2>
+template <class P, int K1, int K2>
 struct LdsTile {
     static constexpr int K = K1 + K2;
     static constexpr int E = 1 << K;               // elements per tile
     static constexpr int TOTAL = ZK_NTT_TILE;
     static constexpr int TI = TOTAL / E;           // instances per tile
     static constexpr int THREADS = TOTAL / 8;
-    static constexpr int LDS_BYTES = TOTAL * 32;
+    static constexpr int LDS_BYTES = TOTAL * (int)sizeof(typename P::E);      // 64 KiB of words / 72 KiB of 9-limb elements
     static_assert(E * TI == TOTAL && TI >= 1, "tile shape");
 };
 
 // DIF: stages loglen .. loglen-K+1 (block lengths len, len/2, ...).  Element e of the tile sits at
 // pos = blk*len + p + e*S with S = len >> K.
-template <int K1, int K2>
+template <class P, int K1, int K2>
 __global__ __launch_bounds__(ZK_NTT_TILE / 8) void k_ntt_dif_lds(Fr *__restrict__ data, size_t B, int logn, int loglen, const Fr *__restrict__ tw,
-                                                     const Fr *__restrict__ postmul) {
-    using T = LdsTile<K1, K2>;
+                                                     const Fr *__restrict__ postmul, int last) {
+    using T = LdsTile<P, K1, K2>;
+    using El = typename P::E;
     constexpr int K = T::K, E = T::E, TI = T::TI, R1 = 1 << K1, R2 = 1 << K2, NT = T::THREADS;
     extern __shared__ uint4 lds_raw[];
-    Fr *lds = (Fr *)lds_raw;                       // [E][TI]
+    El *lds = (El *)lds_raw;                       // [E][TI]
     const int tid = threadIdx.x;
     const int bl = tid % TI;                       // instance within the tile
     // the instance tiles of one element tile are neighbours in the grid: workgroups resident at the same time then read
@@ -209,11 +340,11 @@ __global__ __launch_bounds__(ZK_NTT_TILE / 8) void k_ntt_dif_lds(Fr *__restrict_
     {
         constexpr int STR = E / R1;                // element stride inside the thread's set
         for (int q = tid / TI; q < STR; q += NT / TI) {
-            Fr x[R1];
+            El x[R1];
 #pragma unroll
             for (int m = 0; m < R1; m++) {
                 const size_t e = (size_t)q + (size_t)STR * m;
-                x[m] = active ? data[(base + (e << logS)) * B + b] : Fr::zero();
+                x[m] = active ? P::load(data[(base + (e << logS)) * B + b]) : P::zero();
             }
 #pragma unroll
             for (int st = 0; st < K1; st++) {
@@ -223,10 +354,7 @@ __global__ __launch_bounds__(ZK_NTT_TILE / 8) void k_ntt_dif_lds(Fr *__restrict_
                 for (int m = 0; m < R1; m++) {
                     if ((m / half) & 1) continue;
                     const size_t j = p + (((size_t)q + (size_t)STR * (m % half)) << logS);
-                    Fr u = x[m], v = x[m + half];
-                    x[m] = Fr::add_w(u, v);
-                    Fr d = Fr::sub_w(u, v);
-                    x[m + half] = (j == 0) ? d : Fr::mul_wc(d, tw[j << twshift]);
+                    P::dif(x[m], x[m + half], (j == 0 && !P::F9) ? nullptr : &tw[j << twshift]);
                 }
             }
 #pragma unroll
@@ -237,7 +365,7 @@ __global__ __launch_bounds__(ZK_NTT_TILE / 8) void k_ntt_dif_lds(Fr *__restrict_
     // ---- stage group B: thread holds e = q2 * R2 + m, distances R2/2 .. 1
     {
         for (int q2 = tid / TI; q2 < E / R2; q2 += NT / TI) {
-            Fr x[R2];
+            El x[R2];
 #pragma unroll
             for (int m = 0; m < R2; m++) x[m] = lds[((size_t)q2 * R2 + m) * TI + bl];
 #pragma unroll
@@ -248,19 +376,16 @@ __global__ __launch_bounds__(ZK_NTT_TILE / 8) void k_ntt_dif_lds(Fr *__restrict_
                 for (int m = 0; m < R2; m++) {
                     if ((m / half) & 1) continue;
                     const size_t j = p + ((size_t)(m % half) << logS);
-                    Fr u = x[m], v = x[m + half];
-                    x[m] = Fr::add_w(u, v);
-                    Fr d = Fr::sub_w(u, v);
-                    x[m + half] = (j == 0) ? d : Fr::mul_wc(d, tw[j << twshift]);
+                    P::dif(x[m], x[m + half], (j == 0 && !P::F9) ? nullptr : &tw[j << twshift]);
                 }
             }
             if (active) {
 #pragma unroll
                 for (int m = 0; m < R2; m++) {
                     const size_t idx = base + (((size_t)q2 * R2 + m) << logS);
-                    Fr v = x[m];
-                    if (postmul) v = Fr::mul_wc(v, postmul[idx]);
-                    data[idx * B + b] = v;
+                    El v = x[m];
+                    if (postmul) v = P::mul(v, postmul[idx]);
+                    data[idx * B + b] = P::store(v, last != 0);
                 }
             }
         }
@@ -268,13 +393,14 @@ __global__ __launch_bounds__(ZK_NTT_TILE / 8) void k_ntt_dif_lds(Fr *__restrict_
 }
 
 // DIT: stages with half-distances S, 2S, ... (S = 2^logS), tile element e at pos = blk*(S<<K) + p + e*S.
-template <int K1, int K2>
+template <class P, int K1, int K2>
 __global__ __launch_bounds__(ZK_NTT_TILE / 8) void k_ntt_dit_lds(Fr *__restrict__ data, size_t B, int logn, int logS, const Fr *__restrict__ tw,
-                                                     const Fr *__restrict__ premul) {
-    using T = LdsTile<K1, K2>;
+                                                     const Fr *__restrict__ premul, int last) {
+    using T = LdsTile<P, K1, K2>;
+    using El = typename P::E;
     constexpr int K = T::K, E = T::E, TI = T::TI, R1 = 1 << K1, R2 = 1 << K2, NT = T::THREADS;
     extern __shared__ uint4 lds_raw[];
-    Fr *lds = (Fr *)lds_raw;
+    El *lds = (El *)lds_raw;
     const int tid = threadIdx.x;
     const int bl = tid % TI;
     const size_t b = (size_t)blockIdx.x * TI + bl;
@@ -286,12 +412,12 @@ __global__ __launch_bounds__(ZK_NTT_TILE / 8) void k_ntt_dit_lds(Fr *__restrict_
     // ---- group A: consecutive elements e = q * R1 + m, distances 1 .. R1/2
     {
         for (int q = tid / TI; q < E / R1; q += NT / TI) {
-            Fr x[R1];
+            El x[R1];
 #pragma unroll
             for (int m = 0; m < R1; m++) {
                 const size_t idx = base + (((size_t)q * R1 + m) << logS);
-                Fr v = active ? data[idx * B + b] : Fr::zero();
-                if (premul) v = Fr::mul_wc(v, premul[idx]);
+                El v = active ? P::load(data[idx * B + b]) : P::zero();
+                if (premul) v = P::mul(v, premul[idx]);
                 x[m] = v;
             }
 #pragma unroll
@@ -302,10 +428,7 @@ __global__ __launch_bounds__(ZK_NTT_TILE / 8) void k_ntt_dit_lds(Fr *__restrict_
                 for (int m = 0; m < R1; m++) {
                     if ((m >> st) & 1) continue;
                     const size_t j = p + ((size_t)(m & (h - 1)) << logS);
-                    Fr u = x[m];
-                    Fr v = (j == 0) ? x[m + h] : Fr::mul_wc(x[m + h], tw[j << twshift]);
-                    x[m] = Fr::add_w(u, v);
-                    x[m + h] = Fr::sub_w(u, v);
+                    P::dit(x[m], x[m + h], (j == 0 && !P::F9) ? nullptr : &tw[j << twshift]);
                 }
             }
 #pragma unroll
@@ -316,7 +439,7 @@ __global__ __launch_bounds__(ZK_NTT_TILE / 8) void k_ntt_dit_lds(Fr *__restrict_
     // ---- group B: strided elements e = q2 + R1 * m, distances R1 .. E/2
     {
         for (int q2 = tid / TI; q2 < R1; q2 += NT / TI) {
-            Fr x[R2];
+            El x[R2];
 #pragma unroll
             for (int m = 0; m < R2; m++) x[m] = lds[((size_t)q2 + (size_t)R1 * m) * TI + bl];
 #pragma unroll
@@ -327,88 +450,105 @@ __global__ __launch_bounds__(ZK_NTT_TILE / 8) void k_ntt_dit_lds(Fr *__restrict_
                 for (int m = 0; m < R2; m++) {
                     if ((m >> st) & 1) continue;
                     const size_t j = p + (((size_t)q2 + (size_t)R1 * (m & (h - 1))) << logS);
-                    Fr u = x[m];
-                    Fr v = (j == 0) ? x[m + h] : Fr::mul_wc(x[m + h], tw[j << twshift]);
-                    x[m] = Fr::add_w(u, v);
-                    x[m + h] = Fr::sub_w(u, v);
+                    P::dit(x[m], x[m + h], (j == 0 && !P::F9) ? nullptr : &tw[j << twshift]);
                 }
             }
             if (active) {
 #pragma unroll
-                for (int m = 0; m < R2; m++) data[(base + (((size_t)q2 + (size_t)R1 * m) << logS)) * B + b] = x[m];
+                for (int m = 0; m < R2; m++) data[(base + (((size_t)q2 + (size_t)R1 * m) << logS)) * B + b] = P::store(x[m], last != 0);
             }
         }
     }
 }
 
-template <int K1, int K2>
-static void launch_dif_lds(Fr *data, size_t B, int logn, int loglen, const Fr *tw, const Fr *postmul, hipStream_t s) {
-    using T = LdsTile<K1, K2>;
+template <class P, int K1, int K2>
+static void launch_dif_lds(Fr *data, size_t B, int logn, int loglen, const Fr *tw, const Fr *postmul, bool last, hipStream_t s) {
+    using T = LdsTile<P, K1, K2>;
     static PerDeviceOnce attr;
-    attr.run([] { ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_dif_lds<K1, K2>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES)); });
+    attr.run([] { ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_dif_lds<P, K1, K2>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES)); });
     dim3 grid(ceil_div(B, T::TI), (unsigned)(((size_t)1 << logn) >> T::K));
-    hipLaunchKernelGGL((k_ntt_dif_lds<K1, K2>), grid, dim3(T::THREADS), T::LDS_BYTES, s, data, B, logn, loglen, tw, postmul);
+    hipLaunchKernelGGL((k_ntt_dif_lds<P, K1, K2>), grid, dim3(T::THREADS), T::LDS_BYTES, s, data, B, logn, loglen, tw, postmul, (int)last);
 }
-template <int K1, int K2>
-static void launch_dit_lds(Fr *data, size_t B, int logn, int logS, const Fr *tw, const Fr *premul, hipStream_t s) {
-    using T = LdsTile<K1, K2>;
+template <class P, int K1, int K2>
+static void launch_dit_lds(Fr *data, size_t B, int logn, int logS, const Fr *tw, const Fr *premul, bool last, hipStream_t s) {
+    using T = LdsTile<P, K1, K2>;
     static PerDeviceOnce attr;
-    attr.run([] { ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_dit_lds<K1, K2>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES)); });
+    attr.run([] { ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_dit_lds<P, K1, K2>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES)); });
     dim3 grid(ceil_div(B, T::TI), (unsigned)(((size_t)1 << logn) >> T::K));
-    hipLaunchKernelGGL((k_ntt_dit_lds<K1, K2>), grid, dim3(T::THREADS), T::LDS_BYTES, s, data, B, logn, logS, tw, premul);
+    hipLaunchKernelGGL((k_ntt_dit_lds<P, K1, K2>), grid, dim3(T::THREADS), T::LDS_BYTES, s, data, B, logn, logS, tw, premul, (int)last);
 }
 
-template <int K>
-static void launch_dif(Fr *data, size_t B, int logn, int loglen, const Fr *tw, const Fr *postmul, hipStream_t s) {
+template <class P, int K>
+static void launch_dif(Fr *data, size_t B, int logn, int loglen, const Fr *tw, const Fr *postmul, bool last, hipStream_t s) {
     size_t threads = (((size_t)1 << logn) >> K) * B;
-    hipLaunchKernelGGL(k_ntt_dif<K>, dim3(ceil_div(threads, 256)), dim3(256), 0, s, data, B, logn, loglen, tw, postmul);
+    hipLaunchKernelGGL((k_ntt_dif<P, K>), dim3(ceil_div(threads, 256)), dim3(256), 0, s, data, B, logn, loglen, tw, postmul, (int)last);
 }
-template <int K>
-static void launch_dit(Fr *data, size_t B, int logn, int logS, const Fr *tw, const Fr *premul, hipStream_t s) {
+template <class P, int K>
+static void launch_dit(Fr *data, size_t B, int logn, int logS, const Fr *tw, const Fr *premul, bool last, hipStream_t s) {
     size_t threads = (((size_t)1 << logn) >> K) * B;
-    hipLaunchKernelGGL(k_ntt_dit<K>, dim3(ceil_div(threads, 256)), dim3(256), 0, s, data, B, logn, logS, tw, premul);
+    hipLaunchKernelGGL((k_ntt_dit<P, K>), dim3(ceil_div(threads, 256)), dim3(256), 0, s, data, B, logn, logS, tw, premul, (int)last);
 }
-
 
 // stage schedule: as many 6-stage LDS passes as possible, then one 5- or 4-stage LDS pass, then register passes
 static int next_pass(int rem) {
     if (rem >= 6) return 6;
     return rem;     // 5, 4 -> LDS (3,2)/(2,2); 3, 2, 1 -> register kernels
 }
-void NttDomain::dif(Fr *data, size_t B, bool inverse, const Fr *postmul, hipStream_t s) const {
-    const Fr *tw = inverse ? tw_inv.p : tw_fwd.p;
+template <class P>
+static void dif_passes(int logn, Fr *data, size_t B, const Fr *tw, const Fr *postmul, hipStream_t s) {
     int loglen = logn;
     while (loglen > 0) {
         const int k = next_pass(loglen);
-        const Fr *pm = (loglen - k == 0) ? postmul : nullptr;
+        const bool last = loglen - k == 0;
+        const Fr *pm = last ? postmul : nullptr;
         switch (k) {
-            case 6: launch_dif_lds<3, 3>(data, B, logn, loglen, tw, pm, s); break;
-            case 5: launch_dif_lds<3, 2>(data, B, logn, loglen, tw, pm, s); break;
-            case 4: launch_dif_lds<2, 2>(data, B, logn, loglen, tw, pm, s); break;
-            case 3: launch_dif<3>(data, B, logn, loglen, tw, pm, s); break;
-            case 2: launch_dif<2>(data, B, logn, loglen, tw, pm, s); break;
-            default: launch_dif<1>(data, B, logn, loglen, tw, pm, s); break;
+            case 6: launch_dif_lds<P, 3, 3>(data, B, logn, loglen, tw, pm, last, s); break;
+            case 5: launch_dif_lds<P, 3, 2>(data, B, logn, loglen, tw, pm, last, s); break;
+            case 4: launch_dif_lds<P, 2, 2>(data, B, logn, loglen, tw, pm, last, s); break;
+            case 3: launch_dif<P, 3>(data, B, logn, loglen, tw, pm, last, s); break;
+            case 2: launch_dif<P, 2>(data, B, logn, loglen, tw, pm, last, s); break;
+            default: launch_dif<P, 1>(data, B, logn, loglen, tw, pm, last, s); break;
         }
         loglen -= k;
     }
-    ZK_HIP(hipGetLastError());
 }
-void NttDomain::dit(Fr *data, size_t B, bool inverse, const Fr *premul, hipStream_t s) const {
-    const Fr *tw = inverse ? tw_inv.p : tw_fwd.p;
+template <class P>
+static void dit_passes(int logn, Fr *data, size_t B, const Fr *tw, const Fr *premul, hipStream_t s) {
     int logS = 0;
     while (logS < logn) {
         const int k = next_pass(logn - logS);
         const Fr *pm = (logS == 0) ? premul : nullptr;
+        const bool last = logS + k == logn;
         switch (k) {
-            case 6: launch_dit_lds<3, 3>(data, B, logn, logS, tw, pm, s); break;
-            case 5: launch_dit_lds<3, 2>(data, B, logn, logS, tw, pm, s); break;
-            case 4: launch_dit_lds<2, 2>(data, B, logn, logS, tw, pm, s); break;
-            case 3: launch_dit<3>(data, B, logn, logS, tw, pm, s); break;
-            case 2: launch_dit<2>(data, B, logn, logS, tw, pm, s); break;
-            default: launch_dit<1>(data, B, logn, logS, tw, pm, s); break;
+            case 6: launch_dit_lds<P, 3, 3>(data, B, logn, logS, tw, pm, last, s); break;
+            case 5: launch_dit_lds<P, 3, 2>(data, B, logn, logS, tw, pm, last, s); break;
+            case 4: launch_dit_lds<P, 2, 2>(data, B, logn, logS, tw, pm, last, s); break;
+            case 3: launch_dit<P, 3>(data, B, logn, logS, tw, pm, last, s); break;
+            case 2: launch_dit<P, 2>(data, B, logn, logS, tw, pm, last, s); break;
+            default: launch_dit<P, 1>(data, B, logn, logS, tw, pm, last, s); break;
         }
         logS += k;
     }
+}
+// the multiplier tables of the 9-limb butterflies: same values in the 2^261-Montgomery form
+const Fr *NttDomain::table9(const Fr *t) const {
+    if (t == nullptr) return nullptr;
+    if (t == tw_fwd.p) return tw_fwd9.p;
+    if (t == tw_inv.p) return tw_inv9.p;
+    if (t == coset_pre.p) return coset_pre9.p;
+    if (t == coset_post.p) return coset_post9.p;
+    throw ZkError("ntt: multiplier table without a 9-limb copy");
+}
+void NttDomain::dif(Fr *data, size_t B, bool inverse, const Fr *postmul, hipStream_t s) const {
+    const Fr *tw = inverse ? tw_inv.p : tw_fwd.p;
+    if (f9) dif_passes<Ntt9>(logn, data, B, table9(tw), table9(postmul), s);
+    else dif_passes<NttWords>(logn, data, B, tw, postmul, s);
+    ZK_HIP(hipGetLastError());
+}
+void NttDomain::dit(Fr *data, size_t B, bool inverse, const Fr *premul, hipStream_t s) const {
+    const Fr *tw = inverse ? tw_inv.p : tw_fwd.p;
+    if (f9) dit_passes<Ntt9>(logn, data, B, table9(tw), table9(premul), s);
+    else dit_passes<NttWords>(logn, data, B, tw, premul, s);
     ZK_HIP(hipGetLastError());
 }
 

@@ -6,6 +6,7 @@
 #include <string.h>
 #include <vector>
 #include "kernels.h"
+#include "curve9.cuh"
 
 using namespace zk;
 void fp_to_mont_dev(void *p, size_t count, hipStream_t s);
@@ -222,6 +223,12 @@ extern "C" long zkp_fold_output_matrix(long nzc, const uint8_t *zc, long nk, con
 // -------- micro-benchmarks: raw field-multiplication / point-addition throughput on the device
 namespace zk {
 template <class F>
+struct Nine9;
+template <>
+struct Nine9<Fp> { using F9 = Fp9; using X9 = G1X9; };
+template <>
+struct Nine9<Fp2> { using F9 = Fp29; using X9 = G2X9; };
+template <class F>
 __global__ __launch_bounds__(256) void k_bench_mul(F *x, int iters) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     F a = x[i], b = x[i + 1];
@@ -253,6 +260,39 @@ __global__ __launch_bounds__(256) void k_bench_mad(uint32_t *x, int iters) {
         }
     }
     x[i] = (uint32_t)(acc0 ^ acc1 ^ acc2 ^ acc3) ^ (uint32_t)((acc0 ^ acc1 ^ acc2 ^ acc3) >> 32) ^ c0 ^ c1 ^ c2 ^ c3;
+}
+// the 9-limb field of the bucket kernels (field9.cuh): product chain, G1 / G2 mixed-addition chains
+__global__ __launch_bounds__(256) void k_bench_mul9(Fp *x, int iters) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    Fp9 a = Fp9::from_words(x[i]), b = Fp9::from_words(x[i + 1]);
+    for (int k = 0; k < iters; k++) { a = Fp9::mul(a, b); b = Fp9::mul(b, a); }
+    x[i] = Fp9::to_words(Fp9::norm(Fp9::add(a, b)));
+}
+template <class F>
+__global__ __launch_bounds__(64, sizeof(F) == 64 ? 2 : 4) void k_bench_madd9(typename Nine9<F>::X9 *acc, const Affine<F> *pts, int iters) {
+    using F9 = typename Nine9<F>::F9;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    typename Nine9<F>::X9 a = acc[i];
+    for (int k = 0; k < iters; k++) {
+        const Affine<F> p = pts[(i * 7 + k) & 1023];
+        a.madd(F9::from_words(p.x), F9::cneg(F9::from_words(p.y), (k & 4) ? -1 : 0));
+    }
+    acc[i] = a;
+}
+__global__ __launch_bounds__(256) void k_bench_mad_i64(uint32_t *x, int iters) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int32_t a = (int32_t)x[i], b = (int32_t)(x[i] * 2654435761u + 1u);
+    int64_t acc0 = a, acc1 = b, acc2 = a ^ b, acc3 = a + b;
+    for (int k = 0; k < iters; k++) {
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc0) : "v"(a), "v"(b) : "vcc");
+            asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc1) : "v"(a), "v"(b) : "vcc");
+            asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc2) : "v"(a), "v"(b) : "vcc");
+            asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc3) : "v"(a), "v"(b) : "vcc");
+        }
+    }
+    x[i] = (uint32_t)(acc0 ^ acc1 ^ acc2 ^ acc3) ^ (uint32_t)((acc0 ^ acc1 ^ acc2 ^ acc3) >> 32);
 }
 // iters dependent inversions per thread: GCD = false -> Fermat ladder (inv), true -> binary GCD (inv_gcd)
 template <class F, bool GCD>
@@ -301,7 +341,8 @@ extern "C" int zkp_field_inv(int field, long n, const uint8_t *in, uint8_t *out)
     ZKP_CATCH(-1)
 }
 // returns milliseconds for `threads` threads x `iters` iterations; kind 0: 2 Fp mul / iter, 1: G1 madd, 2: G2 madd, 3: Fp Fermat inversion,
-// 4: Fp binary-GCD inversion, 5: 64 v_mad_u64_u32 per iteration, 6: 64 v_mad_u64_u32 + v_addc_co_u32 pairs per iteration
+// 4: Fp binary-GCD inversion, 5: 64 v_mad_u64_u32 per iteration, 6: 64 v_mad_u64_u32 + v_addc_co_u32 pairs per iteration,
+// 7: 2 products of the 9-limb field / iter, 8: G1 mixed addition on the 9-limb field, 9: G2 on its tower, 10: 64 v_mad_i64_i32 per iteration
 extern "C" double zkp_microbench(int kind, long threads, int iters) {
     ZKP_TRY
     size_t T = (size_t)threads;
@@ -323,6 +364,48 @@ extern "C" double zkp_microbench(int kind, long threads, int iters) {
         ZK_HIP(hipEventRecord(e0, 0));
         if (kind == 5) hipLaunchKernelGGL((k_bench_mad<false>), dim3(T / 256), dim3(256), 0, 0, x.p, iters);
         else hipLaunchKernelGGL((k_bench_mad<true>), dim3(T / 256), dim3(256), 0, 0, x.p, iters);
+        ZK_HIP(hipEventRecord(e1, 0));
+    } else if (kind == 7) {
+        DevBuf<Fp> x(T + 1);
+        std::vector<Fp> h(T + 1);
+        for (size_t i = 0; i <= T; i++) for (int k = 0; k < 8; k++) h[i].l[k] = (uint32_t)(i * 2654435761u + k * 40503u) & (k == 7 ? 0x0fffffffu : 0xffffffffu);
+        x.upload(h.data(), T + 1);
+        hipLaunchKernelGGL(k_bench_mul9, dim3(T / 256), dim3(256), 0, 0, x.p, 4);
+        ZK_HIP(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(k_bench_mul9, dim3(T / 256), dim3(256), 0, 0, x.p, iters);
+        ZK_HIP(hipEventRecord(e1, 0));
+    } else if (kind == 10) {
+        DevBuf<uint32_t> x(T);
+        ZK_HIP(hipMemset(x.p, 0x5a, T * 4));
+        ZK_HIP(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(k_bench_mad_i64, dim3(T / 256), dim3(256), 0, 0, x.p, iters);
+        ZK_HIP(hipEventRecord(e1, 0));
+    } else if (kind == 8) {
+        DevBuf<G1X9> acc(T); acc.zero();
+        // 1024 distinct points k * (1, 2), in the 2^261-Montgomery form the 9-limb kernels read
+        std::vector<G1Affine> hp(1024);
+        G1Affine g{Fp::one(), Fp::one() + Fp::one()};
+        G1XYZZ run = G1XYZZ::inf();
+        Fp k32;
+        for (int j = 0; j < 8; j++) k32.l[j] = Fp9Params::SCALE32[j];
+        for (auto &p : hp) { run.madd(g); const G1Affine a = run.to_affine(); p.x = a.x * k32; p.y = a.y * k32; }
+        DevBuf<G1Affine> pts(1024); pts.upload(hp.data(), 1024);
+        hipLaunchKernelGGL(k_bench_madd9<Fp>, dim3(T / 64), dim3(64), 0, 0, acc.p, pts.p, 2);
+        ZK_HIP(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(k_bench_madd9<Fp>, dim3(T / 64), dim3(64), 0, 0, acc.p, pts.p, iters);
+        ZK_HIP(hipEventRecord(e1, 0));
+    } else if (kind == 9) {
+        DevBuf<G2X9> acc(T); acc.zero();
+        std::vector<G2Affine> hp(1024);      // arbitrary coordinate pairs: the formulas do not care, the timing neither
+        for (size_t i = 0; i < hp.size(); i++) {
+            Fp v = Fp::one();
+            for (size_t k = 0; k < (i & 15) + 1; k++) v = v + v + Fp::one();
+            hp[i] = G2Affine{Fp2{v, v + Fp::one()}, Fp2{v + v, v * v}};
+        }
+        DevBuf<G2Affine> pts(1024); pts.upload(hp.data(), 1024);
+        hipLaunchKernelGGL(k_bench_madd9<Fp2>, dim3(T / 64), dim3(64), 0, 0, acc.p, pts.p, 2);
+        ZK_HIP(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(k_bench_madd9<Fp2>, dim3(T / 64), dim3(64), 0, 0, acc.p, pts.p, iters);
         ZK_HIP(hipEventRecord(e1, 0));
     } else if (kind == 3 || kind == 4) {
         DevBuf<Fp> x(T);
