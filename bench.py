@@ -140,10 +140,11 @@ def roofline_objects(alg, B, mean, value_per_gpu, manifest):
             "frac_of_mixed_add_peak": (Z_TERMS[alg] * nwin * B / (zdur_ms * 1e-3) / mb["g1_mixed_add_per_s"]) if mb.get("g1_mixed_add_per_s") else None,
             "frac_of_isa_ceiling": (Z_TERMS[alg] * nwin * B / (zdur_ms * 1e-3) / mb["g1_mixed_add_isa_ceiling_per_s"]) if mb.get("g1_mixed_add_isa_ceiling_per_s") else None,
             "microbench_source": mb.get("file"),
-            "note": "integer-ALU bound (v_mad_u64_u32 + carry chains), not HBM bound: every term costs W=16 curve additions (one per signed 16-bit window, "
-                    "window multiples precomputed); launch_ms = HIP events around the accumulation launches of the quotient MSM on the prover's stream; "
-                    "mixed_add_peak = back-to-back canonical-form additions (scripts/gpu_microbench.py; the kernel runs the weak-form variant, hence frac > 1 is possible); "
-                    "isa ceiling = measured v_mad_u64_u32 + v_addc_co_u32 pair rate / 1280 pairs per addition; MFMA not applicable"}
+            "note": "integer-ALU bound (v_mad_i64_i32 column sums of the 9 x 29-bit field, csrc/field9.cuh), not HBM bound: every term costs W=16 curve additions "
+                    "(one per signed 16-bit window, window multiples precomputed); launch_ms = HIP events around the accumulation launches of the quotient MSM on the "
+                    "prover's stream; mixed_add_peak = back-to-back mixed additions of the same field with every lane busy (scripts/gpu_microbench.py); "
+                    "isa ceiling = measured v_mad_i64_i32 issue rate / 1467 multiply-adds per addition (the shifts, masks and carry-free additions around them "
+                    "are not counted); MFMA not applicable"}
     n_dom = 1 << (16 if alg == 0 else 17)
     ntt_model = 7 * n_dom * 32 * 2 * B
     ntt_moved = manifest.get("ntt_round_trips", 3) * 4 * n_dom * 32 * 2 * B
