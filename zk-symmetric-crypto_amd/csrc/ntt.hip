@@ -93,7 +93,9 @@ void NttDomain::init(int logn_, hipStream_t s) {
     // multiply-adds against 256 multiply-add / carry instructions) the additions give back -- a sum has to be brought back under 4M
     // and re-normalised (44 instructions against 32), the table entry re-limbed (17), and the tile holds 2 wavefronts per SIMD, where
     // the single dependent accumulator chain of a lone product is not hidden.  The bucket kernels (msm.hip), which are products
-    // almost only, gain 25 % from the same field.
+    // almost only, gain 25 % from the same field.  (Also tried: the weak 8 x 32 additions around the 9-limb product, re-limbing both
+    // operands and packing the result -- 23.5 vs 23.3 ms, dropped.  ZKPROVE_NTT_DIAG=2 runs the passes without any arithmetic: 13.8 ms of
+    // the 23.3 are loads, LDS exchange and stores at 3.7 TB/s, hidden under the butterflies.)
     static const bool want9 = [] { const char *e = getenv("ZKPROVE_NTT_F9"); return e && e[0] == '1'; }();
     f9 = want9;
     if (f9) {
@@ -134,6 +136,23 @@ struct NttWords {
         v = Fr::sub_w(u, w);
         u = a;
     }
+};
+// timing diagnostics (ZKPROVE_NTT_DIAG, results are WRONG): 1 = butterflies without the product, 2 = without anything (loads,
+// LDS exchange and stores only) -- what the passes cost apart from the arithmetic
+template <int LEVEL>
+struct NttDiag {
+    using E = Fr;
+    static constexpr bool F9 = false;
+    static __device__ __forceinline__ E load(const Fr &w) { return w; }
+    static __device__ __forceinline__ Fr store(const E &x, bool) { return x; }
+    static __device__ __forceinline__ E zero() { return Fr::zero(); }
+    static __device__ __forceinline__ E mul(const E &x, const Fr &t) { E r = x; r.l[0] ^= t.l[0]; return r; }
+    static __device__ __forceinline__ void dif(E &u, E &v, const Fr *t) {
+        if (LEVEL == 1) { const E s = Fr::add_w(u, v), d = Fr::sub_w(u, v); u = s; v = d; }
+        if (t) v.l[0] ^= t->l[0];
+        if (LEVEL == 2) { const uint32_t x = u.l[1]; u.l[1] = v.l[1]; v.l[1] = x; }
+    }
+    static __device__ __forceinline__ void dit(E &u, E &v, const Fr *t) { dif(u, v, t); }
 };
 struct Ntt9 {
     using E = Fr9;
@@ -541,13 +560,19 @@ const Fr *NttDomain::table9(const Fr *t) const {
 }
 void NttDomain::dif(Fr *data, size_t B, bool inverse, const Fr *postmul, hipStream_t s) const {
     const Fr *tw = inverse ? tw_inv.p : tw_fwd.p;
-    if (f9) dif_passes<Ntt9>(logn, data, B, table9(tw), table9(postmul), s);
+    static const int diag = [] { const char *e = getenv("ZKPROVE_NTT_DIAG"); return e ? atoi(e) : 0; }();
+    if (diag == 1) dif_passes<NttDiag<1>>(logn, data, B, tw, postmul, s);
+    else if (diag == 2) dif_passes<NttDiag<2>>(logn, data, B, tw, postmul, s);
+    else if (f9) dif_passes<Ntt9>(logn, data, B, table9(tw), table9(postmul), s);
     else dif_passes<NttWords>(logn, data, B, tw, postmul, s);
     ZK_HIP(hipGetLastError());
 }
 void NttDomain::dit(Fr *data, size_t B, bool inverse, const Fr *premul, hipStream_t s) const {
     const Fr *tw = inverse ? tw_inv.p : tw_fwd.p;
-    if (f9) dit_passes<Ntt9>(logn, data, B, table9(tw), table9(premul), s);
+    static const int diag = [] { const char *e = getenv("ZKPROVE_NTT_DIAG"); return e ? atoi(e) : 0; }();
+    if (diag == 1) dit_passes<NttDiag<1>>(logn, data, B, tw, premul, s);
+    else if (diag == 2) dit_passes<NttDiag<2>>(logn, data, B, tw, premul, s);
+    else if (f9) dit_passes<Ntt9>(logn, data, B, table9(tw), table9(premul), s);
     else dit_passes<NttWords>(logn, data, B, tw, premul, s);
     ZK_HIP(hipGetLastError());
 }
