@@ -322,6 +322,9 @@ __global__ __launch_bounds__(256) void k_ntt_dit(Fr *__restrict__ data, size_t B
 #ifndef ZK_NTT_TILE
 #define ZK_NTT_TILE 2048
 #endif
+#ifndef ZK_NTT_TPW
+#define ZK_NTT_TPW 4                                // tiles per workgroup of the pipelined kernels
+#endif
 template <class P, int K1, int K2>
 struct LdsTile {
     static constexpr int K = K1 + K2;
@@ -480,12 +483,181 @@ __global__ __launch_bounds__(ZK_NTT_TILE / 8) void k_ntt_dit_lds(Fr *__restrict_
     }
 }
 
+// Software-pipelined forms of the two kernels above: a workgroup walks TPW consecutive tiles and requests the NEXT tile's
+// elements from HBM before it runs stage group B of the current one, so the loads fly under 12 butterflies instead of in front of
+// them (two resident workgroups per CU are not enough to hide a tile load: the SQ counters show the VALU 69 % busy in the plain
+// kernels, and ZKPROVE_NTT_DIAG=2 that the passes cost 13.8 of 23.3 ms without any arithmetic).  Requires one group-A element set
+// per thread (E / R1 == THREADS / TI: the (3,3) and (3,2) shapes).
+template <class P, int K1, int K2, int TPW>
+__global__ __launch_bounds__(ZK_NTT_TILE / 8) void k_ntt_dif_lds_pipe(Fr *__restrict__ data, size_t B, int logn, int loglen, const Fr *__restrict__ tw,
+                                                          const Fr *__restrict__ postmul, int last) {
+    using T = LdsTile<P, K1, K2>;
+    using El = typename P::E;
+    constexpr int K = T::K, E = T::E, TI = T::TI, R1 = 1 << K1, R2 = 1 << K2, NT = T::THREADS, STR = E / R1;
+    static_assert(STR == NT / TI, "one group-A element set per thread");
+    extern __shared__ uint4 lds_raw[];
+    El *lds = (El *)lds_raw;                       // [E][TI]
+    const int tid = threadIdx.x;
+    const int bl = tid % TI, q = tid / TI;
+    const size_t b = (size_t)blockIdx.x * TI + bl;
+    const int logS = loglen - K;
+    const size_t S = (size_t)1 << logS;
+    const bool active = b < B;
+    const size_t g0 = (size_t)blockIdx.y * TPW;
+    auto tile_base = [&](size_t g) { return ((g >> logS) << loglen) + (g & (S - 1)); };
+    Fr raw[R1];                                    // the tile in flight, as loaded
+    {
+        const size_t base = tile_base(g0);
+#pragma unroll
+        for (int m = 0; m < R1; m++) raw[m] = active ? data[(base + (((size_t)q + (size_t)STR * m) << logS)) * B + b] : Fr::zero();
+    }
+#pragma unroll 1
+    for (int it = 0; it < TPW; it++) {
+        const size_t g = g0 + it;
+        const size_t p = g & (S - 1), base = tile_base(g);
+        El x[R1];
+#pragma unroll
+        for (int m = 0; m < R1; m++) x[m] = P::load(raw[m]);
+#pragma unroll
+        for (int st = 0; st < K1; st++) {
+            const int half = 1 << (K1 - 1 - st);
+            const int twshift = logn - (loglen - st);
+#pragma unroll
+            for (int m = 0; m < R1; m++) {
+                if ((m / half) & 1) continue;
+                const size_t j = p + (((size_t)q + (size_t)STR * (m % half)) << logS);
+                P::dif(x[m], x[m + half], (j == 0 && !P::F9) ? nullptr : &tw[j << twshift]);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < R1; m++) lds[((size_t)q + (size_t)STR * m) * TI + bl] = x[m];
+        __syncthreads();
+        if (it + 1 < TPW) {                        // next tile: requested now, consumed after group B
+            const size_t nbase = tile_base(g + 1);
+#pragma unroll
+            for (int m = 0; m < R1; m++) raw[m] = active ? data[(nbase + (((size_t)q + (size_t)STR * m) << logS)) * B + b] : Fr::zero();
+        }
+        for (int q2 = q; q2 < E / R2; q2 += NT / TI) {
+            El y[R2];
+#pragma unroll
+            for (int m = 0; m < R2; m++) y[m] = lds[((size_t)q2 * R2 + m) * TI + bl];
+#pragma unroll
+            for (int st = 0; st < K2; st++) {
+                const int half = 1 << (K2 - 1 - st);
+                const int twshift = logn - (loglen - K1 - st);
+#pragma unroll
+                for (int m = 0; m < R2; m++) {
+                    if ((m / half) & 1) continue;
+                    const size_t j = p + ((size_t)(m % half) << logS);
+                    P::dif(y[m], y[m + half], (j == 0 && !P::F9) ? nullptr : &tw[j << twshift]);
+                }
+            }
+            if (active) {
+#pragma unroll
+                for (int m = 0; m < R2; m++) {
+                    const size_t idx = base + (((size_t)q2 * R2 + m) << logS);
+                    El v = y[m];
+                    if (postmul) v = P::mul(v, postmul[idx]);
+                    data[idx * B + b] = P::store(v, last != 0);
+                }
+            }
+        }
+        __syncthreads();                           // the tile buffer is rewritten by the next iteration's group A
+    }
+}
+template <class P, int K1, int K2, int TPW>
+__global__ __launch_bounds__(ZK_NTT_TILE / 8) void k_ntt_dit_lds_pipe(Fr *__restrict__ data, size_t B, int logn, int logS, const Fr *__restrict__ tw,
+                                                          const Fr *__restrict__ premul, int last) {
+    using T = LdsTile<P, K1, K2>;
+    using El = typename P::E;
+    constexpr int K = T::K, E = T::E, TI = T::TI, R1 = 1 << K1, R2 = 1 << K2, NT = T::THREADS;
+    static_assert(E / R1 == NT / TI, "one group-A element set per thread");
+    extern __shared__ uint4 lds_raw[];
+    El *lds = (El *)lds_raw;
+    const int tid = threadIdx.x;
+    const int bl = tid % TI, q = tid / TI;
+    const size_t b = (size_t)blockIdx.x * TI + bl;
+    const size_t S = (size_t)1 << logS;
+    const bool active = b < B;
+    const size_t g0 = (size_t)blockIdx.y * TPW;
+    auto tile_base = [&](size_t g) { return ((g >> logS) << (logS + K)) + (g & (S - 1)); };
+    Fr raw[R1];
+    {
+        const size_t base = tile_base(g0);
+#pragma unroll
+        for (int m = 0; m < R1; m++) raw[m] = active ? data[(base + (((size_t)q * R1 + m) << logS)) * B + b] : Fr::zero();
+    }
+#pragma unroll 1
+    for (int it = 0; it < TPW; it++) {
+        const size_t g = g0 + it;
+        const size_t p = g & (S - 1), base = tile_base(g);
+        El x[R1];
+#pragma unroll
+        for (int m = 0; m < R1; m++) {
+            El v = P::load(raw[m]);
+            if (premul) v = P::mul(v, premul[base + (((size_t)q * R1 + m) << logS)]);
+            x[m] = v;
+        }
+#pragma unroll
+        for (int st = 0; st < K1; st++) {
+            const int h = 1 << st;
+            const int twshift = logn - (logS + st + 1);
+#pragma unroll
+            for (int m = 0; m < R1; m++) {
+                if ((m >> st) & 1) continue;
+                const size_t j = p + ((size_t)(m & (h - 1)) << logS);
+                P::dit(x[m], x[m + h], (j == 0 && !P::F9) ? nullptr : &tw[j << twshift]);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < R1; m++) lds[((size_t)q * R1 + m) * TI + bl] = x[m];
+        __syncthreads();
+        if (it + 1 < TPW) {
+            const size_t nbase = tile_base(g + 1);
+#pragma unroll
+            for (int m = 0; m < R1; m++) raw[m] = active ? data[(nbase + (((size_t)q * R1 + m) << logS)) * B + b] : Fr::zero();
+        }
+        for (int q2 = q; q2 < R1; q2 += NT / TI) {
+            El y[R2];
+#pragma unroll
+            for (int m = 0; m < R2; m++) y[m] = lds[((size_t)q2 + (size_t)R1 * m) * TI + bl];
+#pragma unroll
+            for (int st = 0; st < K2; st++) {
+                const int h = 1 << st;                          // in units of R1 elements
+                const int twshift = logn - (logS + K1 + st + 1);
+#pragma unroll
+                for (int m = 0; m < R2; m++) {
+                    if ((m >> st) & 1) continue;
+                    const size_t j = p + (((size_t)q2 + (size_t)R1 * (m & (h - 1))) << logS);
+                    P::dit(y[m], y[m + h], (j == 0 && !P::F9) ? nullptr : &tw[j << twshift]);
+                }
+            }
+            if (active) {
+#pragma unroll
+                for (int m = 0; m < R2; m++) data[(base + (((size_t)q2 + (size_t)R1 * m) << logS)) * B + b] = P::store(y[m], last != 0);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 template <class P, int K1, int K2>
 static void launch_dif_lds(Fr *data, size_t B, int logn, int loglen, const Fr *tw, const Fr *postmul, bool last, hipStream_t s) {
     using T = LdsTile<P, K1, K2>;
     static PerDeviceOnce attr;
     attr.run([] { ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_dif_lds<P, K1, K2>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES)); });
     dim3 grid(ceil_div(B, T::TI), (unsigned)(((size_t)1 << logn) >> T::K));
+    if constexpr (T::E / (1 << K1) == T::THREADS / T::TI) {
+        constexpr int TPW = ZK_NTT_TPW;
+        static const bool pipe = [] { const char *e = getenv("ZKPROVE_NTT_PIPE"); return !(e && e[0] == '0'); }();
+        if (pipe && grid.y % TPW == 0 && grid.y >= (unsigned)TPW) {
+            static PerDeviceOnce attr2;
+            attr2.run([] { ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_dif_lds_pipe<P, K1, K2, TPW>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES)); });
+            grid.y /= TPW;
+            hipLaunchKernelGGL((k_ntt_dif_lds_pipe<P, K1, K2, TPW>), grid, dim3(T::THREADS), T::LDS_BYTES, s, data, B, logn, loglen, tw, postmul, (int)last);
+            return;
+        }
+    }
     hipLaunchKernelGGL((k_ntt_dif_lds<P, K1, K2>), grid, dim3(T::THREADS), T::LDS_BYTES, s, data, B, logn, loglen, tw, postmul, (int)last);
 }
 template <class P, int K1, int K2>
@@ -494,6 +666,17 @@ static void launch_dit_lds(Fr *data, size_t B, int logn, int logS, const Fr *tw,
     static PerDeviceOnce attr;
     attr.run([] { ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_dit_lds<P, K1, K2>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES)); });
     dim3 grid(ceil_div(B, T::TI), (unsigned)(((size_t)1 << logn) >> T::K));
+    if constexpr (T::E / (1 << K1) == T::THREADS / T::TI) {
+        constexpr int TPW = ZK_NTT_TPW;
+        static const bool pipe = [] { const char *e = getenv("ZKPROVE_NTT_PIPE"); return !(e && e[0] == '0'); }();
+        if (pipe && grid.y % TPW == 0 && grid.y >= (unsigned)TPW) {
+            static PerDeviceOnce attr2;
+            attr2.run([] { ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_dit_lds_pipe<P, K1, K2, TPW>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES)); });
+            grid.y /= TPW;
+            hipLaunchKernelGGL((k_ntt_dit_lds_pipe<P, K1, K2, TPW>), grid, dim3(T::THREADS), T::LDS_BYTES, s, data, B, logn, logS, tw, premul, (int)last);
+            return;
+        }
+    }
     hipLaunchKernelGGL((k_ntt_dit_lds<P, K1, K2>), grid, dim3(T::THREADS), T::LDS_BYTES, s, data, B, logn, logS, tw, premul, (int)last);
 }
 
