@@ -68,7 +68,12 @@ struct MsmScratch {
     DevBuf<G1XYZZ> vout1;                     // results of the virtual instances of a split small-batch dense MSM
     void reserve_dense(size_t B, size_t max_dense_entries, size_t nb = 0);
     DevBuf<uint32_t> entries_z, bucket_start_z;   // sorted list of the dense MSM when it is kept apart from the wire MSMs' (nb != 0 above)
-    bool presorted = false;                       // msm_dense_presort has filled them for the next dense msm_batch call
+    DevBuf<uint32_t> entries_zb, bucket_start_zb; // second copy (reserve_dense_second): the NEXT batch's list is sorted while this one is walked
+    bool presorted = false;                       // msm_dense_presort has filled slot `zslot` for the next dense msm_batch call
+    int zslot = 0;
+    uint32_t *ez(int slot) { return slot ? entries_zb.p : entries_z.p; }
+    uint32_t *bz(int slot) { return slot ? bucket_start_zb.p : bucket_start_z.p; }
+    void reserve_dense_second(size_t B, size_t max_dense_entries, size_t nb);
     // affine reduction tree (msm_tree.cuh): ping-pong layouts, final bucket points, per-wavefront prefix-product rows
     DevBuf<G1Affine> treeA1, treeB1, fin1;
     DevBuf<uint8_t> tree_scratch;
@@ -81,7 +86,7 @@ struct MsmScratch {
 void msm_batch(const MsmBasesG1 &mb, const Fr *scalars, size_t B, MsmScratch &sc, G1XYZZ *out, hipStream_t s, hipEvent_t *seg_events = nullptr);
 void msm_batch(const MsmBasesG2 &mb, const Fr *scalars, size_t B, MsmScratch &sc, G2XYZZ *out, hipStream_t s);
 // sort stage of a dense msm_batch on its own (stream s), so that it can run beside other MSMs that share the scratch
-bool msm_dense_presort(const MsmBasesG1 &mb, const Fr *scalars, size_t B, MsmScratch &sc, hipStream_t s);
+bool msm_dense_presort(const MsmBasesG1 &mb, const Fr *scalars, size_t B, MsmScratch &sc, hipStream_t s, int slot = 0);
 
 // out[b * stride + i] = x[i * B + b] * y[i * B + b]
 void fr_transpose_mul(const Fr *x, const Fr *y, Fr *out, size_t rows, size_t B, size_t stride, hipStream_t s);

@@ -156,6 +156,10 @@ void MsmScratch::reserve_dense(size_t B_, size_t max_dense_entries, size_t nb) {
     coarse_base.ensure((B_ > VIRT_MIN ? B_ : VIRT_MIN) * 257);
     vout1.ensure(VIRT_MIN + 1);
 }
+void MsmScratch::reserve_dense_second(size_t B_, size_t max_dense_entries, size_t nb) {
+    entries_zb.ensure(B_ * max_dense_entries + 1);
+    bucket_start_zb.ensure((B_ > VIRT_MIN ? B_ : VIRT_MIN) * (nb + 1));
+}
 // lanes per instance of the accumulation kernels: ~2048 entries per lane at the worst case (all scalars wide); 2048 measured best
 // at B = 1024 (among 512..4096); small batches (a single Prove() call) cut the list finer so that the launch still has ~256k threads
 static uint32_t accumulate_lanes(size_t max_entries, size_t B) {
@@ -1026,14 +1030,16 @@ static void dense_two_level_sort(const MsmBases<F> &mb, const Fr *scalars, size_
 }
 // Sort of the dense (quotient) MSM alone, on stream s, into the dense list buffers; the msm_batch call that follows (on a stream that
 // has waited for s) then starts at the accumulation.  Returns false (and does nothing) when the batch takes another sort path.
-bool msm_dense_presort(const MsmBasesG1 &mb, const Fr *scalars, size_t B, MsmScratch &sc, hipStream_t s) {
+bool msm_dense_presort(const MsmBasesG1 &mb, const Fr *scalars, size_t B, MsmScratch &sc, hipStream_t s, int slot) {
     const size_t max_entries = mb.n * (size_t)mb.W;
     const uint32_t nb = 1u << (mb.c - 1);
     if (!mb.dense || mb.n == 0 || dense_split_factor(mb, B, sc) != 1) return false;
     if (sc.entries_z.n < B * max_entries + 1 || sc.bucket_start_z.n < B * (size_t)(nb + 1)) return false;
-    dense_two_level_sort(mb, scalars, B, sc, sc.entries_z.p, sc.bucket_start_z.p, s);
+    if (slot && (sc.entries_zb.n < B * max_entries + 1 || sc.bucket_start_zb.n < B * (size_t)(nb + 1))) return false;
+    dense_two_level_sort(mb, scalars, B, sc, sc.ez(slot), sc.bz(slot), s);
     ZK_HIP(hipGetLastError());
-    sc.presorted = true;
+    sc.presorted = true;          // for the msm_batch call that follows; a caller that sorts batches ahead sets presorted / zslot itself
+    sc.zslot = slot;
     return true;
 }
 
@@ -1079,12 +1085,15 @@ static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, M
     // the sorted list of the dense MSM lives in buffers of its own when they exist (entries_z): its sort may then run on another
     // stream beside the wire MSMs (msm_dense_presort), which use entries / bucket_start
     uint32_t *ent_p = sc.entries.p, *bs_p = sc.bucket_start.p;
-    if (mb.dense && sc.entries_z.n >= B * max_entries + 1 && sc.bucket_start_z.n >= B * (size_t)(nb + 1)) { ent_p = sc.entries_z.p; bs_p = sc.bucket_start_z.p; }
+    if (mb.dense && sc.entries_z.n >= B * max_entries + 1 && sc.bucket_start_z.n >= B * (size_t)(nb + 1)) {
+        const int slot = sc.presorted ? sc.zslot : 0;
+        ent_p = sc.ez(slot); bs_p = sc.bz(slot);
+    }
     if (mb.dense) {
         // scalars = instance-major [B][dense_stride] copy; no +-1 fast path (every quotient coefficient is wide)
         const uint32_t split = dense_split_factor(mb, B, sc);
         if (sc.presorted) {
-            if (ent_p != sc.entries_z.p || split != 1) throw ZkError("msm: presorted dense list without its buffers");
+            if (ent_p != sc.ez(sc.zslot) || split != 1) throw ZkError("msm: presorted dense list without its buffers");
             sc.presorted = false;                        // sorted on another stream; the caller has joined it into s
         } else if (split >= 1) {
             // small batch: split every instance into `split` virtual instances (see reserve_dense); everything downstream just sees

@@ -67,6 +67,8 @@ class Algorithm {
     void ensure_second_set();
     void enqueue_solve(struct SolveSet &S, MsmScratch &commit_scratch, hipStream_t st);
     void enqueue_main(struct SolveSet &S, hipStream_t st, hipEvent_t before_msm, hipStream_t tail);
+    bool ahead_eligible() const;
+    void enqueue_ntt_sort(struct SolveSet &S, hipStream_t sn, int slot);
     void enqueue_tail_early(struct SolveSet &S, hipStream_t st);
     void enqueue_finalize(struct SolveSet &S, hipStream_t st);
     void collect_times(struct SolveSet &S, PhaseTimes *times);

@@ -111,6 +111,9 @@ struct SolveSet {
     std::vector<G1Affine> h_com;
     std::vector<U256> h_chal;
     hipEvent_t solved = nullptr, consumed = nullptr, uploaded = nullptr, t0 = nullptr, t1 = nullptr, t2 = nullptr, t3 = nullptr;
+    hipEvent_t sorted = nullptr;       // ahead mode: the transforms and the quotient-MSM sort of this batch are complete
+    bool ahead = false;                // ... were enqueued by enqueue_ntt_sort (enqueue_main then starts at the wire MSMs)
+    int zslot = 0;                     // which copy of the sorted list they filled
     bool ready = false;
     void reserve(const SolverProgram &prog, size_t B) {
         sb.reserve(prog, B);
@@ -120,6 +123,7 @@ struct SolveSet {
         if (!solved) {
             ZK_HIP(hipEventCreate(&solved)); ZK_HIP(hipEventCreate(&consumed)); ZK_HIP(hipEventCreate(&uploaded));
             ZK_HIP(hipEventCreate(&t0)); ZK_HIP(hipEventCreate(&t1)); ZK_HIP(hipEventCreate(&t2)); ZK_HIP(hipEventCreate(&t3));
+            ZK_HIP(hipEventCreate(&sorted));
         }
         ready = true;
     }
@@ -136,7 +140,8 @@ struct Algorithm::Resident {
     DevBuf<G1XYZZ> f_t, f_u, f_v;
     int last_set = 0;               // the set that holds the most recent batch
     hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr, copy_stream = nullptr;
-    hipEvent_t ev[19] = {};     // [17] products f ready  [18] dense list sorted     // [10] MSM sums of the current batch complete  [11] tail of the previous batch done  [12] A and B1 sums complete  [13] end of the G1 MSMs
+    bool last_ahead = false;    // the last enqueue_main ran in ahead mode (phase times: the transforms are bracketed by ev[19], ev[20])
+    hipEvent_t ev[21] = {};     // [19], [20] transforms in ahead mode  [17] products f ready  [18] dense list sorted     // [10] MSM sums of the current batch complete  [11] tail of the previous batch done  [12] A and B1 sums complete  [13] end of the G1 MSMs
 };
 
 Algorithm::Algorithm() {}
@@ -474,6 +479,7 @@ void Algorithm::resident_reserve(size_t B) {
     if (has_commit) acc(pk.ped.n, pk.ped.c, pk.ped.W);
     R.ms.reserve(B, max_entries, max_nb, max_part);
     R.ms.reserve_dense(B, pk.Z.n * (size_t)pk.Z.W, (size_t)1 << (pk.Z.c - 1));
+    if (B > SIDE_G2_MAX_B) R.ms.reserve_dense_second(B, pk.Z.n * (size_t)pk.Z.W, (size_t)1 << (pk.Z.c - 1));      // ahead mode, enqueue_ntt_sort
     R.ms.reserve_tree(B, pk.Z.n * (size_t)pk.Z.W, (size_t)1 << (pk.Z.c - 1));
     R.ms.reserve_compact(B, std::max({pk.A.n, pk.B1.n, pk.K.n, pk.B2.n, has_commit ? pk.ped.n : (size_t)1}));
     {
@@ -560,6 +566,32 @@ void Algorithm::enqueue_solve(SolveSet &S, MsmScratch &commit_scratch, hipStream
     ZK_HIP(hipEventRecord(S.t3, st));
 }
 
+// Ahead mode (pipelined entries, large batches): the transforms and the quotient MSM's bucket sort of a batch need nothing but its solved
+// wires, so they are enqueued right behind its solve stage -- on the solve stream / copy stream, i.e. while the main stream still walks
+// the PREVIOUS batch's quotient MSM.  The sort (LDS / memory bound, 10 ms alone, 15 beside other kernels) then hides under that walk
+// instead of standing on the critical path between the wire MSMs and the walk; the sorted list is double-buffered (slot = batch
+// parity).  ZKPROVE_SORT_AHEAD=0 keeps everything in enqueue_main.
+bool Algorithm::ahead_eligible() const {
+    static const bool on = [] { const char *e = getenv("ZKPROVE_SORT_AHEAD"); return !(e && e[0] == '0'); }();
+    const Resident &R = *res;
+    const size_t max_entries = pk.Z.n * (size_t)pk.Z.W, nb = (size_t)1 << (pk.Z.c - 1);
+    return on && R.B > SIDE_G2_MAX_B && split_world == 1 && R.ms.entries_zb.n >= R.B * max_entries + 1 && R.ms.bucket_start_zb.n >= R.B * (nb + 1);
+}
+void Algorithm::enqueue_ntt_sort(SolveSet &S, hipStream_t sn, int slot) {
+    Resident &R = *res;
+    const size_t B = R.B, N = (size_t)1 << prog.log_domain;
+    ZK_HIP(hipEventRecord(R.ev[19], sn));
+    dom.to_coset(S.sb.a.p, S.sb.b.p, B, sn);
+    ZK_HIP(hipEventRecord(R.ev[20], sn));
+    fr_transpose_mul(S.sb.a.p, S.sb.b.p, S.sb.c.p, N, B, N, sn);
+    ZK_HIP(hipEventRecord(R.ev[17], sn));
+    ZK_HIP(hipStreamWaitEvent(R.copy_stream, R.ev[17], 0));
+    if (!msm_dense_presort(pk.Z, S.sb.c.p + z_offset, B, R.ms, R.copy_stream, slot)) throw ZkError("ahead sort: dense list buffers missing");
+    R.ms.presorted = false;                 // the flag belongs to the msm_batch call that consumes the list; enqueue_main sets it
+    ZK_HIP(hipEventRecord(S.sorted, R.copy_stream));
+    S.ahead = true;
+    S.zslot = slot;
+}
 // NTT + MSM of one solved batch on stream st.  R.ev[3..9] bracket the phases.  before_msm (optional): an event the MSMs must
 // wait for -- they overwrite the per-batch sums that the previous batch's tail (on another stream) still reads.
 void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm, hipStream_t tail) {
@@ -567,6 +599,31 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm,
     const size_t B = R.B;
     ZK_HIP(hipEventRecord(R.ev[3], st));
     const size_t N = (size_t)1 << prog.log_domain;
+    R.last_ahead = S.ahead;
+    if (S.ahead) {
+        // transforms, products and sort are under way (enqueue_ntt_sort): wire MSMs now, the quotient MSM as soon as its list is sorted
+        S.ahead = false;
+        ZK_HIP(hipEventRecord(R.ev[4], st));
+        if (before_msm) ZK_HIP(hipStreamWaitEvent(st, before_msm, 0));
+        msm_batch(pk.A, S.sb.wires.p, B, R.ms, R.m_ar.p, st);
+        msm_batch(pk.B1, S.sb.wires.p, B, R.ms, R.m_bs1.p, st);
+        ZK_HIP(hipEventRecord(R.ev[12], st));
+        ZK_HIP(hipStreamWaitEvent(tail, R.ev[12], 0));
+        enqueue_tail_early(S, tail);
+        ZK_HIP(hipEventRecord(R.ev[5], st));
+        msm_batch(pk.B2, S.sb.wires.p, B, R.ms, R.m_bs2.p, st);
+        ZK_HIP(hipEventRecord(R.ev[6], st));
+        ZK_HIP(hipStreamWaitEvent(tail, R.ev[6], 0));
+        hipLaunchKernelGGL(k_finalize_g2, dim3(ceil_div(B, 64)), dim3(64), 0, tail, R.m_bs2.p, pk.g2_misc.p, pk.delta2_tab.p, S.s.p, S.out.p, B);
+        msm_batch(pk.K, S.sb.wires.p, B, R.ms, R.m_k.p, st);
+        ZK_HIP(hipStreamWaitEvent(st, S.sorted, 0));
+        R.ms.presorted = true;
+        R.ms.zslot = S.zslot;
+        msm_batch(pk.Z, S.sb.c.p + z_offset, B, R.ms, R.m_z.p, st, &R.ev[8]);
+        ZK_HIP(hipGetLastError());
+        ZK_HIP(hipEventRecord(R.ev[13], st));
+        return;
+    }
     // A small batch is a set of latency-bound kernel chains: independent chains go to the otherwise idle streams (the transforms of b
     // and the K MSM to the solve stream, the G2 MSM to the copy stream) -- never to new ones, see resident_reserve
     const bool side = B <= SIDE_G2_MAX_B;
@@ -671,6 +728,7 @@ void Algorithm::collect_times(SolveSet &S, PhaseTimes *times) {
     ZK_HIP(hipEventElapsedTime(&t56, R.ev[5], R.ev[6])); ZK_HIP(hipEventElapsedTime(&t6e, R.ev[6], R.ev[13])); ZK_HIP(hipEventElapsedTime(&t67, R.ev[13], R.ev[7]));
     t45 += t6e;
     ZK_HIP(hipEventElapsedTime(&times->z_segments, R.ev[8], R.ev[9]));
+    if (R.last_ahead) ZK_HIP(hipEventElapsedTime(&t34, R.ev[19], R.ev[20]));      // the transforms ran on the solve stream, beside the previous batch's MSMs
     times->solve = t01 + t23; times->commit = t12; times->ntt = t34; times->msm_g1 = t45; times->msm_g2 = t56; times->finalize = t67;
 }
 
@@ -722,8 +780,10 @@ void Algorithm::resident_prove_pipelined(int nsteps, PhaseTimes *times) {
     ZK_HIP(hipEventRecord(R.ev[0], M));
     ZK_HIP(hipStreamWaitEvent(S, R.ev[0], 0));
     ZK_HIP(hipStreamWaitEvent(F, R.ev[0], 0));
+    const bool ahead = ahead_eligible();
     enqueue_solve(R.set[0], has_commit ? R.ms2 : R.ms, S);
     ZK_HIP(hipEventRecord(R.set[0].solved, S));
+    if (ahead) enqueue_ntt_sort(R.set[0], S, 0);
     for (int k = 0; k < nsteps; k++) {
         SolveSet &cur = R.set[k & 1], &nxt = R.set[(k + 1) & 1];
         ZK_HIP(hipStreamWaitEvent(M, cur.solved, 0));
@@ -737,9 +797,11 @@ void Algorithm::resident_prove_pipelined(int nsteps, PhaseTimes *times) {
             if (k >= 1) ZK_HIP(hipStreamWaitEvent(S, nxt.consumed, 0));      // nxt's buffers were read by batch k-1
             enqueue_solve(nxt, has_commit ? R.ms2 : R.ms, S);
             ZK_HIP(hipEventRecord(nxt.solved, S));
+            if (ahead) enqueue_ntt_sort(nxt, S, (k + 1) & 1);
         }
     }
     ZK_HIP(hipStreamSynchronize(S));
+    ZK_HIP(hipStreamSynchronize(R.copy_stream));
     ZK_HIP(hipStreamSynchronize(M));
     ZK_HIP(hipStreamSynchronize(F));
     if (times) {
@@ -869,6 +931,7 @@ void Algorithm::prove_batch(size_t batch, const uint32_t *inputs, const U256 *r,
         ZK_HIP(hipStreamWaitEvent(S, cur.uploaded, 0));
         enqueue_solve(cur, has_commit ? R.ms2 : R.ms, S);
         ZK_HIP(hipEventRecord(cur.solved, S));
+        if (ahead_eligible()) enqueue_ntt_sort(cur, S, (int)(k & 1));
         ZK_HIP(hipStreamWaitEvent(M, cur.solved, 0));
         enqueue_main(cur, M, k ? R.ev[11] : nullptr, F);
         ZK_HIP(hipEventRecord(R.ev[10], M));
