@@ -94,7 +94,8 @@ void NttDomain::init(int logn_, hipStream_t s) {
     // and re-normalised (44 instructions against 32), the table entry re-limbed (17), and the tile holds 2 wavefronts per SIMD, where
     // the single dependent accumulator chain of a lone product is not hidden.  The bucket kernels (msm.hip), which are products
     // almost only, gain 25 % from the same field.  (Also tried: the weak 8 x 32 additions around the 9-limb product, re-limbing both
-    // operands and packing the result -- 23.5 vs 23.3 ms, dropped.  ZKPROVE_NTT_DIAG=2 runs the passes without any arithmetic: 13.8 ms of
+    // operands and packing the result -- 23.5 vs 23.3 ms; the same with two butterflies per call so that the two products run in lockstep --
+    // 24.5 vs 22.3 ms on the pipelined passes, the callee's registers push the kernel past 256 VGPRs; both dropped.  ZKPROVE_NTT_DIAG=2 runs the passes without any arithmetic: 13.8 ms of
     // the 23.3 are loads, LDS exchange and stores at 3.7 TB/s, hidden under the butterflies.)
     static const bool want9 = [] { const char *e = getenv("ZKPROVE_NTT_F9"); return e && e[0] == '1'; }();
     f9 = want9;
