@@ -13,10 +13,10 @@ namespace zk {
 template <class F9>
 struct alignas(16) XYZZ9 {         // 144 bytes: bucket sums travel between the accumulation and the reduction as the raw strict limbs
     using W = typename F9::Words;
-    F9 X, Y, ZZ, ZZZ;      // strict between operations; infinity = ZZ exactly zero (a finite point never has ZZ = 0 mod M ... see is_inf)
+    F9 X, Y, ZZ, ZZZ;      // strict between operations; infinity = all limbs of ZZ zero
 
-    // a finite accumulator's ZZ is a product of non-zero values mod M, but its strict integer may be M itself; only the all-zero
-    // limbs written by inf() mean infinity
+    // A finite point's ZZ is a product of values that are non-zero mod M, so its strict integer is neither 0 nor M: only the
+    // all-zero limbs written by inf() mean infinity, and the test is exact.
     ZK_HD bool is_inf() const { return ZZ.is_zero_exact(); }
     static ZK_HD XYZZ9 inf() { return XYZZ9{F9::zero(), F9::zero(), F9::zero(), F9::zero()}; }
 
@@ -53,10 +53,10 @@ struct alignas(16) XYZZ9 {         // 144 bytes: bucket sums travel between the 
         if (F9::sqr(R).is_zero_mod()) return dbl_affine(x2, y2);
         return inf();
     }
-    // this += (x2, y2): affine point that is NOT infinity, coordinates strict, or y2 the limb-wise negation of a strict value
-    // (a negated base point).  Limb bounds: Pv, R = strict - strict (1-lazy; R up to 2-lazy with a negated y2... no: y2 only enters
-    // the product y2 * ZZZ, whose result is strict), X3 before norm() is 4-lazy and normalised because it becomes state and an
-    // operand; T = Q - X3 is 1-lazy; the fused Y3 takes (1-lazy x 1-lazy) + (strict x strict).
+    // this += (x2, y2): affine point that is NOT infinity; coordinates strict, or y2 the limb-wise negation of a strict value (a
+    // negated base point: it only enters the product y2 * ZZZ, whose result is strict again).  Limb bounds: Pv, R = strict - strict
+    // (1-lazy); X3 before its carry propagation is 4-lazy (it becomes state and an operand, hence normalised); T = Q - X3 is 1-lazy;
+    // the fused Y3 takes (1-lazy x 1-lazy) + (strict x strict).
     // (Deciding the special cases only AFTER the arithmetic -- an empty accumulator computes zeros, P^2 == 0 flags it -- keeps the
     // products in one block but holds old and new state live together: spills at 128 VGPRs (84 ms), 73.8 ms at 3 wavefronts per
     // SIMD against 72.0 for this form.)
@@ -109,10 +109,8 @@ struct alignas(16) XYZZ9 {         // 144 bytes: bucket sums travel between the 
     // canonical words of the 2^261 form (bucket sums that the 9-limb reduction reads back)
     ZK_HD XYZZ<W> to_words() const {
         if (is_inf()) return XYZZ<W>::inf();
-        XYZZ<W> r{F9::to_words(X), F9::to_words(Y), F9::to_words(ZZ), F9::to_words(ZZZ)};
-        // a finite point whose ZZ is M as an integer would read back as infinity: ZZ != 0 mod M for finite points, so to_words
-        // (which reduces into [0, M)) can only give 0 for v == 0 or v == M ... both impossible for a finite ZZ
-        return r;
+        // (to_words reduces into [0, M): a finite point keeps ZZ != 0, so it cannot read back as infinity)
+        return XYZZ<W>{F9::to_words(X), F9::to_words(Y), F9::to_words(ZZ), F9::to_words(ZZZ)};
     }
     static ZK_HD XYZZ9 from_words(const XYZZ<W> &p) {
         return XYZZ9{F9::from_words(p.X), F9::from_words(p.Y), F9::from_words(p.ZZ), F9::from_words(p.ZZZ)};
