@@ -306,7 +306,7 @@ def run_rank(args):
         out = {
             "metric": METRIC, "value": h["value"], "unit": "proofs/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": h["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32x8 (254-bit Montgomery, integer)", "data": "synthetic",
+            "dtype": "254-bit Montgomery integers: u32x8 words in memory and the transforms, i32x9 (29-bit signed limbs, 64-bit column sums) in the MSM kernels", "data": "synthetic",
             "config": {"workload": h["workload"], "algorithm_id": args.alg, "batch_per_gpu": B, "pipelined_steps": pipeline,
                        "parallelism": "dp%d (independent proofs per rank, no data-path collective; %s: barrier, timing, all_gather of proof records)" % (world, "RCCL" if backend == "nccl" else backend),
                        "proofs_total": B * world * K, "blocks_per_s": h["blocks_per_s"],
