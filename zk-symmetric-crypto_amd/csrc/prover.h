@@ -64,11 +64,11 @@ class Algorithm {
     // device-resident variant for the benchmark: inputs already in HBM as [n_inputs][B] (see bench.py)
     struct Resident;
     void upload_set(struct SolveSet &S, size_t B, const uint32_t *inputs, const U256 *r, const U256 *s, const U256 *randomize, hipStream_t st);
-    void ensure_second_set();
+    void ensure_second_set(int nsets = 2);
     void enqueue_solve(struct SolveSet &S, MsmScratch &commit_scratch, hipStream_t st);
     void enqueue_main(struct SolveSet &S, hipStream_t st, hipEvent_t before_msm, hipStream_t tail);
     bool ahead_eligible() const;
-    void enqueue_ntt_sort(struct SolveSet &S, hipStream_t sn, int slot);
+    void enqueue_ntt_sort(struct SolveSet &S, hipStream_t sn, int slot, hipEvent_t slot_free = nullptr);
     void enqueue_tail_early(struct SolveSet &S, hipStream_t st);
     void enqueue_finalize(struct SolveSet &S, hipStream_t st);
     void collect_times(struct SolveSet &S, PhaseTimes *times);

@@ -112,6 +112,7 @@ struct SolveSet {
     std::vector<U256> h_chal;
     hipEvent_t solved = nullptr, consumed = nullptr, uploaded = nullptr, t0 = nullptr, t1 = nullptr, t2 = nullptr, t3 = nullptr;
     hipEvent_t sorted = nullptr;       // ahead mode: the transforms and the quotient-MSM sort of this batch are complete
+    hipEvent_t zdone = nullptr;        // the quotient MSM of this batch has read its sorted list (the slot may be refilled)
     bool ahead = false;                // ... were enqueued by enqueue_ntt_sort (enqueue_main then starts at the wire MSMs)
     int zslot = 0;                     // which copy of the sorted list they filled
     bool ready = false;
@@ -123,7 +124,7 @@ struct SolveSet {
         if (!solved) {
             ZK_HIP(hipEventCreate(&solved)); ZK_HIP(hipEventCreate(&consumed)); ZK_HIP(hipEventCreate(&uploaded));
             ZK_HIP(hipEventCreate(&t0)); ZK_HIP(hipEventCreate(&t1)); ZK_HIP(hipEventCreate(&t2)); ZK_HIP(hipEventCreate(&t3));
-            ZK_HIP(hipEventCreate(&sorted));
+            ZK_HIP(hipEventCreate(&sorted)); ZK_HIP(hipEventCreate(&zdone));
         }
         ready = true;
     }
@@ -131,7 +132,7 @@ struct SolveSet {
 
 struct Algorithm::Resident {
     size_t B = 0, cap = 0;
-    SolveSet set[2];
+    SolveSet set[3];                // two working sets for the pipelined entries, a third when batches are prepared two ahead (resident_prove_pipelined)
     MsmScratch ms, ms2, ms_g2, ms_k, ms_a;      // ms2: the commitment MSMs of the solve stage when it runs on the second stream; ms_g2: the G2 MSM of
                                     // SMALL batches, which runs on its own stream beside the latency-bound G1 MSMs; ms_k, ms_a: likewise the K and the A / B1 MSMs
     DevBuf<G1XYZZ> m_ar, m_bs1, m_k, m_z;
@@ -468,6 +469,7 @@ void Algorithm::resident_reserve(size_t B) {
     R.cap = B;
     R.set[0].reserve(prog, B);
     if (R.set[1].ready) R.set[1].reserve(prog, B);
+    if (R.set[2].ready) R.set[2].reserve(prog, B);
     size_t max_entries = 0, max_nb = 0, max_part = 0;
     auto acc = [&](size_t n, int c, int W) {
         max_entries = std::max(max_entries, n * (size_t)W);
@@ -577,7 +579,7 @@ bool Algorithm::ahead_eligible() const {
     const size_t max_entries = pk.Z.n * (size_t)pk.Z.W, nb = (size_t)1 << (pk.Z.c - 1);
     return on && R.B > SIDE_G2_MAX_B && split_world == 1 && R.ms.entries_zb.n >= R.B * max_entries + 1 && R.ms.bucket_start_zb.n >= R.B * (nb + 1);
 }
-void Algorithm::enqueue_ntt_sort(SolveSet &S, hipStream_t sn, int slot) {
+void Algorithm::enqueue_ntt_sort(SolveSet &S, hipStream_t sn, int slot, hipEvent_t slot_free) {
     Resident &R = *res;
     const size_t B = R.B, N = (size_t)1 << prog.log_domain;
     ZK_HIP(hipEventRecord(R.ev[19], sn));
@@ -586,6 +588,7 @@ void Algorithm::enqueue_ntt_sort(SolveSet &S, hipStream_t sn, int slot) {
     fr_transpose_mul(S.sb.a.p, S.sb.b.p, S.sb.c.p, N, B, N, sn);
     ZK_HIP(hipEventRecord(R.ev[17], sn));
     ZK_HIP(hipStreamWaitEvent(R.copy_stream, R.ev[17], 0));
+    if (slot_free) ZK_HIP(hipStreamWaitEvent(R.copy_stream, slot_free, 0));      // the quotient MSM that walked this copy of the list is done
     if (!msm_dense_presort(pk.Z, S.sb.c.p + z_offset, B, R.ms, R.copy_stream, slot)) throw ZkError("ahead sort: dense list buffers missing");
     R.ms.presorted = false;                 // the flag belongs to the msm_batch call that consumes the list; enqueue_main sets it
     ZK_HIP(hipEventRecord(S.sorted, R.copy_stream));
@@ -622,6 +625,7 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm,
         msm_batch(pk.Z, S.sb.c.p + z_offset, B, R.ms, R.m_z.p, st, &R.ev[8]);
         ZK_HIP(hipGetLastError());
         ZK_HIP(hipEventRecord(R.ev[13], st));
+        ZK_HIP(hipEventRecord(S.zdone, st));
         return;
     }
     // A small batch is a set of latency-bound kernel chains: independent chains go to the otherwise idle streams (the transforms of b
@@ -751,17 +755,19 @@ void Algorithm::resident_prove(PhaseTimes *times) {
 }
 
 // the second working set (and the separate scratch of its commitment MSMs) exists only once a pipelined entry is used
-void Algorithm::ensure_second_set() {
+void Algorithm::ensure_second_set(int nsets) {
     Resident &R = *res;
-    if (R.set[1].ready) return;
-    R.set[1].reserve(prog, R.cap);
-    R.set[1].sb.B = R.B;
-    SolveSet &a = R.set[0], &b = R.set[1];
-    ZK_HIP(hipMemcpy(b.sb.inputs.p, a.sb.inputs.p, prog.n_inputs * R.B * sizeof(uint32_t), hipMemcpyDeviceToDevice));
-    ZK_HIP(hipMemcpy(b.r.p, a.r.p, R.B * sizeof(U256), hipMemcpyDeviceToDevice));
-    ZK_HIP(hipMemcpy(b.s.p, a.s.p, R.B * sizeof(U256), hipMemcpyDeviceToDevice));
-    ZK_HIP(hipMemcpy(b.rnd.p, a.rnd.p, R.B * sizeof(U256), hipMemcpyDeviceToDevice));
-    if (has_commit) {
+    for (int i = 1; i < nsets; i++) {
+        if (R.set[i].ready) continue;
+        R.set[i].reserve(prog, R.cap);
+        R.set[i].sb.B = R.B;
+        SolveSet &a = R.set[0], &b = R.set[i];
+        ZK_HIP(hipMemcpy(b.sb.inputs.p, a.sb.inputs.p, prog.n_inputs * R.B * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+        ZK_HIP(hipMemcpy(b.r.p, a.r.p, R.B * sizeof(U256), hipMemcpyDeviceToDevice));
+        ZK_HIP(hipMemcpy(b.s.p, a.s.p, R.B * sizeof(U256), hipMemcpyDeviceToDevice));
+        ZK_HIP(hipMemcpy(b.rnd.p, a.rnd.p, R.B * sizeof(U256), hipMemcpyDeviceToDevice));
+    }
+    if (has_commit && R.ms2.entries.n == 0) {
         R.ms2.reserve(R.cap, pk.ped.n * (size_t)pk.ped.W, (size_t)1 << (pk.ped.c - 1), msm_part_stride(pk.ped.n, pk.ped.c));
         R.ms2.reserve_compact(R.cap, pk.ped.n);
         R.ms2.reserve_sums(R.cap, (size_t)1 << (pk.ped.c - 1), 1);
@@ -774,18 +780,29 @@ void Algorithm::resident_prove_pipelined(int nsteps, PhaseTimes *times) {
     bind_device(device);
     Resident &R = *res;
     if (nsteps <= 0) return;
-    ensure_second_set();
-    R.last_set = (nsteps - 1) & 1;
     hipStream_t M = R.stream, S = R.stream2, F = R.stream3;
+    const bool ahead = ahead_eligible();
+    // Ahead mode prepares batches TWO ahead (three working sets): solve stage, transforms and products of batch k+2 run while batch k is
+    // on the main stream, its sort as soon as batch k's quotient MSM has released the list copy -- the side chain solve -> transforms ->
+    // sort only gets the issue slots the MSMs leave, and with a single batch of lead it finished after the walk it should hide under
+    // (the main stream waited ~20 ms per step).  ZKPROVE_PIPE_DEPTH=1 keeps one batch of lead.
+    static const int depth_env = [] { const char *e = getenv("ZKPROVE_PIPE_DEPTH"); return e ? atoi(e) : 2; }();
+    const int D = (ahead && depth_env >= 2) ? 2 : 1, NS = D + 1;
+    ensure_second_set(NS);
+    R.last_set = (nsteps - 1) % NS;
     ZK_HIP(hipEventRecord(R.ev[0], M));
     ZK_HIP(hipStreamWaitEvent(S, R.ev[0], 0));
     ZK_HIP(hipStreamWaitEvent(F, R.ev[0], 0));
-    const bool ahead = ahead_eligible();
-    enqueue_solve(R.set[0], has_commit ? R.ms2 : R.ms, S);
-    ZK_HIP(hipEventRecord(R.set[0].solved, S));
-    if (ahead) enqueue_ntt_sort(R.set[0], S, 0);
+    auto prepare = [&](int j, hipEvent_t set_free, hipEvent_t slot_free) {      // solve stage of batch j (+ ahead work) on the solve stream
+        SolveSet &nx = R.set[j % NS];
+        if (set_free) ZK_HIP(hipStreamWaitEvent(S, set_free, 0));
+        enqueue_solve(nx, has_commit ? R.ms2 : R.ms, S);
+        ZK_HIP(hipEventRecord(nx.solved, S));
+        if (ahead) enqueue_ntt_sort(nx, S, j & 1, slot_free);
+    };
+    for (int j = 0; j < D && j < nsteps; j++) prepare(j, nullptr, nullptr);
     for (int k = 0; k < nsteps; k++) {
-        SolveSet &cur = R.set[k & 1], &nxt = R.set[(k + 1) & 1];
+        SolveSet &cur = R.set[k % NS];
         ZK_HIP(hipStreamWaitEvent(M, cur.solved, 0));
         enqueue_main(cur, M, k ? R.ev[11] : nullptr, F);
         ZK_HIP(hipEventRecord(R.ev[10], M));
@@ -793,11 +810,14 @@ void Algorithm::resident_prove_pipelined(int nsteps, PhaseTimes *times) {
         enqueue_finalize(cur, F);
         ZK_HIP(hipEventRecord(R.ev[11], F));
         ZK_HIP(hipEventRecord(cur.consumed, F));
-        if (k + 1 < nsteps) {
-            if (k >= 1) ZK_HIP(hipStreamWaitEvent(S, nxt.consumed, 0));      // nxt's buffers were read by batch k-1
-            enqueue_solve(nxt, has_commit ? R.ms2 : R.ms, S);
-            ZK_HIP(hipEventRecord(nxt.solved, S));
-            if (ahead) enqueue_ntt_sort(nxt, S, (k + 1) & 1);
+        const int j = k + D;
+        if (j < nsteps) {
+            // set j % NS last held batch j - NS (= k - 1 for D = 2, k for D = 1 ... no: k - 1 in both): free once that batch's tail is done;
+            // list copy j & 1 was last walked by batch j - 2
+            SolveSet &nx = R.set[j % NS];
+            const bool reused = j >= NS;
+            hipEvent_t slot_free = (ahead && j >= 2) ? R.set[(j - 2) % NS].zdone : nullptr;
+            prepare(j, reused ? nx.consumed : nullptr, slot_free);
         }
     }
     ZK_HIP(hipStreamSynchronize(S));
@@ -805,7 +825,7 @@ void Algorithm::resident_prove_pipelined(int nsteps, PhaseTimes *times) {
     ZK_HIP(hipStreamSynchronize(M));
     ZK_HIP(hipStreamSynchronize(F));
     if (times) {
-        collect_times(R.set[(nsteps - 1) & 1], times);
+        collect_times(R.set[(nsteps - 1) % NS], times);
         float tot;
         ZK_HIP(hipEventElapsedTime(&tot, R.ev[0], R.ev[7]));
         times->total = tot / nsteps;
@@ -909,7 +929,7 @@ void Algorithm::prove_batch(size_t batch, const uint32_t *inputs, const U256 *r,
     }
     resident_reserve(max_chunk);
     Resident &R = *res;
-    ensure_second_set();
+    ensure_second_set(2);
     hipStream_t M = R.stream, S = R.stream2, F = R.stream3, C = R.copy_stream;
     auto chunk_size = [&](size_t k) { return std::min(max_chunk, batch - k * max_chunk); };
     auto download = [&](size_t k) {           // chunk k lives in set k & 1; waits for its tail, not for the whole pipeline
