@@ -929,11 +929,15 @@ void Algorithm::prove_batch(size_t batch, const uint32_t *inputs, const U256 *r,
     }
     resident_reserve(max_chunk);
     Resident &R = *res;
-    ensure_second_set(2);
+    // two working sets; three when chunks are prepared ahead (as in resident_prove_pipelined: the side chain of chunk k then runs beside
+    // the MSMs of chunks k-2 and k-1)
+    static const int depth_env = [] { const char *e = getenv("ZKPROVE_PIPE_DEPTH"); return e ? atoi(e) : 2; }();
+    const size_t NS = (ahead_eligible() && depth_env >= 2) ? 3 : 2;
+    ensure_second_set((int)NS);
     hipStream_t M = R.stream, S = R.stream2, F = R.stream3, C = R.copy_stream;
     auto chunk_size = [&](size_t k) { return std::min(max_chunk, batch - k * max_chunk); };
-    auto download = [&](size_t k) {           // chunk k lives in set k & 1; waits for its tail, not for the whole pipeline
-        SolveSet &cur = R.set[k & 1];
+    auto download = [&](size_t k) {           // chunk k lives in set k % NS; waits for its tail, not for the whole pipeline
+        SolveSet &cur = R.set[k % NS];
         const size_t off = k * max_chunk, Bk = chunk_size(k);
         ZK_HIP(hipStreamWaitEvent(C, cur.consumed, 0));
         ZK_HIP(hipMemcpyAsync(out + off, cur.out.p, Bk * sizeof(ProofPoints), hipMemcpyDeviceToHost, C));
@@ -942,8 +946,8 @@ void Algorithm::prove_batch(size_t batch, const uint32_t *inputs, const U256 *r,
     };
     ZK_HIP(hipEventRecord(R.ev[0], M));
     for (size_t k = 0; k < nchunks; k++) {
-        SolveSet &cur = R.set[k & 1];
-        if (k >= 2) download(k - 2);            // also guarantees that the set is free again
+        SolveSet &cur = R.set[k % NS];
+        if (k >= NS) download(k - NS);          // also guarantees that the set is free again
         const size_t off = k * max_chunk, Bk = chunk_size(k);
         R.B = Bk; cur.sb.B = Bk; R.ms.B = Bk; R.ms2.B = Bk;
         upload_set(cur, Bk, inputs + off * ni, r + off, s + off, randomize ? randomize + off : nullptr, C);
@@ -951,7 +955,7 @@ void Algorithm::prove_batch(size_t batch, const uint32_t *inputs, const U256 *r,
         ZK_HIP(hipStreamWaitEvent(S, cur.uploaded, 0));
         enqueue_solve(cur, has_commit ? R.ms2 : R.ms, S);
         ZK_HIP(hipEventRecord(cur.solved, S));
-        if (ahead_eligible()) enqueue_ntt_sort(cur, S, (int)(k & 1));
+        if (ahead_eligible()) enqueue_ntt_sort(cur, S, (int)(k & 1), k >= 2 ? R.set[(k - 2) % NS].zdone : nullptr);
         ZK_HIP(hipStreamWaitEvent(M, cur.solved, 0));
         enqueue_main(cur, M, k ? R.ev[11] : nullptr, F);
         ZK_HIP(hipEventRecord(R.ev[10], M));
@@ -960,15 +964,14 @@ void Algorithm::prove_batch(size_t batch, const uint32_t *inputs, const U256 *r,
         ZK_HIP(hipEventRecord(R.ev[11], F));
         ZK_HIP(hipEventRecord(cur.consumed, F));
     }
-    if (nchunks >= 2) download(nchunks - 2);
-    download(nchunks - 1);
+    for (size_t k = nchunks > NS ? nchunks - NS : 0; k < nchunks; k++) download(k);
     ZK_HIP(hipStreamSynchronize(S));
     ZK_HIP(hipStreamSynchronize(M));
     ZK_HIP(hipStreamSynchronize(F));
-    R.last_set = (int)((nchunks - 1) & 1);
+    R.last_set = (int)((nchunks - 1) % NS);
     if (times) {
         PhaseTimes t;
-        collect_times(R.set[(nchunks - 1) & 1], &t);
+        collect_times(R.set[(nchunks - 1) % NS], &t);
         float tot;
         ZK_HIP(hipEventElapsedTime(&tot, R.ev[0], R.ev[7]));
         t.total = tot;
