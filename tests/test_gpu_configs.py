@@ -91,6 +91,35 @@ def test_config3_aes256_full_size_batch_every_proof_verifies(zk, oracle):
     zk.lib.ZkpReset()
 
 
+@pytest.mark.parametrize("alg,B", [(0, 128), (1, 128)])
+def test_pipelined_steps_rotate_working_sets_and_list_copies(zk, oracle, alg, B):
+    """resident_prove_pipelined (csrc/prover.hip) prepares batches two ahead: three working sets, two copies of the quotient MSM's sorted
+    list, solve / transforms / sort of later batches beside the MSMs of earlier ones.  Seven steps take every set and both list copies
+    through at least two rounds; every step proves the same resident inputs, so the last batch must be byte-identical to ONE
+    unpipelined step (which uses none of that machinery) -- and instance 0 to the oracle."""
+    _fresh(zk, alg)
+    rng = H.SplitMix64(0x5EED0000 + 70 + alg)
+    insts = [H.make_instance(alg, rng) for _ in range(B)]
+    wits, outs = [], []
+    for inst in insts:
+        _, w, out = zk.request_witness(H.request_json(alg, inst))
+        wits.append(w); outs.append(out)
+    args = (alg, np.array(wits, np.uint32), [i["r"] for i in insts], [i["s"] for i in insts], [i["randomize"] for i in insts])
+    rb = zk.ResidentBatch(*args)
+    rb.step()
+    ref, errs = rb.fetch()
+    assert not errs.any()
+    ref = [zk.proof_serialize(ref[k], alg != 0) for k in range(B)]
+    for nsteps in (7, 1, 2):
+        rb.steps(nsteps)
+        got, errs = rb.fetch()
+        assert not errs.any()
+        assert [zk.proof_serialize(got[k], alg != 0) for k in range(B)] == ref, "pipelined run of %d steps differs from the single step" % nsteps
+    exp, out, *_ = H.oracle_proof_bytes(alg, insts[0])
+    assert ref[0] == exp and outs[0] == out
+    zk.lib.ZkpReset()
+
+
 def test_config4_per_gpu_share_8192_requests_through_prove_batch(zk, oracle):
     """BASELINE config 4 = 65 536 ChaCha20 proofs over 8 GPUs = 8 192 per GPU: one ProveBatch call of 8 192 requests (eight
     device chunks of 1024, software-pipelined).  Order preserved, every ciphertext right, every 16th proof plus the chunk
