@@ -136,6 +136,13 @@ int zkp_msm_g1(long n, long batch, const uint8_t *points, const uint8_t *scalars
 int zkp_msm_g2(long n, long batch, const uint8_t *points, const uint8_t *scalars, uint8_t *out, int c);
 /* same as zkp_msm_g1 through the dense (quotient-MSM) sort path: no 0/+-1 fast path, two-level sort when c >= 9 */
 int zkp_msm_g1_dense(long n, long batch, const uint8_t *points, const uint8_t *scalars, uint8_t *out, int c);
+/* same sum through the fixed-base bit-plane comb of the quotient MSM of large batches (csrc/msm_comb.hip): clumps of k bases, table
+ * of their signed subset sums; mode 1 passes the scalars as products of two matrices (the prover's call shape).
+ * returns 0, or 1 when the bases are degenerate for the comb (point at infinity, coinciding subset sum) and nothing was computed */
+int zkp_msm_comb(long n, long batch, const uint8_t *points, const uint8_t *scalars, uint8_t *out, int k, int mode);
+/* timing of the comb path at production shape (2^logn synthetic bases, pseudo-random scalars): out_ms[5] = table build, patterns,
+ * walk, fold, table GiB */
+int zkp_bench_comb(int logn, long batch, int k, int iters, double *out_ms);
 /* Key folding done at InitAlgorithm (csrc/keyfold.hip): pk.G1.Z (2^logn - 1 points, 64 B canonical LE x|y each) ->
  * ze[i] = 1/(N D) sum_k w^-ik g^-k Z_k (2^logn points) and zc[j] = -1/(N D) sum_k w^-jk Z_k (ncons points), D = g^N - 1;
  * replaces the last four transforms of gnark's computeH (backend/groth16/bn254/prove.go) per proof. */

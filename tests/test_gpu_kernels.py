@@ -130,6 +130,49 @@ def test_msm_g1_dense_path_matches_oracle(zk, oracle, n, batch, c):
     assert np.array_equal(got, exp)
 
 
+@pytest.mark.parametrize("n,batch,k,mode", [(1, 1, 4, 0), (5, 3, 2, 0), (37, 3, 5, 0), (300, 65, 8, 1), (1000, 2, 16, 0), (2500, 130, 11, 1), (4099, 1, 13, 0)])
+def test_msm_comb_matches_oracle(zk, oracle, n, batch, k, mode):
+    """quotient MSM of large batches: fixed-base bit-plane comb (csrc/msm_comb.hip) -- clumps of k bases incl. a short last clump,
+    signed subset-sum tables of the halved bases, one accumulator per (proof, bit plane, clump range), Horner fold"""
+    rng = np.random.default_rng(8100 + n + k)
+    pts = oracle.g1_fixed_base(_rand_fr(rng, n))
+    sc = np.stack([_rand_fr(rng, n) for _ in range(batch)])
+    if n > 10:
+        sc[0, :4] = 0
+        sc[0, 4, :] = 0; sc[0, 4, 0] = 1
+        sc[0, 5] = np.frombuffer((R - 1).to_bytes(32, "little"), np.uint8)
+        sc[0, 6:10] = sc[0, 11]
+    if batch > 1:
+        sc[1] = 0                                             # all bit planes select the all-minus entry; the constant cancels them: infinity
+        if batch > 2:
+            sc[2] = np.frombuffer((R - 1).to_bytes(32, "little"), np.uint8)
+    exp = np.stack([oracle.msm_g1(pts, sc[b]) for b in range(batch)])
+    got = np.zeros((batch, 64), np.uint8)
+    rc = zk.lib.zkp_msm_comb(n, batch, pts.ctypes.data, sc.ctypes.data, got.ctypes.data, k, mode)
+    assert rc == 0, zk.last_error()
+    assert np.array_equal(got, exp)
+    if batch > 1:
+        assert not got[1].any()
+
+
+def test_msm_comb_refuses_degenerate_bases(zk, oracle):
+    """a base at infinity, or two equal / opposite bases inside a clump (a subset sum at infinity), cannot be tabulated: the
+    builder reports it and the prover keeps the bucket path for such a key"""
+    rng = np.random.default_rng(8200)
+    n, batch = 40, 2
+    pts = oracle.g1_fixed_base(_rand_fr(rng, n))
+    sc = np.stack([_rand_fr(rng, n) for _ in range(batch)])
+    got = np.zeros((batch, 64), np.uint8)
+    p_inf = pts.copy(); p_inf[7] = 0
+    assert zk.lib.zkp_msm_comb(n, batch, p_inf.ctypes.data, sc.ctypes.data, got.ctypes.data, 8, 0) == 1
+    p_top = pts.copy(); p_top[8] = p_top[15]                # clump 1 = bases 8..15: its first level adds base 8 to the top base 15
+    assert zk.lib.zkp_msm_comb(n, batch, p_top.ctypes.data, sc.ctypes.data, got.ctypes.data, 8, 0) == 1
+    # equal bases elsewhere in a clump are ordinary: no subset sum (they all contain the top base) meets +-P_j
+    p_eq = pts.copy(); p_eq[9] = p_eq[12]
+    for p in (pts, p_eq):
+        assert zk.lib.zkp_msm_comb(n, batch, p.ctypes.data, sc.ctypes.data, got.ctypes.data, 8, 0) == 0
+        assert np.array_equal(got, np.stack([oracle.msm_g1(p, sc[b]) for b in range(batch)]))
+
 def test_msm_dense_all_equal_scalars_overflows_lds_bins(zk, oracle):
     """adversarial input: identical scalars put every entry of a window into ONE bucket (bins far beyond the LDS capacity
     of the bin sort, one thread's piece spanning a single huge bucket)"""

@@ -91,6 +91,30 @@ bool msm_dense_presort(const MsmBasesG1 &mb, const Fr *scalars, size_t B, MsmScr
 // out[b * stride + i] = x[i * B + b] * y[i * B + b]
 void fr_transpose_mul(const Fr *x, const Fr *y, Fr *out, size_t rows, size_t B, size_t stride, hipStream_t s);
 
+
+// ------------------------------------------------------------------------------- comb MSM (msm_comb.hip)
+// Fixed-base bit-plane comb for the quotient MSM of large batches: per clump of k consecutive bases the table of all signed subset
+// sums (2^(k-1) affine entries, 2^261-Montgomery words, of the HALVED bases), see msm_comb.hip.
+struct CombBases {
+    size_t n = 0, nclumps = 0, E = 0;      // bases, clumps, entries per clump
+    int k = 0;
+    DevBuf<G1Affine> table;                // [nclumps][E]
+    DevBuf<G1Affine> corr;                 // (2^254 - 1) * sum P_i / 2: the constant of the signed-bit form
+    bool ok = false;
+};
+struct CombScratch {
+    DevBuf<uint32_t> pat[2];               // [clump][254][B] table index | sign << 31; two copies: the next batch's is written while this one is walked
+    DevBuf<uint8_t> acc, r1;               // range accumulators [Q][254][B] and first-stage fold results [32][B] (G1X9 records)
+    void reserve(const CombBases &cb, size_t B, int nslots);
+};
+size_t comb_table_bytes(size_t n, int k);
+// false (table released): a base at infinity or a degenerate subset sum -- the caller keeps the bucket path
+bool comb_build(CombBases &cb, const G1Affine *d_points, size_t n, int k, hipStream_t s);
+// scalars x[row][B] (y == nullptr) or the products x * y, Montgomery form -> pat
+void comb_patterns(const CombBases &cb, const Fr *x, const Fr *y, size_t B, uint32_t *pat, hipStream_t s);
+// out[b] = sum_i scalar_i(b) * P_i
+void comb_msm(const CombBases &cb, const uint32_t *pat, size_t B, CombScratch &sc, G1XYZZ *out, hipStream_t s, hipEvent_t *seg_events = nullptr);
+
 // ------------------------------------------------------------------------------- key folding (keyfold.hip)
 // Unscaled inverse DFT over G1: out[i] = sum_k w^{-ik} * data[k] for i < n_out (natural order; data is destroyed)
 void g1_point_idft(G1XYZZ *data, const NttDomain &dom, size_t n_out, G1Affine *out, hipStream_t s);

@@ -149,6 +149,108 @@ extern "C" int zkp_msm_g1_dense(long n, long batch, const uint8_t *points, const
     return msm_test<Fp>(n, batch, points, scalars, out, c, true);
     ZKP_CATCH(-1)
 }
+// quotient-MSM comb path (msm_comb.hip) on its own: points n*64 canonical LE, scalars [batch][n], clumps of k bases.
+// returns 0 ok, 1 = the bases are degenerate for the comb (a point at infinity / a coinciding subset sum): nothing computed
+// mode 1: the scalars are passed as the products of two matrices (x = scalars, y = all ones), the prover's call shape
+extern "C" int zkp_msm_comb(long n_, long batch, const uint8_t *points, const uint8_t *scalars, uint8_t *out, int k, int mode) {
+    ZKP_TRY
+    const size_t n = (size_t)n_, B = (size_t)batch;
+    DevBuf<G1Affine> dp(n ? n : 1);
+    if (n) ZK_HIP(hipMemcpy(dp.p, points, n * 64, hipMemcpyHostToDevice));
+    fp_to_mont_dev(dp.p, n * 2, 0);
+    CombBases cb;
+    if (!comb_build(cb, dp.p, n, k, 0)) return 1;
+    std::vector<Fr> hs;
+    transpose_in(hs, scalars, B, n);
+    DevBuf<Fr> ds(n * B + 1), ones;
+    ds.upload(hs.data(), n * B);
+    fr_to_mont(ds.p, n * B, 0);
+    if (mode == 1) {
+        std::vector<Fr> h1(n * B, Fr::one());
+        ones.upload(h1.data(), n * B);
+    }
+    CombScratch sc;
+    sc.reserve(cb, B, 1);
+    DevBuf<G1XYZZ> res(B);
+    DevBuf<G1Affine> aff(B);
+    comb_patterns(cb, ds.p, mode == 1 ? ones.p : nullptr, B, sc.pat[0].p, 0);
+    comb_msm(cb, sc.pat[0].p, B, sc, res.p, 0);
+    g1_to_affine_canonical(res.p, aff.p, B, 0);
+    ZK_HIP(hipMemcpy(out, aff.p, B * 64, hipMemcpyDeviceToHost));
+    return 0;
+    ZKP_CATCH(-1)
+}
+// timing of the comb path at production shape without a key: n = 2^logn bases j * G, pseudo-random 254-bit scalars.
+// out_ms[0..4] = table build, patterns, walk, fold (both stages), table bytes / 2^30.  Returns 0, 1 = degenerate, -1 error.
+namespace zk {
+__global__ void k_bench_points(G1Affine *out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const G1Affine g{Fp::one(), Fp::one() + Fp::one()};
+    uint32_t k[8];
+    uint64_t x = i * 0xD6E8FEB86659FD93ull + 0xABCDEF01ull;          // unstructured 253-bit multiples of G (structured ones make subset sums coincide)
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+        x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+        k[w] = (uint32_t)x;
+    }
+    k[7] &= 0x1fffffffu;
+    out[i] = scalar_mul(g, k, 254).to_affine();
+}
+__global__ void k_bench_scalars(Fr *out, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    Fr v;
+    uint64_t x = i * 0x9E3779B97F4A7C15ull + 0x1234567ull;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+        v.l[k] = (uint32_t)x;
+    }
+    v.l[7] &= 0x1fffffffu;
+    out[i] = v;
+}
+}
+extern "C" int zkp_bench_comb(int logn, long batch, int k, int iters, double *out_ms) {
+    ZKP_TRY
+    const size_t n = (size_t)1 << logn, B = (size_t)batch;
+    DevBuf<G1Affine> pts(n);
+    hipLaunchKernelGGL(k_bench_points, dim3(ceil_div(n, 64)), dim3(64), 0, 0, pts.p, n);
+    DevBuf<Fr> x(n * B);
+    hipLaunchKernelGGL(k_bench_scalars, dim3(ceil_div(n * B, 256)), dim3(256), 0, 0, x.p, n * B);
+    hipEvent_t e[5];
+    for (auto &ev : e) ZK_HIP(hipEventCreate(&ev));
+    CombBases cb;
+    ZK_HIP(hipEventRecord(e[0], 0));
+    const bool ok = comb_build(cb, pts.p, n, k, 0);
+    ZK_HIP(hipEventRecord(e[1], 0));
+    ZK_HIP(hipEventSynchronize(e[1]));
+    float ms;
+    ZK_HIP(hipEventElapsedTime(&ms, e[0], e[1]));
+    out_ms[0] = ms;
+    out_ms[4] = (double)comb_table_bytes(n, k) / (double)(1ull << 30);
+    if (!ok) return 1;
+    CombScratch sc;
+    sc.reserve(cb, B, 1);
+    DevBuf<G1XYZZ> res(B);
+    double acc[3] = {0, 0, 0};
+    for (int it = 0; it < iters + 1; it++) {
+        ZK_HIP(hipEventRecord(e[0], 0));
+        comb_patterns(cb, x.p, nullptr, B, sc.pat[0].p, 0);
+        ZK_HIP(hipEventRecord(e[1], 0));
+        comb_msm(cb, sc.pat[0].p, B, sc, res.p, 0, &e[2]);
+        ZK_HIP(hipEventRecord(e[4], 0));
+        ZK_HIP(hipEventSynchronize(e[4]));
+        if (it == 0) continue;          // warm-up
+        ZK_HIP(hipEventElapsedTime(&ms, e[0], e[1])); acc[0] += ms;
+        ZK_HIP(hipEventElapsedTime(&ms, e[2], e[3])); acc[1] += ms;
+        ZK_HIP(hipEventElapsedTime(&ms, e[3], e[4])); acc[2] += ms;
+    }
+    for (int i = 0; i < 3; i++) out_ms[1 + i] = acc[i] / iters;
+    for (auto &ev : e) (void)hipEventDestroy(ev);
+    return 0;
+    ZKP_CATCH(-1)
+}
 // points: n*128 canonical LE (x.a0|x.a1|y.a0|y.a1)
 extern "C" int zkp_msm_g2(long n, long batch, const uint8_t *points, const uint8_t *scalars, uint8_t *out, int c) {
     ZKP_TRY
