@@ -86,6 +86,8 @@ struct MsmScratch {
 void msm_batch(const MsmBasesG1 &mb, const Fr *scalars, size_t B, MsmScratch &sc, G1XYZZ *out, hipStream_t s, hipEvent_t *seg_events = nullptr);
 void msm_batch(const MsmBasesG2 &mb, const Fr *scalars, size_t B, MsmScratch &sc, G2XYZZ *out, hipStream_t s);
 // sort stage of a dense msm_batch on its own (stream s), so that it can run beside other MSMs that share the scratch
+// would msm_dense_presort sort this batch into slot 0 (two-level sort applicable, list buffers reserved)?
+bool msm_dense_presort_applicable(const MsmBasesG1 &mb, size_t B, const MsmScratch &sc);
 bool msm_dense_presort(const MsmBasesG1 &mb, const Fr *scalars, size_t B, MsmScratch &sc, hipStream_t s, int slot = 0);
 
 // out[b * stride + i] = x[i * B + b] * y[i * B + b]

@@ -1030,6 +1030,11 @@ static void dense_two_level_sort(const MsmBases<F> &mb, const Fr *scalars, size_
 }
 // Sort of the dense (quotient) MSM alone, on stream s, into the dense list buffers; the msm_batch call that follows (on a stream that
 // has waited for s) then starts at the accumulation.  Returns false (and does nothing) when the batch takes another sort path.
+bool msm_dense_presort_applicable(const MsmBasesG1 &mb, size_t B, const MsmScratch &sc) {
+    const size_t max_entries = mb.n * (size_t)mb.W;
+    const uint32_t nb = 1u << (mb.c - 1);
+    return mb.dense && mb.n != 0 && dense_split_factor(mb, B, sc) == 1 && sc.entries_z.n >= B * max_entries + 1 && sc.bucket_start_z.n >= B * (size_t)(nb + 1);
+}
 bool msm_dense_presort(const MsmBasesG1 &mb, const Fr *scalars, size_t B, MsmScratch &sc, hipStream_t s, int slot) {
     const size_t max_entries = mb.n * (size_t)mb.W;
     const uint32_t nb = 1u << (mb.c - 1);

@@ -21,6 +21,11 @@ struct ProvingKeyDev {
     MsmBasesG1 A, B1, K, Z, ped, ped_sigma;   // Z and K hold pk.G1.Z / pk.G1.K in the folded form of keyfold.hip
     MsmBasesG2 B2;
     size_t n_ped = 0;
+    // quotient MSM of large batches: comb tables over the evaluation-form bases Ze (msm_comb.hip), built the first time a batch of
+    // at least comb_min_batch() proofs is reserved (tens of GB and ~1-3 s: not spent on keys that only ever serve single Prove() calls)
+    DevBuf<G1Affine> ze;        // this rank's slice of Ze (kept for the lazy build)
+    CombBases Zcomb;
+    bool comb_tried = false;
 };
 
 // canonical little-endian affine coordinates; (0,0) = infinity
@@ -68,6 +73,8 @@ class Algorithm {
     void enqueue_solve(struct SolveSet &S, MsmScratch &commit_scratch, hipStream_t st);
     void enqueue_main(struct SolveSet &S, hipStream_t st, hipEvent_t before_msm, hipStream_t tail);
     bool ahead_eligible() const;
+    bool comb_active() const;                               // the current resident batch takes the comb path for its quotient MSM
+    void comb_prepare(size_t B);                            // lazy table build + scratch (resident_reserve)
     void enqueue_ntt_sort(struct SolveSet &S, hipStream_t sn, int slot, hipEvent_t slot_free = nullptr);
     void enqueue_tail_early(struct SolveSet &S, hipStream_t st);
     void enqueue_finalize(struct SolveSet &S, hipStream_t st);

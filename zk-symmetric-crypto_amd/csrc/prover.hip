@@ -114,7 +114,8 @@ struct SolveSet {
     hipEvent_t sorted = nullptr;       // ahead mode: the transforms and the quotient-MSM sort of this batch are complete
     hipEvent_t zdone = nullptr;        // the quotient MSM of this batch has read its sorted list (the slot may be refilled)
     bool ahead = false;                // ... were enqueued by enqueue_ntt_sort (enqueue_main then starts at the wire MSMs)
-    int zslot = 0;                     // which copy of the sorted list they filled
+    int zslot = 0;                     // which copy of the sorted list / of the comb patterns they filled
+    bool comb = false;                 // ... as comb patterns (msm_comb.hip) rather than a sorted bucket list
     bool ready = false;
     void reserve(const SolverProgram &prog, size_t B) {
         sb.reserve(prog, B);
@@ -139,6 +140,9 @@ struct Algorithm::Resident {
     DevBuf<G2XYZZ> m_bs2;
     DevBuf<G1Affine> ar_aff, bs1_aff;
     DevBuf<G1XYZZ> f_t, f_u, f_v;
+    CombScratch comb;               // bit-plane patterns (two copies) and range accumulators of the comb quotient MSM
+    size_t comb_cap = 0, dense_cap = 0;      // batch sizes the comb scratch / the dense bucket-sort buffers are reserved for
+    bool used_comb = false;         // the last enqueue_main took the comb path (debug_fetch then forms the products f itself)
     int last_set = 0;               // the set that holds the most recent batch
     hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr, copy_stream = nullptr;
     bool last_ahead = false;    // the last enqueue_main ran in ahead mode (phase times: the transforms are bracketed by ev[19], ev[20])
@@ -150,7 +154,7 @@ Algorithm::~Algorithm() {
     (void)hipSetDevice(device);
     if (res) {
         for (auto &e : res->ev) if (e) (void)hipEventDestroy(e);
-        for (auto &st : res->set) for (hipEvent_t e : {st.solved, st.consumed, st.uploaded, st.t0, st.t1, st.t2, st.t3}) if (e) (void)hipEventDestroy(e);
+        for (auto &st : res->set) for (hipEvent_t e : {st.solved, st.consumed, st.uploaded, st.t0, st.t1, st.t2, st.t3, st.sorted, st.zdone}) if (e) (void)hipEventDestroy(e);
         if (res->stream) (void)hipStreamDestroy(res->stream);
         if (res->stream2) (void)hipStreamDestroy(res->stream2);
         if (res->stream3) (void)hipStreamDestroy(res->stream3);
@@ -240,6 +244,8 @@ void Algorithm::load(const uint8_t *pkb, size_t pk_len, const uint8_t *r1cs_byte
         msm_bases_build(pk.Z, ze.p + lo, hi - lo, nullptr, C_H, st);
         pk.Z.dense_stride = N;
         z_offset = lo;
+        pk.ze.alloc(hi - lo);
+        ZK_HIP(hipMemcpyAsync(pk.ze.p, ze.p + lo, (hi - lo) * sizeof(G1Affine), hipMemcpyDeviceToDevice, st));
         std::vector<OutputTerm> terms;
         for (size_t i = 0; i < cs.nb_instructions(); i++) {
             if (cs.bp_kind[cs.blueprint_id[i]] != BP_R1C) continue;
@@ -445,6 +451,56 @@ __global__ __launch_bounds__(64) void k_bsb22_challenge(const G1Affine *__restri
     challenge[b] = hi.to_mont().to_mont() + lo.to_mont();
 }
 
+// ---------------------------------------------------------------------------- comb quotient MSM (msm_comb.hip)
+// Table build is triggered by the first batch of >= comb_min_batch() proofs; once the tables exist every batch that fills whole
+// wavefronts (B > SIDE_G2_MAX_B) takes the comb path.  ZKPROVE_COMB=0 keeps the bucket pipeline (A/B runs), ZKPROVE_COMB_K fixes the
+// clump size (default: the largest k <= 19 whose table fits 30 % of the free device memory), ZKPROVE_COMB_MIN_BATCH the trigger.
+static bool comb_enabled() {
+    static const bool on = [] { const char *e = getenv("ZKPROVE_COMB"); return !(e && e[0] == '0'); }();
+    return on;
+}
+static size_t comb_min_batch() {
+    static const size_t v = [] { const char *e = getenv("ZKPROVE_COMB_MIN_BATCH"); return e ? (size_t)atol(e) : (size_t)256; }();
+    return v;
+}
+static int comb_pick_k(size_t n) {
+    static const int forced = [] { const char *e = getenv("ZKPROVE_COMB_K"); return e ? atoi(e) : 0; }();
+    if (forced) return forced;
+    size_t free_b = 0, total_b = 0;
+    ZK_HIP(hipMemGetInfo(&free_b, &total_b));
+    for (int k = 19; k >= 12; k--)
+        if ((double)comb_table_bytes(n, k) <= 0.30 * (double)free_b) return k;
+    return 0;
+}
+bool Algorithm::comb_active() const {
+    return pk.Zcomb.ok && res && split_world == 1 && res->B > SIDE_G2_MAX_B && res->comb_cap >= res->B;
+}
+void Algorithm::comb_prepare(size_t B) {
+    if (!comb_enabled() || split_world != 1 || B <= SIDE_G2_MAX_B) return;
+    Resident &R = *res;
+    if (!pk.comb_tried && B >= comb_min_batch()) {
+        pk.comb_tried = true;
+        const int k = comb_pick_k(pk.ze.n);
+        bool ok = false;
+        std::string why = "not enough free device memory";
+        if (k) {
+            try {
+                ok = comb_build(pk.Zcomb, pk.ze.p, pk.ze.n, k, R.stream);
+                if (!ok) why = "degenerate bases";
+            } catch (const ZkError &e) {
+                pk.Zcomb.table.release();
+                (void)hipGetLastError();
+                why = e.what();
+            }
+        }
+        if (!ok) fprintf(stderr, "zkprove: comb tables of the quotient MSM not built (%s): the bucket pipeline is kept\n", why.c_str());
+    }
+    if (pk.Zcomb.ok && R.comb_cap < B) {
+        R.comb.reserve(pk.Zcomb, B, 2);
+        R.comb_cap = B;
+    }
+}
+
 // ------------------------------------------------------------------------------- pipeline
 void Algorithm::resident_reserve(size_t B) {
     bind_device(device);
@@ -465,6 +521,18 @@ void Algorithm::resident_reserve(size_t B) {
     }
     Resident &R = *res;
     R.B = B;
+    comb_prepare(B);
+    // bucket pipeline of the quotient MSM: for every batch when there are no comb tables, else only for the batches too small for the comb
+    const size_t nbz = (size_t)1 << (pk.Z.c - 1), ez = pk.Z.n * (size_t)pk.Z.W;
+    const size_t Bd = pk.Zcomb.ok ? std::min(B, SIDE_G2_MAX_B) : B;
+    if (R.dense_cap < Bd) {
+        R.dense_cap = Bd;
+        R.ms.reserve(Bd, ez, nbz, msm_part_stride(pk.Z.n, pk.Z.c));
+        R.ms.reserve_dense(Bd, ez, nbz);
+        if (Bd > SIDE_G2_MAX_B) R.ms.reserve_dense_second(Bd, ez, nbz);      // ahead mode, enqueue_ntt_sort
+        R.ms.reserve_tree(Bd, ez, nbz);
+        R.ms.reserve_sums(Bd, nbz, 1);
+    }
     if (B <= R.cap) { for (auto &st : R.set) st.sb.B = B; R.ms.B = B; R.ms2.B = B; return; }
     R.cap = B;
     R.set[0].reserve(prog, B);
@@ -476,13 +544,10 @@ void Algorithm::resident_reserve(size_t B) {
         max_nb = std::max(max_nb, (size_t)1 << (c - 1));
         max_part = std::max(max_part, msm_part_stride(n, c));
     };
-    acc(pk.A.n, pk.A.c, pk.A.W); acc(pk.B1.n, pk.B1.c, pk.B1.W); acc(pk.K.n, pk.K.c, pk.K.W); acc(pk.Z.n, pk.Z.c, pk.Z.W);
+    acc(pk.A.n, pk.A.c, pk.A.W); acc(pk.B1.n, pk.B1.c, pk.B1.W); acc(pk.K.n, pk.K.c, pk.K.W);      // (the quotient MSM's share: above)
     acc(pk.B2.n, pk.B2.c, pk.B2.W);
     if (has_commit) acc(pk.ped.n, pk.ped.c, pk.ped.W);
     R.ms.reserve(B, max_entries, max_nb, max_part);
-    R.ms.reserve_dense(B, pk.Z.n * (size_t)pk.Z.W, (size_t)1 << (pk.Z.c - 1));
-    if (B > SIDE_G2_MAX_B) R.ms.reserve_dense_second(B, pk.Z.n * (size_t)pk.Z.W, (size_t)1 << (pk.Z.c - 1));      // ahead mode, enqueue_ntt_sort
-    R.ms.reserve_tree(B, pk.Z.n * (size_t)pk.Z.W, (size_t)1 << (pk.Z.c - 1));
     R.ms.reserve_compact(B, std::max({pk.A.n, pk.B1.n, pk.K.n, pk.B2.n, has_commit ? pk.ped.n : (size_t)1}));
     {
         const size_t Bs = std::min(B, SIDE_G2_MAX_B);
@@ -503,7 +568,7 @@ void Algorithm::resident_reserve(size_t B) {
         R.ms_g2.reserve_sums(Bs, has_commit ? (size_t)1 << (pk.ped_sigma.c - 1) : 1, (size_t)1 << (pk.B2.c - 1));
     }
     {
-        size_t nb1 = (size_t)1 << (std::max({pk.A.c, pk.B1.c, pk.K.c, pk.Z.c, has_commit ? pk.ped.c : 1}) - 1);
+        size_t nb1 = (size_t)1 << (std::max({pk.A.c, pk.B1.c, pk.K.c, has_commit ? pk.ped.c : 1}) - 1);
         R.ms.reserve_sums(B, nb1, (size_t)1 << (pk.B2.c - 1));
     }
     R.m_ar.alloc(B); R.m_bs1.alloc(B); R.m_k.alloc(B); R.m_z.alloc(B); R.m_bs2.alloc(B);
@@ -577,7 +642,11 @@ bool Algorithm::ahead_eligible() const {
     static const bool on = [] { const char *e = getenv("ZKPROVE_SORT_AHEAD"); return !(e && e[0] == '0'); }();
     const Resident &R = *res;
     const size_t max_entries = pk.Z.n * (size_t)pk.Z.W, nb = (size_t)1 << (pk.Z.c - 1);
-    return on && R.B > SIDE_G2_MAX_B && split_world == 1 && R.ms.entries_zb.n >= R.B * max_entries + 1 && R.ms.bucket_start_zb.n >= R.B * (nb + 1);
+    if (!(on && R.B > SIDE_G2_MAX_B && split_world == 1)) return false;
+    if (comb_active()) return true;                      // the comb path prepares its bit-plane patterns ahead instead of a sorted list
+    // the complete predicate of msm_dense_presort: a batch that does not meet it takes the in-line sort of enqueue_main
+    return pk.Z.dense && pk.Z.n != 0 && msm_dense_presort_applicable(pk.Z, R.B, R.ms) && R.ms.entries_zb.n >= R.B * max_entries + 1 &&
+           R.ms.bucket_start_zb.n >= R.B * (nb + 1);
 }
 void Algorithm::enqueue_ntt_sort(SolveSet &S, hipStream_t sn, int slot, hipEvent_t slot_free) {
     Resident &R = *res;
@@ -585,12 +654,18 @@ void Algorithm::enqueue_ntt_sort(SolveSet &S, hipStream_t sn, int slot, hipEvent
     ZK_HIP(hipEventRecord(R.ev[19], sn));
     dom.to_coset(S.sb.a.p, S.sb.b.p, B, sn);
     ZK_HIP(hipEventRecord(R.ev[20], sn));
-    fr_transpose_mul(S.sb.a.p, S.sb.b.p, S.sb.c.p, N, B, N, sn);
+    S.comb = comb_active();
+    if (!S.comb) fr_transpose_mul(S.sb.a.p, S.sb.b.p, S.sb.c.p, N, B, N, sn);
     ZK_HIP(hipEventRecord(R.ev[17], sn));
     ZK_HIP(hipStreamWaitEvent(R.copy_stream, R.ev[17], 0));
     if (slot_free) ZK_HIP(hipStreamWaitEvent(R.copy_stream, slot_free, 0));      // the quotient MSM that walked this copy of the list is done
-    if (!msm_dense_presort(pk.Z, S.sb.c.p + z_offset, B, R.ms, R.copy_stream, slot)) throw ZkError("ahead sort: dense list buffers missing");
-    R.ms.presorted = false;                 // the flag belongs to the msm_batch call that consumes the list; enqueue_main sets it
+    if (S.comb) {
+        // comb path: the products f = A*B are formed on the fly and only their bit planes (table indices) are written
+        comb_patterns(pk.Zcomb, S.sb.a.p, S.sb.b.p, B, R.comb.pat[slot].p, R.copy_stream);
+    } else {
+        if (!msm_dense_presort(pk.Z, S.sb.c.p + z_offset, B, R.ms, R.copy_stream, slot)) throw ZkError("ahead sort: dense list buffers missing");
+        R.ms.presorted = false;                 // the flag belongs to the msm_batch call that consumes the list; enqueue_main sets it
+    }
     ZK_HIP(hipEventRecord(S.sorted, R.copy_stream));
     S.ahead = true;
     S.zslot = slot;
@@ -620,9 +695,14 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm,
         hipLaunchKernelGGL(k_finalize_g2, dim3(ceil_div(B, 64)), dim3(64), 0, tail, R.m_bs2.p, pk.g2_misc.p, pk.delta2_tab.p, S.s.p, S.out.p, B);
         msm_batch(pk.K, S.sb.wires.p, B, R.ms, R.m_k.p, st);
         ZK_HIP(hipStreamWaitEvent(st, S.sorted, 0));
-        R.ms.presorted = true;
-        R.ms.zslot = S.zslot;
-        msm_batch(pk.Z, S.sb.c.p + z_offset, B, R.ms, R.m_z.p, st, &R.ev[8]);
+        R.used_comb = S.comb;
+        if (S.comb) {
+            comb_msm(pk.Zcomb, R.comb.pat[S.zslot].p, B, R.comb, R.m_z.p, st, &R.ev[8]);
+        } else {
+            R.ms.presorted = true;
+            R.ms.zslot = S.zslot;
+            msm_batch(pk.Z, S.sb.c.p + z_offset, B, R.ms, R.m_z.p, st, &R.ev[8]);
+        }
         ZK_HIP(hipGetLastError());
         ZK_HIP(hipEventRecord(R.ev[13], st));
         ZK_HIP(hipEventRecord(S.zdone, st));
@@ -657,13 +737,16 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm,
     ZK_HIP(hipEventRecord(R.ev[4], st));
     if (before_msm) ZK_HIP(hipStreamWaitEvent(st, before_msm, 0));
     bool presorted = false;
+    const bool comb = !side && comb_active();
+    R.used_comb = comb;
     if (!side) {
-        // the quotient MSM's scalars f = A*B are complete: its bucket sort (LDS / memory bound) runs on the copy stream beside the
-        // wire MSMs (multiplier bound) and is joined just before the accumulation
-        fr_transpose_mul(S.sb.a.p, S.sb.b.p, S.sb.c.p, N, B, N, st);
+        // the quotient MSM's scalars f = A*B are complete: its bucket sort (LDS / memory bound) -- or, on the comb path, the extraction
+        // of its bit-plane patterns -- runs on the copy stream beside the wire MSMs (multiplier bound) and is joined just before the walk
+        if (!comb) fr_transpose_mul(S.sb.a.p, S.sb.b.p, S.sb.c.p, N, B, N, st);
         ZK_HIP(hipEventRecord(R.ev[17], st));
         ZK_HIP(hipStreamWaitEvent(R.copy_stream, R.ev[17], 0));
-        presorted = msm_dense_presort(pk.Z, S.sb.c.p + z_offset, B, R.ms, R.copy_stream);
+        if (comb) { comb_patterns(pk.Zcomb, S.sb.a.p, S.sb.b.p, B, R.comb.pat[0].p, R.copy_stream); presorted = true; }
+        else presorted = msm_dense_presort(pk.Z, S.sb.c.p + z_offset, B, R.ms, R.copy_stream);
         if (presorted) ZK_HIP(hipEventRecord(R.ev[18], R.copy_stream));
         msm_batch(pk.A, S.sb.wires.p, B, R.ms, R.m_ar.p, st);
         msm_batch(pk.B1, S.sb.wires.p, B, R.ms, R.m_bs1.p, st);
@@ -694,7 +777,8 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm,
         fr_transpose_mul(S.sb.a.p, S.sb.b.p, S.sb.c.p, N, B, N, st);
     }
     if (presorted) ZK_HIP(hipStreamWaitEvent(st, R.ev[18], 0));
-    msm_batch(pk.Z, S.sb.c.p + z_offset, B, R.ms, R.m_z.p, st, &R.ev[8]);
+    if (comb) comb_msm(pk.Zcomb, R.comb.pat[0].p, B, R.comb, R.m_z.p, st, &R.ev[8]);
+    else msm_batch(pk.Z, S.sb.c.p + z_offset, B, R.ms, R.m_z.p, st, &R.ev[8]);
     ZK_HIP(hipGetLastError());
     if (side) {                                                  // the batch's sums are complete only when the side streams are done too
         ZK_HIP(hipStreamWaitEvent(st, R.ev[6], 0));
@@ -998,7 +1082,8 @@ void Algorithm::debug_fetch(uint8_t *wires_out, uint8_t *h_out) {
         for (size_t b = 0; b < B; b++)
             for (size_t w = 0; w < nw; w++) memcpy(wires_out + (b * nw + w) * 32, &tmp[w * B + b], 32);
     }
-    if (h_out) {   // instance-major products f = A*B on the coset, as left in c by enqueue_main
+    if (h_out) {   // instance-major products f = A*B on the coset, as left in c by enqueue_main (the comb path never forms them: done here)
+        if (R.used_comb) { fr_transpose_mul(R.set[0].sb.a.p, R.set[0].sb.b.p, R.set[0].sb.c.p, N, B, N, 0); ZK_HIP(hipDeviceSynchronize()); }
         DevBuf<Fr> d(N * B);
         ZK_HIP(hipMemcpy(d.p, R.set[0].sb.c.p, N * B * sizeof(Fr), hipMemcpyDeviceToDevice));
         fr_from_mont(d.p, N * B, 0);
