@@ -46,6 +46,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-aes256", action="store_true", help="skip the AES-256-CTR leg of the metric")
     ap.add_argument("--no-pipeline", action="store_true", help="one stream, no overlap of consecutive steps")
     ap.add_argument("--cpu-proofs", type=int, default=-1, help="cpu_baseline sample: proofs per worker process (0 = skip, -1 = default 8)")
+    ap.add_argument("--abi-requests", type=int, default=-1,
+                    help="ABI leg: JSON requests per ProveBatch call (0 = skip, -1 = default 8192 ChaCha20 / 4096 AES-256)")
     ap.add_argument("--master-port", type=int, default=0)
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="CPU check of the N-rank launcher + gather plumbing (gloo, no GPU, nothing is proved or timed)")
@@ -114,13 +116,16 @@ def profile_manifest():
     return m
 
 
-def roofline_objects(alg, B, mean, value_per_gpu, manifest):
+def roofline_objects(alg, B, mean, value_per_gpu, manifest, zinfo):
+    """zinfo = zkp_quotient_msm_info of the resident batch: [comb?, k | c, clumps | windows, table MiB, mixed additions per proof]"""
     zdur_ms = mean.get("z_segments", 0.0) or mean["msm_g1"]
     zbytes = Z_TERMS[alg] * 96 * B
     achieved = zbytes / (zdur_ms * 1e-3) / 1e9
+    comb = bool(zinfo[0])
+    adds = zinfo[4] * B / (zdur_ms * 1e-3)
     traffic, traffic_src = None, None
     pm = manifest.get("pmc_traffic", {}).get(str(alg))
-    if pm and B == 1024:
+    if pm and B == 1024 and bool(pm.get("comb")) == comb:
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", pm["file"])))
             v = d["kernels"][pm["kernel"]]
@@ -129,26 +134,32 @@ def roofline_objects(alg, B, mean, value_per_gpu, manifest):
         except Exception:
             traffic = None
     mb = manifest.get("microbench", {})
-    nwin = 16
-    roof = {"bound": "hbm", "kernel": manifest.get("dominant_kernel", "bucket accumulation of the quotient MSM over G1.Z"), "achieved": achieved, "peak": HBM_PEAK_GBS,
+    if comb:
+        kernel = "k_comb_walk (quotient MSM over G1.Z as a fixed-base bit-plane comb, csrc/msm_comb.hip: clumps of k = %d bases, %d clumps, %d MiB of signed subset-sum tables)" % (zinfo[1], zinfo[2], zinfo[3])
+        how = ("every proof costs clumps x 254 = %d mixed additions (one per clump and bit plane; no sort, no buckets, no reduction)" % zinfo[4])
+    else:
+        kernel = "k_msm_accumulate9<Fp, dense> (bucket accumulation of the quotient MSM over G1.Z, csrc/msm.hip: c = %d, %d windows)" % (zinfo[1], zinfo[2])
+        how = "every term costs W = %d curve additions (one per signed window, window multiples precomputed)" % zinfo[2]
+    roof = {"bound": "valu-issue", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "launch_ms": zdur_ms, "algorithmic_bytes_per_launch": zbytes,
             "whole_path_GBps": value_per_gpu * BYTES_PER_PROOF[alg] / 1e9,
-            "point_adds_per_s": Z_TERMS[alg] * nwin * B / (zdur_ms * 1e-3),
+            "quotient_msm": {"comb": comb, "k_or_c": zinfo[1], "clumps_or_windows": zinfo[2], "table_MiB": zinfo[3], "mixed_adds_per_proof": zinfo[4]},
+            "point_adds_per_s": adds,
             "mixed_add_peak_per_s": mb.get("g1_mixed_add_per_s"), "fp_mul_peak_per_s": mb.get("fp_mul_per_s"),
             "mixed_add_isa_ceiling_per_s": mb.get("g1_mixed_add_isa_ceiling_per_s"),
-            "frac_of_mixed_add_peak": (Z_TERMS[alg] * nwin * B / (zdur_ms * 1e-3) / mb["g1_mixed_add_per_s"]) if mb.get("g1_mixed_add_per_s") else None,
-            "frac_of_isa_ceiling": (Z_TERMS[alg] * nwin * B / (zdur_ms * 1e-3) / mb["g1_mixed_add_isa_ceiling_per_s"]) if mb.get("g1_mixed_add_isa_ceiling_per_s") else None,
+            "frac_of_mixed_add_peak": (adds / mb["g1_mixed_add_per_s"]) if mb.get("g1_mixed_add_per_s") else None,
+            "frac_of_isa_ceiling": (adds / mb["g1_mixed_add_isa_ceiling_per_s"]) if mb.get("g1_mixed_add_isa_ceiling_per_s") else None,
             "microbench_source": mb.get("file"),
-            "note": "integer-ALU bound (v_mad_i64_i32 column sums of the 9 x 29-bit field, csrc/field9.cuh), not HBM bound: every term costs W=16 curve additions "
-                    "(one per signed 16-bit window, window multiples precomputed); launch_ms = HIP events around the accumulation launches of the quotient MSM on the "
-                    "prover's stream; mixed_add_peak = back-to-back mixed additions of the same field with every lane busy (scripts/gpu_microbench.py); "
+            "note": "`frac` is the HBM fraction by ALGORITHMIC bytes (terms x 96 B; SURVEY 8d) and is small by construction: the kernel is bound by VALU instruction issue "
+                    "(v_mad_i64_i32 column sums of the 9 x 29-bit field, csrc/field9.cuh), not by HBM: " + how + "; launch_ms = HIP events around the walk launches of the "
+                    "quotient MSM on the prover's stream; mixed_add_peak = back-to-back mixed additions of the same field with every lane busy (scripts/gpu_microbench.py); "
                     "isa ceiling = measured v_mad_i64_i32 issue rate / 1467 multiply-adds per addition (the shifts, masks and carry-free additions around them "
                     "are not counted); MFMA not applicable"}
     n_dom = 1 << (16 if alg == 0 else 17)
     ntt_model = 7 * n_dom * 32 * 2 * B
     ntt_moved = manifest.get("ntt_round_trips", 3) * 4 * n_dom * 32 * 2 * B
-    rntt = {"bound": "hbm", "kernel": "NTT passes of one batch (4 transforms: inverse + coset-forward of a and b)", "achieved": ntt_model / (mean["ntt"] * 1e-3) / 1e9,
+    rntt = {"bound": "valu-issue", "kernel": "NTT passes of one batch (4 transforms: inverse + coset-forward of a and b)", "achieved": ntt_model / (mean["ntt"] * 1e-3) / 1e9,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ntt_model / (mean["ntt"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "phase_ms": mean["ntt"], "algorithmic_bytes": ntt_model, "bytes_moved_by_design": ntt_moved,
             "moved_GBps": ntt_moved / (mean["ntt"] * 1e-3) / 1e9,
@@ -275,6 +286,50 @@ def run_rank(args):
             good += bool(zk.verify(H.CIPHER[leg.alg], pb, out, list(zip(inst["nonces"], inst["counters"])), inst["data"]))
         return "%d/%d" % (good, world)
 
+    def golden_check(alg, res):
+        """every rank's slice of the gathered records, serialised as gnark Proof.WriteTo bytes, against the oracle-generated digests of
+        tests/golden/bench_proofs_sha256.json (scripts/make_bench_golden.py): {"match": all compared slices equal, "ranks_compared": n}"""
+        try:
+            gold = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_proofs_sha256.json")))["sha256"].get(str(alg), {}).get(str(B), {})
+        except Exception:
+            gold = {}
+        compared, good, digests = 0, 0, []
+        for r in range(world):
+            hsh = hashlib.sha256(b"".join(zk.proof_serialize(res["gathered"][r, i], alg != 0) for i in range(B))).hexdigest()
+            digests.append(hsh)
+            if str(r) in gold:
+                compared += 1
+                good += gold[str(r)] == hsh
+        return {"match": (good == compared) if compared else None, "ranks_compared": compared, "of_ranks": world, "sha256_rank0": digests[0]}
+
+    def abi_leg(alg, nreq):
+        """what the reference's own harness times (gnark/libraries/core_test.go:121-150: prover.Prove(json) in a loop): JSON requests in,
+        JSON responses out, through the exported C ABI -- request decoding, ciphers, witness packing, PCIe and proof serialisation inside
+        the timed region.  One ProveBatch call of nreq requests (best of 2) and the median of 15 synchronous single Prove() calls."""
+        rng = H.SplitMix64(0xAB10 + alg)
+        reqs = [json.loads(H.request_json(alg, H.make_instance(alg, rng))) for _ in range(nreq)]
+        body = json.dumps(reqs).encode()
+        zk.prove_batch_raw(json.dumps(reqs[:2048]).encode())          # warm-up: chunk buffers of the batch entry
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            out = zk.prove_batch_raw(body)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        resl = json.loads(out)
+        ok = sum(1 for x in resl if isinstance(x, dict) and "proof" in x)
+        one = json.dumps(reqs[0]).encode()
+        zk.prove_raw(one)
+        lat = []
+        for _ in range(15):
+            t0 = time.perf_counter()
+            zk.prove_raw(one)
+            lat.append(time.perf_counter() - t0)
+        lat.sort()
+        return {"proofs_per_s": nreq / best, "requests_per_call": nreq, "ok": ok, "seconds_per_call": best,
+                "single_prove_ms": lat[len(lat) // 2] * 1e3, "single_prove_ms_min": lat[0] * 1e3,
+                "what": "ProveBatch(JSON array) -> JSON array and Prove(JSON) -> JSON through the C ABI; host decoding, ciphers, witness packing, PCIe, serialisation included"}
+
     manifest = profile_manifest()
     legs_out = {}
     head = Leg(zk, args.alg, B, rank)
@@ -288,7 +343,9 @@ def run_rank(args):
         lines = {}
         for alg, leg, r in algs:
             value = B * world * K / r["dt"]
-            roof, rntt = roofline_objects(alg, B, r["mean"], value / world, manifest)
+            zinfo = np.zeros(5, np.int64)
+            zk.lib.zkp_quotient_msm_info(alg, zinfo.ctypes.data)
+            roof, rntt = roofline_objects(alg, B, r["mean"], value / world, manifest, [int(x) for x in zinfo])
             lines[alg] = {
                 "value": value, "unit": "proofs/s", "ms_per_step": r["dt"] / K * 1e3,
                 "per_rank_proofs_per_s": [B * K / t for t in r["per_rank"]],
@@ -299,6 +356,7 @@ def run_rank(args):
                 "gathered_proof_records": int(r["gathered"].shape[0] * r["gathered"].shape[1]),
                 "gathered_sha256": hashlib.sha256(r["gathered"].tobytes()).hexdigest(),
                 "gather_spot_check_verified": spot_check(leg, r),
+                "proofs_match_golden": golden_check(alg, r),
                 "init_s": leg.t_init, "setup_s": leg.t_setup,
                 "roofline": roof, "roofline_ntt": rntt,
             }
@@ -320,8 +378,17 @@ def run_rank(args):
             "init_s": h["init_s"], "setup_s": h["setup_s"],
             "roofline": h["roofline"], "roofline_ntt": h["roofline_ntt"],
         }
+        out["proofs_match_golden"] = h["proofs_match_golden"]
         if 2 in lines and args.alg != 2:
             out["aes256_ctr"] = lines[2]
+        if args.abi_requests != 0 and world == 1:
+            # after every timed region: the ABI-inclusive rates (not `value`: the contract times resident inputs)
+            try:
+                out["abi"] = abi_leg(args.alg, args.abi_requests if args.abi_requests > 0 else (8192 if args.alg == 0 else 4096))
+                if 2 in lines and args.alg != 2:
+                    out["aes256_ctr"]["abi"] = abi_leg(2, args.abi_requests if args.abi_requests > 0 else 4096)
+            except Exception as e:
+                out["abi"] = {"error": repr(e)}
         if args.cpu_proofs != 0 and world == 1:
             # CPU baseline: scripts/cpu_baseline.py in its own interpreter (no GPU runtime): one single-threaded oracle
             # prover process per worker, forked after key generation; best of {cores, 1.5 x cores} workers

@@ -111,6 +111,9 @@ int zkp_bench_fetch(int algorithmID, uint8_t *proofs, uint32_t *errs);
 int ZkpSetSplit(int rank, int world);
 int zkp_split_partials(int algorithmID, uint8_t *out384);
 int zkp_split_finish(int algorithmID, int world, const uint8_t *gathered);
+/* how the quotient MSM of the current resident batch runs: info5 = {1 comb path | 0 bucket pipeline, clump size k | window bits c,
+ * clumps | windows, table MiB, mixed additions per proof of its walk} */
+int zkp_quotient_msm_info(int algorithmID, long *info5);
 /* after a step: copy out the solved wire vectors [batch][n_wires][32] and the quotient-stage products
  * f_i = A(g w^i) * B(g w^i) [batch][N][32] (canonical LE, natural order; the scalars of the folded quotient MSM, see
  * csrc/keyfold.hip) -- parity tests only */

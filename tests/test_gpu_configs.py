@@ -60,7 +60,7 @@ def test_config1_rfc8439_vector_through_prove(zk, oracle):
 
 
 def test_config3_aes256_full_size_batch_every_proof_verifies(zk, oracle):
-    """BASELINE config 3 at full size (AES-256-CTR, resident batch 1024, two pipelined passes): no solver error, 1024 distinct
+    """BASELINE config 3 at full size (AES-256-CTR, resident batch 1024, seven pipelined passes == one single pass): no solver error, 1024 distinct
     proofs, every one passes the product's verifier, a proof does not verify against its neighbour's public inputs, and
     instances 0 / 511 / 1023 are bit-identical to the oracle's proofs (BSB22 commitment and its proof of knowledge included)."""
     from concurrent.futures import ThreadPoolExecutor
@@ -73,9 +73,13 @@ def test_config3_aes256_full_size_batch_every_proof_verifies(zk, oracle):
         _, w, out = zk.request_witness(H.request_json(alg, inst))
         wits.append(w); outs.append(out)
     rb = zk.ResidentBatch(alg, np.array(wits, np.uint32), [i["r"] for i in insts], [i["s"] for i in insts], [i["randomize"] for i in insts])
-    rb.steps(2)
+    rb.step()                                   # unpipelined reference pass
+    single, errs = rb.fetch()
+    assert not errs.any()
+    rb.steps(7)                                 # every working set and both ahead-prepared copies reused at the bench's size
     proofs, errs = rb.fetch()
     assert not errs.any()
+    assert np.array_equal(proofs, single), "pipelined passes differ from the single pass in records %s" % np.nonzero((proofs != single).any(axis=1))[0][:10]
     ser = [zk.proof_serialize(proofs[k], True) for k in range(B)]
     assert len(set(ser)) == B and all(len(s) == 196 for s in ser)
 
@@ -150,6 +154,44 @@ def test_config4_per_gpu_share_8192_requests_through_prove_batch(zk, oracle):
     assert pairing.groth16_verify(vk, gf.proof_parse(base64.b64decode(res[n - 1]["proof"])), wit[:2304])
     zk.lib.ZkpReset()
 
+
+def test_config4_all_65536_proofs_eight_rank_streams(zk, oracle):
+    """BASELINE config 4 at its FULL size on one GPU: the eight ranks' shares, 8 x 8 192 = 65 536 independent ChaCha20 proofs, each
+    share one ProveBatch call over its own SplitMix64 stream (0x5EED0000 + 1 + 1000 r, the streams bench.py gives its ranks).  All
+    65 536 responses carry the right ciphertext and pairwise different proofs; from every share every 64th proof and the chunk edges
+    verify against THEIR request; the first and the last proof of every share verify under the oracle's independent pairing.  (An
+    8-GPU node runs the same eight shares side by side; independence of the chunks: js/src/zk.ts:94-177.)"""
+    from concurrent.futures import ThreadPoolExecutor
+    alg, per, ranks = 0, 8192, 8
+    _fresh(zk, alg)
+    vk = gf.vk_from_pk(H.oracle_pk(alg))
+    seen = set()
+    total = 0
+    for r in range(ranks):
+        rng = H.SplitMix64(0x5EED0000 + 1 + 1000 * r)
+        insts = [H.make_instance(alg, rng) for _ in range(per)]
+        body = ("[" + ",".join(H.request_json(alg, i).decode() for i in insts) + "]").encode()
+        res = json.loads(zk.prove_batch_raw(body))
+        assert len(res) == per and all(isinstance(x, dict) and "proof" in x for x in res)
+        outs = [zk.request_witness(H.request_json(alg, i))[2] for i in insts]
+        assert all(base64.b64decode(res[k]["ciphertext"]) == outs[k] for k in range(per))
+        proofs = {x["proof"] for x in res}
+        assert len(proofs) == per and not (proofs & seen)
+        seen |= proofs
+        total += per
+        picks = sorted(set(list(range(0, per, 64)) + [c * 1024 + d for c in range(8) for d in (0, 1023)]))
+
+        def check(k):
+            blocks = list(zip(insts[k]["nonces"], insts[k]["counters"]))
+            return zk.verify("chacha20", base64.b64decode(res[k]["proof"]), outs[k], blocks, insts[k]["data"])
+        with ThreadPoolExecutor(max_workers=16) as ex:
+            ok = list(ex.map(check, picks))
+        assert all(ok), "rank %d: requests failing: %s" % (r, [picks[i] for i, v in enumerate(ok) if not v][:10])
+        for k in (0, per - 1):
+            wit, _ = H.oracle_witness(alg, insts[k])
+            assert pairing.groth16_verify(vk, gf.proof_parse(base64.b64decode(res[k]["proof"])), wit[:2304]), "rank %d proof %d" % (r, k)
+    assert total == 65536 and len(seen) == 65536
+    zk.lib.ZkpReset()
 
 _SHARD_SCRIPT = r"""
 import base64, importlib, json, os, sys, threading

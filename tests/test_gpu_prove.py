@@ -353,9 +353,18 @@ def test_full_size_batch_every_proof_verifies(zk, oracle):
         _, w, out = zk.request_witness(H.request_json(alg, inst))
         wits.append(w); outs.append(out)
     rb = zk.ResidentBatch(alg, np.array(wits, np.uint32), [i["r"] for i in insts], [i["s"] for i in insts], [0] * B)
-    rb.steps(2)
+    rb.step()                                   # one unpipelined pass: a single working set, no batch prepared ahead
+    single, errs = rb.fetch()
+    assert not errs.any()
+    # seven pipelined passes at the size the bench runs: all three working sets and both copies of the quotient MSM's ahead-prepared
+    # data (comb patterns / sorted list) are reused, so the consumed / zdone waits of prover.hip are on the path; every pass proves the
+    # same resident inputs, hence all 1024 records of the last one must equal the single pass
+    rb.steps(7)
     proofs, errs = rb.fetch()
     assert not errs.any()
+    assert np.array_equal(proofs, single), "pipelined passes differ from the single pass in records %s" % np.nonzero((proofs != single).any(axis=1))[0][:10]
+    info = np.zeros(5, np.int64)
+    assert zk.lib.zkp_quotient_msm_info(alg, info.ctypes.data) == 0 and info[0] == 1, "a 1024-batch must take the comb path of the quotient MSM"
     ser = [zk.proof_serialize(proofs[k], False) for k in range(B)]
     assert len(set(ser)) == B
 

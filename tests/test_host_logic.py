@@ -103,8 +103,20 @@ def test_reference_panic_messages(zk, req, panic):
         assert got == panic
 
 
+def test_syntax_errors_answer_with_the_offset_like_gos_json_syntax_error(zk):
+    """json.Unmarshal fails with *json.SyntaxError, impl.Prove panics with it and the export marshals the error value
+    (gnark/libraries/prover/libprove.go:34-44): {"Offset":n}, n = bytes read when the scanner gave up (offending byte included;
+    len(data) at end of input).  Through Prove itself: the parse fails before anything touches a device."""
+    cases = [(b"{", 1), (b"", 0), (b"nul", 3), (b"nulx", 4), (b'{"cipher":"chacha20",}', 22), (b'{"a":1} x', 9), (b'{"a" 1}', 6), (b'["\q"]', 4), (b"[1,]", 4)]
+    for bad, off in cases:
+        assert json.loads(zk.prove_raw(bad)) == {"Offset": off}, bad
+        with pytest.raises(ValueError) as e:
+            zk.request_witness(bad)
+        assert json.loads(str(e.value)) == {"Offset": off}, bad
+
+
 def test_malformed_json_and_types_answer_with_empty_object(zk):
-    for bad in (b"{", b"[]", b'{"cipher": 5}', b'{"cipher":"chacha20","key":"!!!"}', b'{"cipher":"chacha20","blocks":[{"counter":-1}]}', b"null"):
+    for bad in (b"[]", b'{"cipher": 5}', b'{"cipher":"chacha20","key":"!!!"}', b'{"cipher":"chacha20","blocks":[{"counter":-1}]}', b"null"):
         with pytest.raises(ValueError) as e:
             zk.request_witness(bad)
         assert str(e.value) == "{}"

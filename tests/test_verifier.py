@@ -97,3 +97,35 @@ def test_vk_directory_fallback(zk, oracle, tmp_path, monkeypatch):
     assert zk.verify_raw(req) is False
     monkeypatch.setenv("ZKPROVE_VK_DIR", str(tmp_path))
     assert zk.verify_raw(req) is True
+
+
+def test_vk_files_beside_the_shared_object(zk, oracle, tmp_path):
+    """The reference embeds generated/vk.* in libverify at build time (gnark/libraries/verifier/impl/library.go:92-108), so the unchanged
+    JS `lib.verify` works with no set-up call.  Drop-in equivalent: with ZKPROVE_VK_DIR unset the library reads vk.<ext> from the
+    directory IT was loaded from (`make dropin` copies them beside bin/gnark/linux-x86_64-libverify.so).  Own process: a copy of the
+    library in a directory that holds the key, nothing initialised."""
+    import shutil
+    import subprocess
+    import sys
+    alg = 0
+    inst = H.make_instance(alg, H.SplitMix64(6))
+    proof, out, *_ = H.oracle_proof_bytes(alg, inst)
+    shutil.copy(zk.LIB_PATH, tmp_path / "linux-x86_64-libverify.so")
+    (tmp_path / "vk.chacha20").write_bytes(gf.vk_bytes(gf.vk_from_pk(H.oracle_pk(alg))))
+    (tmp_path / "req.json").write_bytes(json.dumps(_req(alg, inst, proof, out)).encode())
+    script = (
+        "import ctypes as C, sys\n"
+        "class GoSlice(C.Structure):\n"
+        "    _fields_ = [('data', C.c_void_p), ('len', C.c_longlong), ('cap', C.c_longlong)]\n"
+        "lib = C.CDLL(sys.argv[1] + '/linux-x86_64-libverify.so')\n"
+        "lib.Verify.restype = C.c_ubyte; lib.Verify.argtypes = [GoSlice]\n"
+        "b = open(sys.argv[1] + '/req.json', 'rb').read()\n"
+        "buf = C.create_string_buffer(b, len(b))\n"
+        "print('VERIFY', int(lib.Verify(GoSlice(C.cast(buf, C.c_void_p), len(b), len(b)))))\n")
+    env = {k: v for k, v in os.environ.items() if k != "ZKPROVE_VK_DIR"}
+    res = subprocess.run([sys.executable, "-c", script, str(tmp_path)], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert "VERIFY 1" in res.stdout, res.stdout[-500:]
+    os.remove(tmp_path / "vk.chacha20")                     # without the file: false, as before
+    res = subprocess.run([sys.executable, "-c", script, str(tmp_path)], env=env, capture_output=True, text=True, timeout=300)
+    assert "VERIFY 0" in res.stdout

@@ -89,6 +89,7 @@ _sig("zkp_bench_step", _i32, [_i32, _vp])
 _sig("zkp_bench_fetch", _i32, [_i32, _vp, _vp])
 _sig("zkp_bench_steps", _i32, [_i32, _i32, _vp])
 _sig("zkp_debug_fetch", _i32, [_i32, _vp, _vp])
+_sig("zkp_quotient_msm_info", _i32, [_i32, _vp])
 _sig("ZkpSetSplit", _i32, [_i32, _i32])
 _sig("zkp_split_partials", _i32, [_i32, _vp])
 _sig("zkp_split_finish", _i32, [_i32, _i32, _vp])

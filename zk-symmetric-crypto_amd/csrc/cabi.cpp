@@ -432,7 +432,9 @@ ProveReturn prove_one(GoSlice params, const U256 *r, const U256 *s, const U256 *
     try {
         Json j;
         std::string err;
-        if (!json_parse((const char *)params.data, (size_t)params.len, j, err)) panic_err();   // *json.SyntaxError -> {"Offset":n}; offsets are not reproduced
+        size_t off = 0;
+        // json.Unmarshal fails with *json.SyntaxError, impl.Prove panics with it and libprove.go:34-44 marshals it: {"Offset":n}
+        if (!json_parse((const char *)params.data, (size_t)params.len, j, err, &off)) throw Panic{"{\"Offset\":" + std::to_string(off) + "}"};
         Prepared p;
         prepare(j, p);
         if (!p.ok) throw Panic{p.panic};
@@ -469,7 +471,7 @@ int ZkpSetDevice(int device) {
     return 0;
 }
 // Split mode (one proof over several GPUs): this process is rank `rank` of `world`; call before InitAlgorithm.
-int g_split_rank = 0, g_split_world = 1;
+static int g_split_rank = 0, g_split_world = 1;
 int ZkpSetSplit(int rank, int world) {
     if (world < 1 || rank < 0 || rank >= world) return -1;
     g_split_rank = rank; g_split_world = world;
@@ -669,6 +671,22 @@ int zkp_split_finish(int id, int world, const uint8_t *gathered) {
     return 0;
     CABI_CATCH
 }
+// how the quotient MSM of the current resident batch runs: info[0] = 1 comb path (msm_comb.hip) / 0 bucket pipeline, [1] = clump size k
+// (comb) or window bits c (buckets), [2] = clumps (comb) or windows, [3] = table MiB, [4] = mixed additions per proof of its walk
+int zkp_quotient_msm_info(int id, long *info5) {
+    CABI_TRY
+    Algorithm *a = (id >= 0 && id < 3) ? get_alg(id) : nullptr;
+    if (!a || !a->res) throw ZkError("algorithm not initialised / nothing uploaded");
+    if (a->comb_active()) {
+        const CombBases &cb = a->pk.Zcomb;
+        info5[0] = 1; info5[1] = cb.k; info5[2] = (long)cb.nclumps; info5[3] = (long)(cb.table.bytes() >> 20); info5[4] = (long)cb.nclumps * 254;
+    } else {
+        const MsmBasesG1 &z = a->pk.Z;
+        info5[0] = 0; info5[1] = z.c; info5[2] = z.W; info5[3] = (long)(z.table.bytes() >> 20); info5[4] = (long)z.n * z.W;
+    }
+    return 0;
+    CABI_CATCH
+}
 int zkp_debug_fetch(int id, uint8_t *wires, uint8_t *h) {
     CABI_TRY
     Algorithm *a = (id >= 0 && id < 3) ? get_alg(id) : nullptr;
@@ -681,7 +699,8 @@ int zkp_request_witness(GoSlice params, uint32_t *inputs, long inputs_cap, uint8
     try {
         Json j;
         std::string err;
-        if (!json_parse((const char *)params.data, (size_t)params.len, j, err)) panic_err();
+        size_t off = 0;
+        if (!json_parse((const char *)params.data, (size_t)params.len, j, err, &off)) throw Panic{"{\"Offset\":" + std::to_string(off) + "}"};
         Request rq = decode_request(j);
         std::vector<uint32_t> w;
         std::vector<uint8_t> o;

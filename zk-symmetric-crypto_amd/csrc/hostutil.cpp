@@ -103,8 +103,17 @@ struct JP {
     const char *p, *e;
     std::string err;
     int depth = 0;
+    const char *errpos = nullptr;      // where the first error was detected (the offending byte, or e at end of input)
     void ws() { while (p < e && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) p++; }
-    bool fail(const char *m) { if (err.empty()) err = m; return false; }
+    bool fail(const char *m) { if (err.empty()) { err = m; errpos = p < e ? p : e; } return false; }
+    // a literal (null / true / false), byte by byte so that an error points at the first byte that differs, as Go's scanner does
+    bool lit(const char *w) {
+        for (; *w; w++, p++) {
+            if (p >= e) return fail("unexpected end of JSON input");
+            if (*p != *w) return fail("invalid character in literal");
+        }
+        return true;
+    }
     bool str(std::string &out) {
         if (p >= e || *p != '"') return fail("expected string");
         p++;
@@ -197,9 +206,9 @@ struct JP {
         } else if (*p == '"') {
             j.t = Json::STR;
             ok = str(j.s);
-        } else if (e - p >= 4 && !strncmp(p, "null", 4)) { j.t = Json::NUL; p += 4; }
-        else if (e - p >= 4 && !strncmp(p, "true", 4)) { j.t = Json::BOOL; j.b = true; p += 4; }
-        else if (e - p >= 5 && !strncmp(p, "false", 5)) { j.t = Json::BOOL; j.b = false; p += 5; }
+        } else if (*p == 'n') { j.t = Json::NUL; ok = lit("null"); }
+        else if (*p == 't') { j.t = Json::BOOL; j.b = true; ok = lit("true"); }
+        else if (*p == 'f') { j.t = Json::BOOL; j.b = false; ok = lit("false"); }
         else if (*p == '-' || (*p >= '0' && *p <= '9')) {
             const char *s0 = p;
             if (*p == '-') p++;
@@ -236,11 +245,13 @@ const Json *Json::get(const char *key) const {
     }
     return found;
 }
-bool json_parse(const char *p, size_t n, Json &out, std::string &err) {
+bool json_parse(const char *p, size_t n, Json &out, std::string &err, size_t *err_offset) {
     JP jp{p, p + n};
-    if (!jp.val(out)) { err = jp.err; return false; }
+    // Go's json.SyntaxError.Offset = bytes read when the scanner gave up: the offending byte included, len(data) at end of input
+    auto offset = [&](const char *at) { return at >= p + n ? n : (size_t)(at - p) + 1; };
+    if (!jp.val(out)) { err = jp.err; if (err_offset) *err_offset = offset(jp.errpos ? jp.errpos : jp.p); return false; }
     jp.ws();
-    if (jp.p != jp.e) { err = "invalid character after top-level value"; return false; }
+    if (jp.p != jp.e) { err = "invalid character after top-level value"; if (err_offset) *err_offset = offset(jp.p); return false; }
     return true;
 }
 std::string json_quote(const std::string &s) {

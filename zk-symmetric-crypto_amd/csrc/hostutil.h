@@ -27,8 +27,8 @@ struct Json {
     // Go's json.Unmarshal matches keys case-insensitively, preferring an exact match
     const Json *get(const char *key) const;
 };
-// returns false and fills err on malformed input
-bool json_parse(const char *p, size_t n, Json &out, std::string &err);
+// returns false and fills err on malformed input; err_offset (optional) = Go's json.SyntaxError.Offset for the same input
+bool json_parse(const char *p, size_t n, Json &out, std::string &err, size_t *err_offset = nullptr);
 std::string json_quote(const std::string &s);   // Go json.Marshal string escaping (HTML-safe form)
 
 // ---- ciphers (the reference computes the ciphertext itself: provers.go:139-150, 227-238) ----

@@ -6,6 +6,7 @@
 // per proof is not a GPU workload); BN254 ate pairing over the tower Fp12 = Fp2[w]/(w^6 - (9+u)).
 // The reference embeds its vk.* files at build time; here the verifying key is supplied with ZkpInitVerifier
 // (keys are synthetic in this repo).
+#include <dlfcn.h>
 #include <string.h>
 #include <memory>
 #include <mutex>
@@ -282,11 +283,22 @@ static bool verify_impl(const uint8_t *data, size_t len) {
     }
     std::unique_lock<std::mutex> lk(g_vk_lock);
     if (!g_vk[alg]) {
-        // the reference embeds generated/vk.* at build time (verifier/impl/library.go:92-160); the drop-in equivalent is a
-        // directory of the same files: $ZKPROVE_VK_DIR/vk.{chacha20,aes128,aes256}
+        // the reference embeds generated/vk.* at build time (verifier/impl/library.go:92-160), so its `Verify` works with no set-up call.
+        // The drop-in equivalent: the same files vk.{chacha20,aes128,aes256} in $ZKPROVE_VK_DIR or, when that is unset, in the directory
+        // this shared object was loaded from (`make dropin` puts them beside bin/gnark/linux-x86_64-libverify.so).
         static const char *EXT[3] = {"chacha20", "aes128", "aes256"};
-        if (const char *dir = getenv("ZKPROVE_VK_DIR")) {
-            std::string path = std::string(dir) + "/vk." + EXT[alg];
+        std::vector<std::string> dirs;
+        if (const char *dir = getenv("ZKPROVE_VK_DIR")) dirs.push_back(dir);
+        else {
+            Dl_info di;
+            if (dladdr((const void *)&verify_impl, &di) && di.dli_fname) {
+                std::string so = di.dli_fname;
+                const size_t slash = so.rfind('/');
+                dirs.push_back(slash == std::string::npos ? std::string(".") : so.substr(0, slash));
+            }
+        }
+        for (const std::string &dir : dirs) {
+            const std::string path = dir + "/vk." + EXT[alg];
             if (FILE *f = fopen(path.c_str(), "rb")) {
                 std::vector<uint8_t> buf;
                 uint8_t tmp[65536];
@@ -296,6 +308,7 @@ static bool verify_impl(const uint8_t *data, size_t len) {
                 std::unique_ptr<VerifyingKey> k(new VerifyingKey());
                 vk_parse(buf.data(), buf.size(), *k);
                 g_vk[alg] = std::move(k);
+                break;
             }
         }
     }
