@@ -215,6 +215,18 @@ for k in range(n):
     out = zk.request_witness(H.request_json(alg, insts[k]))[2]
     blocks = list(zip(insts[k]["nonces"], insts[k]["counters"]))
     ok += bool(base64.b64decode(res[k]["ciphertext"]) == out and zk.verify(H.CIPHER[alg], base64.b64decode(res[k]["proof"]), out, blocks, insts[k]["data"]))
+# a call large enough to be STREAMED (cabi.cpp prove_batch_json): chunks of ~n/(2 replicas x 2) pulled by both replicas from one feed
+m = {stream_n}
+insts2 = [H.make_instance(alg, rng) for _ in range(m)]
+res2 = json.loads(zk.prove_batch_raw(("[" + ",".join(H.request_json(alg, i).decode() for i in insts2) + "]").encode()))
+ok2 = 0
+for k in range(m):
+    out = zk.request_witness(H.request_json(alg, insts2[k]))[2]
+    good = base64.b64decode(res2[k]["ciphertext"]) == out
+    if k % 7 == 0 or k in (m - 1, m - 2):
+        blocks = list(zip(insts2[k]["nonces"], insts2[k]["counters"]))
+        good = good and zk.verify(H.CIPHER[alg], base64.b64decode(res2[k]["proof"]), out, blocks, insts2[k]["data"])
+    ok2 += bool(good)
 # Prove from a thread that never touched HIP before (Node's libuv pool, a goroutine's OS thread): the library binds the device itself
 box = []
 inst = insts[7]
@@ -222,7 +234,7 @@ t = threading.Thread(target=lambda: box.append(zk.prove_deterministic_raw(H.requ
 t.start(); t.join()
 exp, out, *_ = H.oracle_proof_bytes(alg, inst)
 got = json.loads(box[0])
-print(json.dumps(dict(replicas=nrep, verified=ok, n=n, thread_proof_matches_oracle=base64.b64decode(got["proof"]) == exp)))
+print(json.dumps(dict(replicas=nrep, verified=ok, n=n, streamed_ok=ok2, streamed_n=m, thread_proof_matches_oracle=base64.b64decode(got["proof"]) == exp)))
 """
 
 
@@ -234,11 +246,12 @@ def test_in_library_sharding_over_two_device_replicas(alg):
     of 300 proofs must verify against ITS request.  Also: Prove from a brand-new thread (hipSetDevice is per thread)."""
     env = dict(os.environ, ZKPROVE_DEVICES="0,0")
     env.pop("LOCAL_RANK", None)
-    res = subprocess.run([sys.executable, "-c", _SHARD_SCRIPT.format(root=H.ROOT, alg=alg)], env=env, capture_output=True, text=True, timeout=1200)
+    res = subprocess.run([sys.executable, "-c", _SHARD_SCRIPT.format(root=H.ROOT, alg=alg, stream_n=2500 if alg == 0 else 1300)], env=env, capture_output=True, text=True, timeout=1200)
     assert res.returncode == 0, res.stderr[-3000:]
     out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
     assert out["replicas"] == 2
     assert out["verified"] == out["n"] == 300
+    assert out["streamed_ok"] == out["streamed_n"]          # the streamed call: every ciphertext right, every 7th proof verified
     assert out["thread_proof_matches_oracle"]
 
 

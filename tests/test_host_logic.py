@@ -107,7 +107,7 @@ def test_syntax_errors_answer_with_the_offset_like_gos_json_syntax_error(zk):
     """json.Unmarshal fails with *json.SyntaxError, impl.Prove panics with it and the export marshals the error value
     (gnark/libraries/prover/libprove.go:34-44): {"Offset":n}, n = bytes read when the scanner gave up (offending byte included;
     len(data) at end of input).  Through Prove itself: the parse fails before anything touches a device."""
-    cases = [(b"{", 1), (b"", 0), (b"nul", 3), (b"nulx", 4), (b'{"cipher":"chacha20",}', 22), (b'{"a":1} x', 9), (b'{"a" 1}', 6), (b'["\q"]', 4), (b"[1,]", 4)]
+    cases = [(b"{", 1), (b"", 0), (b"nul", 3), (b"nulx", 4), (b'{"cipher":"chacha20",}', 22), (b'{"a":1} x', 9), (b'{"a" 1}', 6), (rb'["\q"]', 4), (b"[1,]", 4)]
     for bad, off in cases:
         assert json.loads(zk.prove_raw(bad)) == {"Offset": off}, bad
         with pytest.raises(ValueError) as e:
@@ -141,3 +141,19 @@ def test_proof_serialisation_matches_gnark_format(zk, oracle):
         rec = oracle.ints_to_le32([prf["Ar"][0], prf["Ar"][1], prf["Bs"][0][0], prf["Bs"][0][1], prf["Bs"][1][0], prf["Bs"][1][1],
                                    prf["Krs"][0], prf["Krs"][1], prf["commitment"][0], prf["commitment"][1], prf["pok"][0], prf["pok"][1]]).reshape(-1)
         assert zk.proof_serialize(rec, alg != 0) == pb
+
+
+def test_prove_batch_array_structure_and_per_element_answers(zk):
+    """ProveBatch (extension of the ABI): the array is cut into elements by a structural scanner, every element answers as Prove would;
+    nothing here reaches a device (no algorithm is initialised / no element is provable)."""
+    zk.lib.ZkpReset()
+    pb = lambda b: json.loads(zk.prove_batch_raw(b))
+    assert pb(b"[]") == [] and pb(b" [ ] ") == []
+    assert pb(b"[") == {"Offset": 1} and pb(b"") == {"Offset": 0} and pb(b"[1,]") == {"Offset": 4} and pb(b"[,1]") == {"Offset": 2}
+    assert pb(b'[{"a":"]"}') == {"Offset": 10} and pb(b"[1] x") == {"Offset": 5} and pb(b"[1}") == {"Offset": 3}
+    assert pb(b'{"cipher":"chacha20"}') == {} and pb(b"{") == {"Offset": 1}               # not an array: type error / syntax error
+    got = pb(b'[{"cipher":"rot13"}, 5, {"cipher":"chacha20","key":"!!!"}, {"cipher" "x"}, "a,]b", null]')
+    assert got[0] == "could not find prover forrot13" and got[1] == {} and got[2] == {} and got[5] == {}
+    assert got[3] == {"Offset": 70} and got[4] == {}          # the quote of "x" (index 69), counted in the whole call's bytes
+    # the decodable request names the algorithm: not initialised -> the reference's message, per element
+    assert pb(b"[" + _req() + b"," + _req() + b"]") == ["proving params are not initialized for cipher: chacha20"] * 2

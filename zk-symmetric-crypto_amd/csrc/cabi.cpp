@@ -9,6 +9,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <deque>
+#include <chrono>
 #include "../../include/zkprove.h"
 #include "prover.h"
 
@@ -427,6 +428,341 @@ std::string prove_coalesced(const Prepared &p) {
     return me.result;
 }
 
+// ------------------------------------------------------------------------------------------- ProveBatch
+// Extension of the reference's ABI (not in libprove.go): a JSON array of Prove requests -> a JSON array of responses, element i
+// answering request i exactly as Prove would (js/src/zk.ts:94-177 proves the chunks of a transcript one by one; a batch entry lets
+// one call keep the GPU full).  Host work is pipelined against the device: the array is cut into elements by a scanner that only
+// tracks strings and nesting, every element is then parsed / decoded / packed by a pool of host threads chunk by chunk, device
+// replicas pull chunks as they become ready (dynamic sharing between GPUs), and a third stage serialises finished chunks -- so for
+// large arrays the host phases hide under the device phase instead of bracketing it.
+
+// boundaries [lo, hi) of the elements of the top-level array; false + Go's SyntaxError offset on malformed structure.
+// not_array: the top-level value is something else (decoded like json.Unmarshal into a slice: type error -> {})
+bool split_array(const char *p, size_t n, std::vector<std::pair<size_t, size_t>> &el, size_t &err_off, bool &not_array) {
+    size_t i = 0;
+    not_array = false;
+    auto ws = [&] { while (i < n && (p[i] == ' ' || p[i] == '\t' || p[i] == '\n' || p[i] == '\r')) i++; };
+    ws();
+    if (i >= n) { err_off = n; return false; }
+    if (p[i] != '[') { not_array = true; return false; }
+    i++;
+    ws();
+    if (i < n && p[i] == ']') {
+        i++; ws();
+        if (i != n) { err_off = i + 1; return false; }
+        return true;
+    }
+    for (;;) {
+        ws();
+        const size_t lo = i;
+        int depth = 0;
+        bool in_str = false;
+        for (; i < n; i++) {
+            const char c = p[i];
+            if (in_str) {
+                if (c == '\\') i++;
+                else if (c == '"') in_str = false;
+                continue;
+            }
+            if (c == '"') in_str = true;
+            else if (c == '{' || c == '[') depth++;
+            else if (c == '}' || c == ']') { if (depth == 0) break; depth--; }
+            else if (c == ',' && depth == 0) break;
+        }
+        if (i >= n) { err_off = n; return false; }               // unexpected end of JSON input
+        size_t hi = i;
+        while (hi > lo && (p[hi - 1] == ' ' || p[hi - 1] == '\t' || p[hi - 1] == '\n' || p[hi - 1] == '\r')) hi--;
+        if (hi == lo || p[i] == '}') { err_off = i + 1; return false; }      // "[1,]" / "[,1]" / stray '}': invalid character
+        el.emplace_back(lo, hi);
+        if (p[i] == ',') { i++; continue; }
+        i++;                                                      // ']'
+        ws();
+        if (i != n) { err_off = i + 1; return false; }
+        return true;
+    }
+}
+// element [lo, hi) of the request array -> Prepared (a syntax error inside the element answers like Prove: {"Offset": position in the call's bytes})
+void prepare_element(const char *data, const std::pair<size_t, size_t> &e, Prepared &p) {
+    Json j;
+    std::string err;
+    size_t off = 0;
+    if (!json_parse(data + e.first, e.second - e.first, j, err, &off)) { p.panic = "{\"Offset\":" + std::to_string(e.first + off) + "}"; return; }
+    prepare(j, p);
+}
+
+// pinned host staging of one device chunk (the async copies of Algorithm::prove_stream are only asynchronous from pinned memory)
+struct ChunkBuf {
+    size_t cap = 0, ni = 0;
+    uint32_t *inputs = nullptr;
+    U256 *r = nullptr, *s = nullptr, *rnd = nullptr;
+    ProofPoints *pp = nullptr;
+    uint32_t *errs = nullptr;
+    void alloc(size_t items, size_t n_inputs) {
+        cap = items; ni = n_inputs;
+        ZK_HIP(hipHostMalloc((void **)&inputs, items * n_inputs * sizeof(uint32_t), hipHostMallocDefault));
+        ZK_HIP(hipHostMalloc((void **)&r, 3 * items * sizeof(U256), hipHostMallocDefault));
+        s = r + items; rnd = s + items;
+        ZK_HIP(hipHostMalloc((void **)&pp, items * sizeof(ProofPoints), hipHostMallocDefault));
+        ZK_HIP(hipHostMalloc((void **)&errs, items * sizeof(uint32_t), hipHostMallocDefault));
+    }
+    void release() {
+        if (inputs) (void)hipHostFree(inputs);
+        if (r) (void)hipHostFree(r);
+        if (pp) (void)hipHostFree(pp);
+        if (errs) (void)hipHostFree(errs);
+        inputs = nullptr; r = nullptr; pp = nullptr; errs = nullptr; cap = 0;
+    }
+};
+// buffers are kept between calls (pinning 10 MB costs about a millisecond per buffer)
+struct ChunkBufPool {
+    std::mutex m;
+    std::vector<ChunkBuf> free_list;
+    ChunkBuf take(size_t items, size_t ni) {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            for (size_t i = 0; i < free_list.size(); i++)
+                if (free_list[i].cap >= items && free_list[i].ni == ni) { ChunkBuf b = free_list[i]; free_list.erase(free_list.begin() + i); return b; }
+        }
+        ChunkBuf b;
+        b.alloc(items, ni);
+        return b;
+    }
+    void give(ChunkBuf b) {
+        std::lock_guard<std::mutex> lk(m);
+        if (free_list.size() < 24) free_list.push_back(b); else b.release();
+    }
+    void clear() {
+        std::lock_guard<std::mutex> lk(m);
+        for (auto &b : free_list) b.release();
+        free_list.clear();
+    }
+};
+ChunkBufPool g_chunk_pool;
+
+// optional timeline of a streamed call (ZKPROVE_TIMELINE=<file>: one JSON line per event, microseconds since the call started)
+struct Timeline {
+    std::mutex m;
+    std::vector<std::string> lines;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    const char *path = getenv("ZKPROVE_TIMELINE");
+    void add(const char *stage, size_t chunk, int who, const char *edge) {
+        if (!path) return;
+        const long us = (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+        char buf[160];
+        snprintf(buf, sizeof(buf), "{\"us\":%ld,\"stage\":\"%s\",\"chunk\":%zu,\"who\":%d,\"edge\":\"%s\"}", us, stage, chunk, who, edge);
+        std::lock_guard<std::mutex> lk(m);
+        lines.push_back(buf);
+    }
+    void dump() {
+        if (!path) return;
+        if (FILE *f = fopen(path, "a")) { for (auto &l : lines) fprintf(f, "%s\n", l.c_str()); fclose(f); }
+    }
+};
+
+struct StreamChunk {
+    size_t id = 0, lo = 0, hi = 0;              // requests [lo, hi) of the call
+    std::vector<Prepared> prep;                 // hi - lo
+    std::vector<size_t> idx;                    // positions (relative to lo) of the requests that go to the device
+    ChunkBuf buf;
+};
+// the feed shared by the device replicas of one streamed call
+struct StreamFeed : ChunkFeed {
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<StreamChunk *> ready, finished;
+    bool prep_done = false, aborted = false;
+    size_t outstanding = 0;                     // chunks that hold a pinned buffer (prepared, on a device, or waiting to be serialised)
+    Timeline *tl = nullptr;
+    // per-thread identity of the replica pulling (timeline only)
+    bool next(Chunk &c) override {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return !ready.empty() || prep_done || aborted; });
+        if (aborted || ready.empty()) return false;
+        StreamChunk *sc = ready.front();
+        ready.pop_front();
+        lk.unlock();
+        c.id = (size_t)(uintptr_t)sc;           // opaque: handed back through done()
+        c.count = sc->idx.size();
+        c.inputs = sc->buf.inputs; c.r = sc->buf.r; c.s = sc->buf.s; c.rnd = sc->buf.rnd; c.out = sc->buf.pp; c.errs = sc->buf.errs;
+        if (tl) tl->add("device", sc->id, 0, "begin");
+        return true;
+    }
+    void done(const Chunk &c) override {
+        StreamChunk *sc = (StreamChunk *)(uintptr_t)c.id;
+        if (tl) tl->add("device", sc->id, 0, "end");
+        std::lock_guard<std::mutex> lk(m);
+        finished.push_back(sc);
+        cv.notify_all();
+    }
+};
+
+std::string prove_batch_json(const char *data, size_t len) {
+    std::string result;
+    try {
+        std::vector<std::pair<size_t, size_t>> el;
+        size_t off = 0;
+        bool not_array = false;
+        if (!split_array(data, len, el, off, not_array)) {
+            if (not_array) {           // a syntactically valid non-array answers {} (type error); a malformed one its offset
+                Json j; std::string err;
+                if (json_parse(data, len, j, err, &off)) panic_err();
+            }
+            throw Panic{"{\"Offset\":" + std::to_string(off) + "}"};
+        }
+        const size_t n = el.size();
+        std::vector<std::string> res(n);
+        // the cipher of the first decodable request names the algorithm (all requests of a call must share it) and with it the replicas
+        int alg = -1;
+        for (size_t i = 0; i < n && alg < 0; i++) {
+            Json j; std::string err;
+            if (!json_parse(data + el[i].first, el[i].second - el[i].first, j, err)) continue;
+            try { alg = decode_request(j).alg; } catch (const Panic &) {}
+        }
+        const std::vector<Algorithm *> reps = alg >= 0 ? get_replicas(alg) : std::vector<Algorithm *>();
+        const size_t max_chunk = reps.empty() ? 1024 : reps[0]->max_chunk;
+        if (reps.empty() || n <= max_chunk) {
+            // small call (or nothing provable): one device batch per replica, no streaming
+            std::vector<Prepared> prep(n);
+            parallel_for(n, [&](size_t i) { prepare_element(data, el[i], prep[i]); });
+            std::vector<const Prepared *> items;
+            std::vector<size_t> idx;
+            for (size_t i = 0; i < n; i++) {
+                if (!prep[i].ok) { res[i] = prep[i].panic; continue; }      // one bad request does not poison the batch
+                if (prep[i].rq.alg != alg) { res[i] = json_quote("ProveBatch: all requests must use the same cipher"); continue; }
+                items.push_back(&prep[i]);
+                idx.push_back(i);
+            }
+            if (!items.empty()) {
+                try {
+                    auto out = prove_prepared(alg, items, nullptr, nullptr, nullptr);
+                    for (size_t k = 0; k < idx.size(); k++) res[idx[k]] = std::move(out[k]);
+                } catch (const Panic &p) {
+                    for (size_t k = 0; k < idx.size(); k++) res[idx[k]] = p.json;
+                }
+            }
+        } else {
+            // streamed call.  Chunk size: the device chunk, cut down when that would leave replicas without work
+            const size_t nrep = reps.size(), ni = reps[0]->n_inputs();
+            size_t chunk = max_chunk;
+            if (nrep > 1) chunk = std::min(max_chunk, std::max<size_t>(MIN_SHARD, (n + 2 * nrep - 1) / (2 * nrep)));
+            const size_t nchunks = (n + chunk - 1) / chunk;
+            std::vector<StreamChunk> chunks(nchunks);
+            Timeline tl;
+            StreamFeed feed;
+            feed.tl = &tl;
+            const size_t max_outstanding = 3 * nrep + 3;
+            const bool has_commit = reps[0]->has_commit;
+            std::exception_ptr first_error;
+            std::mutex err_lock;
+            auto fail = [&](std::exception_ptr e) {
+                { std::lock_guard<std::mutex> lk(err_lock); if (!first_error) first_error = e; }
+                std::lock_guard<std::mutex> lk(feed.m);
+                feed.aborted = true;
+                feed.cv.notify_all();
+            };
+            // stage 1: decode + pack, chunk by chunk, in request order
+            std::thread prep_thread([&] {
+                try {
+                    bind_device(reps[0]->device);                   // hipHostMalloc needs a device context
+                    for (size_t k = 0; k < nchunks; k++) {
+                        StreamChunk &sc = chunks[k];
+                        sc.id = k; sc.lo = k * chunk; sc.hi = std::min(n, sc.lo + chunk);
+                        {
+                            std::unique_lock<std::mutex> lk(feed.m);
+                            feed.cv.wait(lk, [&] { return feed.outstanding < max_outstanding || feed.aborted; });
+                            if (feed.aborted) break;
+                        }
+                        tl.add("prepare", k, -1, "begin");
+                        const size_t cnt = sc.hi - sc.lo;
+                        sc.prep.resize(cnt);
+                        parallel_for(cnt, [&](size_t i) { prepare_element(data, el[sc.lo + i], sc.prep[i]); });
+                        for (size_t i = 0; i < cnt; i++) {
+                            if (!sc.prep[i].ok) res[sc.lo + i] = sc.prep[i].panic;
+                            else if (sc.prep[i].rq.alg != alg) res[sc.lo + i] = json_quote("ProveBatch: all requests must use the same cipher");
+                            else if (sc.prep[i].w.size() != ni) res[sc.lo + i] = "{}";
+                            else sc.idx.push_back(i);
+                        }
+                        if (sc.idx.empty()) { tl.add("prepare", k, -1, "end"); continue; }
+                        sc.buf = g_chunk_pool.take(chunk, ni);
+                        const size_t m = sc.idx.size();
+                        parallel_for(m, [&](size_t q) { memcpy(sc.buf.inputs + q * ni, sc.prep[sc.idx[q]].w.data(), ni * 4); });
+                        fr_random_fill(sc.buf.r, 3 * sc.buf.cap);           // r, s and the Randomize values: one entropy read per chunk
+                        tl.add("prepare", k, -1, "end");
+                        std::lock_guard<std::mutex> lk(feed.m);
+                        feed.outstanding++;
+                        feed.ready.push_back(&sc);
+                        feed.cv.notify_all();
+                    }
+                } catch (...) { fail(std::current_exception()); }
+                std::lock_guard<std::mutex> lk(feed.m);
+                feed.prep_done = true;
+                feed.cv.notify_all();
+            });
+            // stage 3: responses of finished chunks
+            bool devices_done = false;
+            std::thread ser_thread([&] {
+                try {
+                    for (;;) {
+                        StreamChunk *sc = nullptr;
+                        {
+                            std::unique_lock<std::mutex> lk(feed.m);
+                            feed.cv.wait(lk, [&] { return !feed.finished.empty() || devices_done; });
+                            if (feed.finished.empty()) break;
+                            sc = feed.finished.front();
+                            feed.finished.pop_front();
+                        }
+                        tl.add("serialise", sc->id, -2, "begin");
+                        parallel_for(sc->idx.size(), [&](size_t q) {
+                            const size_t i = sc->idx[q];
+                            res[sc->lo + i] = sc->buf.errs[q] ? std::string("{}")       // groth16.Prove returned an error -> panic(err) -> {}
+                                                              : response_json(proof_serialize(sc->buf.pp[q], has_commit), sc->prep[i].out);
+                        });
+                        g_chunk_pool.give(sc->buf);
+                        sc->buf = ChunkBuf();
+                        std::vector<Prepared>().swap(sc->prep);
+                        tl.add("serialise", sc->id, -2, "end");
+                        std::lock_guard<std::mutex> lk(feed.m);
+                        feed.outstanding--;
+                        feed.cv.notify_all();
+                    }
+                } catch (...) { fail(std::current_exception()); }
+            });
+            // stage 2: every replica pulls chunks until the feed is dry
+            auto run = [&](size_t r) {
+                try { reps[r]->prove_stream(feed); } catch (...) { fail(std::current_exception()); }
+            };
+            std::vector<std::thread> th;
+            const size_t nrun = std::min(nrep, nchunks);
+            for (size_t r = 1; r < nrun; r++) th.emplace_back(run, r);
+            run(0);
+            for (auto &t : th) t.join();
+            prep_thread.join();
+            { std::lock_guard<std::mutex> lk(feed.m); devices_done = true; feed.cv.notify_all(); }
+            ser_thread.join();
+            tl.dump();
+            for (auto &sc : chunks) if (sc.buf.cap) { g_chunk_pool.give(sc.buf); sc.buf = ChunkBuf(); }
+            if (first_error) {
+                // requests that did not get an answer take the failure's value (a modelled panic, else a Go error object)
+                std::string v = "{}";
+                try { std::rethrow_exception(first_error); } catch (const Panic &p) { v = p.json; } catch (const std::exception &e) { fprintf(stderr, "zkprove: %s\n", e.what()); } catch (...) {}
+                for (auto &r : res) if (r.empty()) r = v;
+            }
+        }
+        size_t total = 2 + n;
+        for (auto &r : res) total += r.size();
+        result.reserve(total);
+        result = "[";
+        for (size_t i = 0; i < n; i++) { if (i) result += ","; result += res[i]; }
+        result += "]";
+    } catch (const Panic &p) {
+        result = p.json;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "zkprove: %s\n", e.what());
+        result = "{}";
+    }
+    return result;
+}
+
 ProveReturn prove_one(GoSlice params, const U256 *r, const U256 *s, const U256 *rnd) {
     std::string result;
     try {
@@ -486,6 +822,7 @@ void ZkpReset(void) {
         std::lock_guard<std::mutex> lk(s.lock);
         s.replicas.clear();
     }
+    g_chunk_pool.clear();
     std::lock_guard<std::mutex> lk(g_dev_lock);
     g_device_list.clear();                  // ZKPROVE_DEVICES / ZkpSetDevice are read again by the next InitAlgorithm
 }
@@ -556,45 +893,7 @@ ProveReturn ZkpProveDeterministic(GoSlice params, const uint8_t *r32, const uint
     return prove_one(params, &r, &s, &rnd);
 }
 
-ProveReturn ProveBatch(GoSlice params) {
-    std::string result;
-    try {
-        Json j;
-        std::string err;
-        if (!json_parse((const char *)params.data, (size_t)params.len, j, err) || j.t != Json::ARR) panic_err();
-        const size_t n = j.a.size();
-        std::vector<std::string> res(n);
-        std::vector<Prepared> prep(n);
-        parallel_for(n, [&](size_t i) { prepare(j.a[i], prep[i]); });
-        std::vector<const Prepared *> items;
-        std::vector<size_t> idx;
-        int alg = -1;
-        for (size_t i = 0; i < n; i++) {
-            if (!prep[i].ok) { res[i] = prep[i].panic; continue; }      // one bad request does not poison the batch
-            if (alg < 0) alg = prep[i].rq.alg;
-            if (prep[i].rq.alg != alg) { res[i] = json_quote("ProveBatch: all requests must use the same cipher"); continue; }
-            items.push_back(&prep[i]);
-            idx.push_back(i);
-        }
-        if (!items.empty()) {
-            try {
-                auto out = prove_prepared(alg, items, nullptr, nullptr, nullptr);
-                for (size_t k = 0; k < idx.size(); k++) res[idx[k]] = std::move(out[k]);
-            } catch (const Panic &p) {
-                for (size_t k = 0; k < idx.size(); k++) res[idx[k]] = p.json;
-            }
-        }
-        result = "[";
-        for (size_t i = 0; i < n; i++) { if (i) result += ","; result += res[i]; }
-        result += "]";
-    } catch (const Panic &p) {
-        result = p.json;
-    } catch (const std::exception &e) {
-        fprintf(stderr, "zkprove: %s\n", e.what());
-        result = "{}";
-    }
-    return make_return(result);
-}
+ProveReturn ProveBatch(GoSlice params) { return make_return(prove_batch_json((const char *)params.data, (size_t)params.len)); }
 
 ProveReturn GenerateOPRFRequestData(GoSlice) { return make_return(json_quote("toprf is not supported by libzkprove")); }
 ProveReturn TOPRFFinalize(GoSlice) { return make_return(json_quote("toprf is not supported by libzkprove")); }

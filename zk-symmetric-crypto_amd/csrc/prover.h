@@ -38,6 +38,22 @@ struct PhaseTimes {   // milliseconds, device time measured with HIP events on t
     float z_segments = 0;   // the dominant kernel alone: k_msm_accumulate<Fp, true> of the quotient MSM
 };
 
+// Source / sink of the device chunks of a streamed batch (Algorithm::prove_stream): the host side hands over chunks as it finishes
+// preparing them and takes the proofs back chunk by chunk, so request decoding / witness packing of later chunks and the proof
+// serialisation of earlier ones overlap the device work (cabi.cpp, ProveBatch).
+struct ChunkFeed {
+    struct Chunk {
+        size_t id = 0, count = 0;                 // count <= Algorithm::max_chunk
+        const uint32_t *inputs = nullptr;         // [count][n_inputs]
+        const U256 *r = nullptr, *s = nullptr, *rnd = nullptr;
+        ProofPoints *out = nullptr;               // [count], written before done()
+        uint32_t *errs = nullptr;
+    };
+    virtual bool next(Chunk &c) = 0;              // blocks until the next chunk is ready; false: no more chunks
+    virtual void done(const Chunk &c) = 0;        // the chunk's proofs and solver error words have been written
+    virtual ~ChunkFeed() {}
+};
+
 class Algorithm {
    public:
     R1cs cs;
@@ -65,6 +81,9 @@ class Algorithm {
     // (0 = ok).  Work is processed in chunks of at most `chunk` instances.
     void prove_batch(size_t batch, const uint32_t *inputs, const U256 *r, const U256 *s, const U256 *randomize, ProofPoints *out,
                      uint32_t *errs, PhaseTimes *times = nullptr);
+
+    // the same over chunks pulled from a feed (several replicas may pull from one feed: dynamic sharing of a batch between devices)
+    void prove_stream(ChunkFeed &feed, PhaseTimes *times = nullptr);
 
     // device-resident variant for the benchmark: inputs already in HBM as [n_inputs][B] (see bench.py)
     struct Resident;

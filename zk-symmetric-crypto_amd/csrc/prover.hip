@@ -999,7 +999,7 @@ void Algorithm::resident_download(ProofPoints *out, uint32_t *errs) {
 // with the uploads / downloads on a copy stream, so callers of ProveBatch see the pipelined rate.
 void Algorithm::prove_batch(size_t batch, const uint32_t *inputs, const U256 *r, const U256 *s, const U256 *randomize, ProofPoints *out,
                             uint32_t *errs, PhaseTimes *times) {
-    std::lock_guard<std::mutex> lk(mu);
+    std::unique_lock<std::mutex> lk(mu);
     bind_device(device);
     const size_t ni = prog.n_inputs;
     const size_t nchunks = (batch + max_chunk - 1) / max_chunk;
@@ -1011,6 +1011,33 @@ void Algorithm::prove_batch(size_t batch, const uint32_t *inputs, const U256 *r,
         if (times) *times = t;
         return;
     }
+    // more than one chunk: stream them from the caller's arrays
+    struct ArrayFeed : ChunkFeed {
+        size_t batch, chunk, ni, k = 0;
+        const uint32_t *inputs; const U256 *r, *s, *rnd; ProofPoints *out; uint32_t *errs;
+        bool next(Chunk &c) override {
+            const size_t off = k * chunk;
+            if (off >= batch) return false;
+            c.id = k++; c.count = std::min(chunk, batch - off);
+            c.inputs = inputs + off * ni; c.r = r + off; c.s = s + off; c.rnd = rnd ? rnd + off : nullptr;
+            c.out = out + off; c.errs = errs ? errs + off : nullptr;
+            return true;
+        }
+        void done(const Chunk &) override {}
+    } feed;
+    feed.batch = batch; feed.chunk = max_chunk; feed.ni = ni;
+    feed.inputs = inputs; feed.r = r; feed.s = s; feed.rnd = randomize; feed.out = out; feed.errs = errs;
+    lk.unlock();
+    prove_stream(feed, times);
+}
+
+// Chunks of at most max_chunk instances, software-pipelined exactly as resident_prove_pipelined does with repeated passes (solve stage,
+// transforms and the quotient MSM's ahead-prepared data of chunk k+1 and the tail of chunk k-1 under the MSM stage of chunk k), uploads
+// and downloads on the copy stream.  The feed is asked for chunk k only after chunk k-NS has been handed back.
+void Algorithm::prove_stream(ChunkFeed &feed, PhaseTimes *times) {
+    std::lock_guard<std::mutex> lk(mu);
+    bind_device(device);
+    const size_t ni = prog.n_inputs;
     resident_reserve(max_chunk);
     Resident &R = *res;
     // two working sets; three when chunks are prepared ahead (as in resident_prove_pipelined: the side chain of chunk k then runs beside
@@ -1019,43 +1046,53 @@ void Algorithm::prove_batch(size_t batch, const uint32_t *inputs, const U256 *r,
     const size_t NS = (ahead_eligible() && depth_env >= 2) ? 3 : 2;
     ensure_second_set((int)NS);
     hipStream_t M = R.stream, S = R.stream2, F = R.stream3, C = R.copy_stream;
-    auto chunk_size = [&](size_t k) { return std::min(max_chunk, batch - k * max_chunk); };
-    auto download = [&](size_t k) {           // chunk k lives in set k % NS; waits for its tail, not for the whole pipeline
+    ChunkFeed::Chunk held[3];
+    // chunk k lives in set k % NS.  The host waits for ITS tail only (event), then copies on the null stream: none of the prover's
+    // (non-blocking) streams is synchronised or gets the copies queued behind the ahead work of later chunks.
+    auto download = [&](size_t k) {
         SolveSet &cur = R.set[k % NS];
-        const size_t off = k * max_chunk, Bk = chunk_size(k);
-        ZK_HIP(hipStreamWaitEvent(C, cur.consumed, 0));
-        ZK_HIP(hipMemcpyAsync(out + off, cur.out.p, Bk * sizeof(ProofPoints), hipMemcpyDeviceToHost, C));
-        if (errs) ZK_HIP(hipMemcpyAsync(errs + off, cur.sb.err.p, Bk * sizeof(uint32_t), hipMemcpyDeviceToHost, C));
-        ZK_HIP(hipStreamSynchronize(C));
+        const ChunkFeed::Chunk &c = held[k % NS];
+        ZK_HIP(hipEventSynchronize(cur.consumed));
+        ZK_HIP(hipMemcpy(c.out, cur.out.p, c.count * sizeof(ProofPoints), hipMemcpyDeviceToHost));
+        if (c.errs) ZK_HIP(hipMemcpy(c.errs, cur.sb.err.p, c.count * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        feed.done(c);
     };
     ZK_HIP(hipEventRecord(R.ev[0], M));
-    for (size_t k = 0; k < nchunks; k++) {
-        SolveSet &cur = R.set[k % NS];
+    size_t k = 0;
+    for (;; k++) {
         if (k >= NS) download(k - NS);          // also guarantees that the set is free again
-        const size_t off = k * max_chunk, Bk = chunk_size(k);
+        ChunkFeed::Chunk c;
+        if (!feed.next(c)) break;
+        if (c.count == 0 || c.count > max_chunk) throw ZkError("prove_stream: bad chunk size");
+        SolveSet &cur = R.set[k % NS];
+        held[k % NS] = c;
+        const size_t Bk = c.count;
         R.B = Bk; cur.sb.B = Bk; R.ms.B = Bk; R.ms2.B = Bk;
-        upload_set(cur, Bk, inputs + off * ni, r + off, s + off, randomize ? randomize + off : nullptr, C);
-        ZK_HIP(hipEventRecord(cur.uploaded, C));
-        ZK_HIP(hipStreamWaitEvent(S, cur.uploaded, 0));
+        // inputs go up on the solve stream itself (the set is free: its previous chunk has been downloaded); the copy stream carries
+        // the ahead-prepared patterns / sort of earlier chunks, which wait for other streams
+        upload_set(cur, Bk, c.inputs, c.r, c.s, c.rnd, S);
         enqueue_solve(cur, has_commit ? R.ms2 : R.ms, S);
         ZK_HIP(hipEventRecord(cur.solved, S));
         if (ahead_eligible()) enqueue_ntt_sort(cur, S, (int)(k & 1), k >= 2 ? R.set[(k - 2) % NS].zdone : nullptr);
         ZK_HIP(hipStreamWaitEvent(M, cur.solved, 0));
         enqueue_main(cur, M, k ? R.ev[11] : nullptr, F);
+        ZK_HIP(hipEventRecord(cur.zdone, M));
         ZK_HIP(hipEventRecord(R.ev[10], M));
         ZK_HIP(hipStreamWaitEvent(F, R.ev[10], 0));
         enqueue_finalize(cur, F);
         ZK_HIP(hipEventRecord(R.ev[11], F));
         ZK_HIP(hipEventRecord(cur.consumed, F));
     }
-    for (size_t k = nchunks > NS ? nchunks - NS : 0; k < nchunks; k++) download(k);
+    // k chunks were enqueued; those before k - NS (and k - NS itself, by the last loop pass) are already back
+    for (size_t j = k >= NS ? k - NS + 1 : 0; j < k; j++) download(j);
     ZK_HIP(hipStreamSynchronize(S));
+    ZK_HIP(hipStreamSynchronize(C));
     ZK_HIP(hipStreamSynchronize(M));
     ZK_HIP(hipStreamSynchronize(F));
-    R.last_set = (int)((nchunks - 1) % NS);
-    if (times) {
+    if (k) R.last_set = (int)((k - 1) % NS);
+    if (times && k) {
         PhaseTimes t;
-        collect_times(R.set[(nchunks - 1) % NS], &t);
+        collect_times(R.set[(k - 1) % NS], &t);
         float tot;
         ZK_HIP(hipEventElapsedTime(&tot, R.ev[0], R.ev[7]));
         t.total = tot;
