@@ -53,6 +53,12 @@ void VFree(void *pointer);
 ProveReturn OPRFEvaluate(GoSlice params);
 ProveReturn GenerateThresholdKeys(GoSlice params);
 unsigned char ZkpInitVerifier(unsigned char algorithmID, GoSlice vk);
+/* Extension: JSON array of Verify requests -> JSON array of booleans (element i answers request i as Verify would).  The requests of
+ * one circuit are checked together on the GPU: one pairing-product equation under random 128-bit coefficients (two MSM-like sums over
+ * the proofs' points, kSum as a batched MSM over vk.K, one Miller loop per proof on the device, one final exponentiation on the host);
+ * a batch that fails is re-checked proof by proof.  Free the result with VFree.  (verifier/impl/verifiers.go:73-89,142-158 per proof) */
+ProveReturn VerifyBatch(GoSlice params);
+ProveReturn zkp_verify_batch_timed(GoSlice params, double *device_ms);
 
 /* ---------------------------------------------------------------- 2. extensions */
 /* Accept proving keys whose SHA-256 differs from the pinned KeyHash (impl/library.go:37,42,47).

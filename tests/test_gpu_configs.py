@@ -193,6 +193,46 @@ def test_config4_all_65536_proofs_eight_rank_streams(zk, oracle):
     assert total == 65536 and len(seen) == 65536
     zk.lib.ZkpReset()
 
+@pytest.mark.parametrize("alg,B", [(0, 1024), (1, 160)])
+def test_verify_batch_on_the_gpu_agrees_with_verify(zk, oracle, alg, B):
+    """VerifyBatch (csrc/verifier.cpp): the requests of a circuit are checked with one pairing-product equation under random
+    coefficients -- decompression, G2 subgroup checks, kSum as a batched MSM over vk.K, the BSB22 challenges and one Miller loop per
+    proof on the device, one final exponentiation on the host.  A valid batch answers all-true from the device check alone; a batch
+    with tampered members falls back to per-proof verification and answers exactly as Verify does (verifier/impl/verifiers.go:73-89,
+    142-158); malformed and foreign elements answer false without disturbing the others."""
+    _fresh(zk, alg)
+    rng = H.SplitMix64(0x5EED0000 + 90 + alg)
+    insts = [H.make_instance(alg, rng) for _ in range(B)]
+    wits, outs = [], []
+    for inst in insts:
+        _, w, out = zk.request_witness(H.request_json(alg, inst))
+        wits.append(w); outs.append(out)
+    rb = zk.ResidentBatch(alg, np.array(wits, np.uint32), [i["r"] for i in insts], [i["s"] for i in insts], [i["randomize"] for i in insts])
+    rb.step()
+    proofs, errs = rb.fetch()
+    assert not errs.any()
+    ser = [zk.proof_serialize(proofs[k], alg != 0) for k in range(B)]
+    reqs = [zk.verify_request(H.CIPHER[alg], ser[k], outs[k], list(zip(insts[k]["nonces"], insts[k]["counters"])), insts[k]["data"]) for k in range(B)]
+    res, ms = zk.verify_batch_raw(json.dumps(reqs).encode(), timed=True)
+    assert res == [True] * B and ms > 0, "device batch check declined or failed: %s" % [k for k, v in enumerate(res) if not v][:10]
+    print("verify_batch alg %d: %d proofs, device %.1f ms" % (alg, B, ms))
+    # tampered members: a proof under its neighbour's public inputs, a flipped ciphertext byte, a proof with A and Krs swapped
+    bad = [dict(r) for r in reqs]
+    bad[3] = dict(reqs[3], proof=reqs[4]["proof"])
+    ct = bytearray(outs[7]); ct[0] ^= 1
+    bad[7] = zk.verify_request(H.CIPHER[alg], ser[7], bytes(ct), list(zip(insts[7]["nonces"], insts[7]["counters"])), insts[7]["data"])
+    sw = bytearray(ser[B - 1]); sw[0:32], sw[96:128] = ser[B - 1][96:128], ser[B - 1][0:32]
+    bad[B - 1] = zk.verify_request(H.CIPHER[alg], bytes(sw), outs[B - 1], list(zip(insts[B - 1]["nonces"], insts[B - 1]["counters"])), insts[B - 1]["data"])
+    expect = [zk.verify_raw(json.dumps(r).encode()) for r in (bad[3], bad[7], bad[B - 1])]
+    assert expect == [False, False, False]
+    res = zk.verify_batch_raw(json.dumps(bad).encode())
+    assert res == [k not in (3, 7, B - 1) for k in range(B)]
+    # malformed / foreign elements
+    mixed = [reqs[0], 5, {"cipher": "rot13"}, reqs[1], {"cipher": H.CIPHER[alg], "proof": "AAAA", "publicSignals": {}}] + reqs[2:20]
+    assert zk.verify_batch_raw(json.dumps(mixed).encode()) == [True, False, False, True, False] + [True] * 18
+    assert zk.verify_batch_raw(b"[]") == [] and zk.verify_batch_raw(b"{") == []
+    zk.lib.ZkpReset()
+
 _SHARD_SCRIPT = r"""
 import base64, importlib, json, os, sys, threading
 sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))

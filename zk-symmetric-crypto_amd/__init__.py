@@ -82,6 +82,9 @@ _sig("TOPRFFinalize", ProveReturn, [GoSlice])
 _sig("ZkpAllowUnpinnedKeys", None, [_i32])
 _sig("ZkpSetDevice", _i32, [_i32])
 _sig("ZkpReset", None, [])
+_sig("VerifyBatch", ProveReturn, [GoSlice])
+_sig("zkp_verify_batch_timed", ProveReturn, [GoSlice, C.POINTER(C.c_double)])
+_sig("VFree", None, [C.c_void_p])
 _sig("ZkpProveDeterministic", ProveReturn, [GoSlice, _u8p, _u8p, _u8p])
 _sig("zkp_n_inputs", _i64, [_i32])
 _sig("zkp_bench_upload", _i32, [_i32, _i64, _vp, _vp, _vp, _vp])
@@ -266,6 +269,26 @@ def verify_raw(request_json: bytes) -> bool:
     """lib.verify(json) (js/src/gnark/operator.ts:33-45 -> libverify.go:19)"""
     s, keep = _slice(request_json)
     return bool(lib.Verify(s))
+
+
+def verify_request(cipher: str, proof: bytes, ciphertext: bytes, blocks, plaintext_input: bytes) -> dict:
+    """the JSON object lib.verify takes (js/src/gnark/operator.ts:33-45)"""
+    import base64 as _b64
+    b = lambda x: _b64.b64encode(x).decode()
+    return {"cipher": cipher, "proof": b(proof),
+            "publicSignals": {"ciphertext": b(ciphertext), "blocks": [{"nonce": b(n), "counter": c} for n, c in blocks], "input": b(plaintext_input)}}
+
+
+def verify_batch_raw(requests_json: bytes, timed: bool = False):
+    """VerifyBatch: JSON array of Verify requests -> list of booleans (GPU batch check per circuit, host fallback per proof);
+    timed=True also returns the device milliseconds of the batch check"""
+    s, keep = _slice(requests_json)
+    ms = C.c_double(0.0)
+    ret = lib.zkp_verify_batch_timed(s, C.byref(ms))
+    out = C.string_at(ret.r0, ret.r1)
+    lib.VFree(ret.r0)
+    res = _json.loads(out)
+    return (res, ms.value) if timed else res
 
 
 def verify(cipher: str, proof: bytes, ciphertext: bytes, blocks, plaintext_input: bytes) -> bool:

@@ -263,36 +263,6 @@ std::string response_json(const std::vector<uint8_t> &proof, const std::vector<u
     return "{\"proof\":\"" + base64_encode(proof.data(), proof.size()) + "\",\"ciphertext\":\"" + base64_encode(ct.data(), ct.size()) + "\"}";
 }
 
-// host-side parallel loop (request decoding, witness packing, proof serialisation are independent per request)
-template <class Fn>
-void parallel_for(size_t n, Fn fn) {
-    unsigned nt = std::thread::hardware_concurrency();
-    if (nt > 16) nt = 16;
-    if (n < 64 || nt <= 1) { for (size_t i = 0; i < n; i++) fn(i); return; }
-    std::atomic<size_t> next{0};
-    std::exception_ptr first_error;
-    std::mutex err_lock;
-    auto worker = [&] {
-        try {
-            for (;;) {
-                const size_t i0 = next.fetch_add(32);
-                if (i0 >= n) return;
-                const size_t i1 = i0 + 32 < n ? i0 + 32 : n;
-                for (size_t i = i0; i < i1; i++) fn(i);
-            }
-        } catch (...) {          // an exception must not leave a std::thread: keep the first one for the caller
-            std::lock_guard<std::mutex> lk(err_lock);
-            if (!first_error) first_error = std::current_exception();
-            next.store(n);
-        }
-    };
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < nt; t++) th.emplace_back(worker);
-    worker();
-    for (auto &t : th) t.join();
-    if (first_error) std::rethrow_exception(first_error);
-}
-
 // one decoded request with its witness assignment and cipher output (or the panic value it produced)
 struct Prepared {
     Request rq;
@@ -436,51 +406,6 @@ std::string prove_coalesced(const Prepared &p) {
 // replicas pull chunks as they become ready (dynamic sharing between GPUs), and a third stage serialises finished chunks -- so for
 // large arrays the host phases hide under the device phase instead of bracketing it.
 
-// boundaries [lo, hi) of the elements of the top-level array; false + Go's SyntaxError offset on malformed structure.
-// not_array: the top-level value is something else (decoded like json.Unmarshal into a slice: type error -> {})
-bool split_array(const char *p, size_t n, std::vector<std::pair<size_t, size_t>> &el, size_t &err_off, bool &not_array) {
-    size_t i = 0;
-    not_array = false;
-    auto ws = [&] { while (i < n && (p[i] == ' ' || p[i] == '\t' || p[i] == '\n' || p[i] == '\r')) i++; };
-    ws();
-    if (i >= n) { err_off = n; return false; }
-    if (p[i] != '[') { not_array = true; return false; }
-    i++;
-    ws();
-    if (i < n && p[i] == ']') {
-        i++; ws();
-        if (i != n) { err_off = i + 1; return false; }
-        return true;
-    }
-    for (;;) {
-        ws();
-        const size_t lo = i;
-        int depth = 0;
-        bool in_str = false;
-        for (; i < n; i++) {
-            const char c = p[i];
-            if (in_str) {
-                if (c == '\\') i++;
-                else if (c == '"') in_str = false;
-                continue;
-            }
-            if (c == '"') in_str = true;
-            else if (c == '{' || c == '[') depth++;
-            else if (c == '}' || c == ']') { if (depth == 0) break; depth--; }
-            else if (c == ',' && depth == 0) break;
-        }
-        if (i >= n) { err_off = n; return false; }               // unexpected end of JSON input
-        size_t hi = i;
-        while (hi > lo && (p[hi - 1] == ' ' || p[hi - 1] == '\t' || p[hi - 1] == '\n' || p[hi - 1] == '\r')) hi--;
-        if (hi == lo || p[i] == '}') { err_off = i + 1; return false; }      // "[1,]" / "[,1]" / stray '}': invalid character
-        el.emplace_back(lo, hi);
-        if (p[i] == ',') { i++; continue; }
-        i++;                                                      // ']'
-        ws();
-        if (i != n) { err_off = i + 1; return false; }
-        return true;
-    }
-}
 // element [lo, hi) of the request array -> Prepared (a syntax error inside the element answers like Prove: {"Offset": position in the call's bytes})
 void prepare_element(const char *data, const std::pair<size_t, size_t> &e, Prepared &p) {
     Json j;
@@ -602,7 +527,7 @@ std::string prove_batch_json(const char *data, size_t len) {
         std::vector<std::pair<size_t, size_t>> el;
         size_t off = 0;
         bool not_array = false;
-        if (!split_array(data, len, el, off, not_array)) {
+        if (!json_split_array(data, len, el, off, not_array)) {
             if (not_array) {           // a syntactically valid non-array answers {} (type error); a malformed one its offset
                 Json j; std::string err;
                 if (json_parse(data, len, j, err, &off)) panic_err();
@@ -858,6 +783,8 @@ unsigned char InitAlgorithm(unsigned char algorithmID, GoSlice provingKey, GoSli
                 std::unique_ptr<Algorithm> a(new Algorithm());
                 a->device = devs[k];
                 a->split_rank = g_split_rank; a->split_world = g_split_world;
+                for (int d : devs) a->comb_share += (d == devs[k]);
+                a->comb_share -= 1;
                 a->load((const uint8_t *)provingKey.data, (size_t)provingKey.len, (const uint8_t *)r1cs.data, (size_t)r1cs.len);
                 reps[k] = std::move(a);
             } catch (const std::exception &e) {

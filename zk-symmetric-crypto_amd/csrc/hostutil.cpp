@@ -254,6 +254,49 @@ bool json_parse(const char *p, size_t n, Json &out, std::string &err, size_t *er
     if (jp.p != jp.e) { err = "invalid character after top-level value"; if (err_offset) *err_offset = offset(jp.p); return false; }
     return true;
 }
+bool json_split_array(const char *p, size_t n, std::vector<std::pair<size_t, size_t>> &el, size_t &err_off, bool &not_array) {
+    size_t i = 0;
+    not_array = false;
+    auto ws = [&] { while (i < n && (p[i] == ' ' || p[i] == '\t' || p[i] == '\n' || p[i] == '\r')) i++; };
+    ws();
+    if (i >= n) { err_off = n; return false; }
+    if (p[i] != '[') { not_array = true; return false; }
+    i++;
+    ws();
+    if (i < n && p[i] == ']') {
+        i++; ws();
+        if (i != n) { err_off = i + 1; return false; }
+        return true;
+    }
+    for (;;) {
+        ws();
+        const size_t lo = i;
+        int depth = 0;
+        bool in_str = false;
+        for (; i < n; i++) {
+            const char c = p[i];
+            if (in_str) {
+                if (c == '\\') i++;
+                else if (c == '"') in_str = false;
+                continue;
+            }
+            if (c == '"') in_str = true;
+            else if (c == '{' || c == '[') depth++;
+            else if (c == '}' || c == ']') { if (depth == 0) break; depth--; }
+            else if (c == ',' && depth == 0) break;
+        }
+        if (i >= n) { err_off = n; return false; }               // unexpected end of JSON input
+        size_t hi = i;
+        while (hi > lo && (p[hi - 1] == ' ' || p[hi - 1] == '\t' || p[hi - 1] == '\n' || p[hi - 1] == '\r')) hi--;
+        if (hi == lo || p[i] == '}') { err_off = i + 1; return false; }      // "[1,]" / "[,1]" / stray '}': invalid character
+        el.emplace_back(lo, hi);
+        if (p[i] == ',') { i++; continue; }
+        i++;                                                      // ']'
+        ws();
+        if (i != n) { err_off = i + 1; return false; }
+        return true;
+    }
+}
 std::string json_quote(const std::string &s) {
     std::string o = "\"";
     char buf[8];

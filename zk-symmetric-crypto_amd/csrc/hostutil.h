@@ -1,6 +1,11 @@
 // Host-side helpers of the request path: SHA-256, base64, a small JSON reader, the two ciphers, and the
 // handful of 256-bit integer operations the host needs (everything heavy runs on the GPU).
 #pragma once
+#include <utility>
+#include <exception>
+#include <mutex>
+#include <thread>
+#include <atomic>
 #include <stdint.h>
 #include <map>
 #include <memory>
@@ -30,6 +35,42 @@ struct Json {
 // returns false and fills err on malformed input; err_offset (optional) = Go's json.SyntaxError.Offset for the same input
 bool json_parse(const char *p, size_t n, Json &out, std::string &err, size_t *err_offset = nullptr);
 std::string json_quote(const std::string &s);   // Go json.Marshal string escaping (HTML-safe form)
+
+// boundaries [lo, hi) of the elements of a top-level JSON array, found by a scanner that only tracks strings and nesting (the elements
+// are parsed later, independently and in parallel).  false + Go's SyntaxError offset on malformed structure; not_array: the top-level
+// value is something else
+bool json_split_array(const char *p, size_t n, std::vector<std::pair<size_t, size_t>> &el, size_t &err_off, bool &not_array);
+
+// host-side parallel loop (request decoding, witness packing, proof serialisation are independent per request)
+template <class Fn>
+inline void parallel_for(size_t n, Fn fn) {
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt > 16) nt = 16;
+    if (n < 64 || nt <= 1) { for (size_t i = 0; i < n; i++) fn(i); return; }
+    std::atomic<size_t> next{0};
+    std::exception_ptr first_error;
+    std::mutex err_lock;
+    auto worker = [&] {
+        try {
+            for (;;) {
+                const size_t i0 = next.fetch_add(32);
+                if (i0 >= n) return;
+                const size_t i1 = i0 + 32 < n ? i0 + 32 : n;
+                for (size_t i = i0; i < i1; i++) fn(i);
+            }
+        } catch (...) {          // an exception must not leave a std::thread: keep the first one for the caller
+            std::lock_guard<std::mutex> lk(err_lock);
+            if (!first_error) first_error = std::current_exception();
+            next.store(n);
+        }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(worker);
+    worker();
+    for (auto &t : th) t.join();
+    if (first_error) std::rethrow_exception(first_error);
+}
+
 
 // ---- ciphers (the reference computes the ciphertext itself: provers.go:139-150, 227-238) ----
 void chacha20_block(const uint8_t key[32], uint32_t counter, const uint8_t nonce[12], uint8_t out[64]);

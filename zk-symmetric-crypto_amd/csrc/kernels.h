@@ -117,6 +117,9 @@ void comb_patterns(const CombBases &cb, const Fr *x, const Fr *y, size_t B, uint
 // out[b] = sum_i scalar_i(b) * P_i
 void comb_msm(const CombBases &cb, const uint32_t *pat, size_t B, CombScratch &sc, G1XYZZ *out, hipStream_t s, hipEvent_t *seg_events = nullptr);
 
+// BSB22 challenges H2F(commitment.Marshal(), "bsb22-commitment") of n canonical affine commitments, Montgomery form (prover.hip)
+void bsb22_challenge_device(const G1Affine *com_canonical, Fr *challenge_mont, size_t n, hipStream_t s);
+
 // ------------------------------------------------------------------------------- key folding (keyfold.hip)
 // Unscaled inverse DFT over G1: out[i] = sum_k w^{-ik} * data[k] for i < n_out (natural order; data is destroyed)
 void g1_point_idft(G1XYZZ *data, const NttDomain &dom, size_t n_out, G1Affine *out, hipStream_t s);

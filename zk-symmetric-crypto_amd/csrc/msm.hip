@@ -41,10 +41,15 @@ static constexpr size_t FOLD_GROUP = 8;      // partial sums are folded 8 at a t
 // Conditional-sum path (scalars 0 / +1 / -1): bases are taken TERN_G at a time and every signed subset sum of a group is
 // precomputed, so a group costs one mixed addition whatever its +-1 pattern is.  Index of a pattern: sum (t_i + 1) 3^i,
 // t_i in {-1, 0, +1}; the patterns above the centre (all zero) are stored, the ones below are their negatives.
-static constexpr int TERN_G = 6;
-static constexpr int TERN_CENTER = 364;                    // (3^6 - 1) / 2
-static constexpr int TERN_ENTRIES = 364;                   // patterns 365 .. 728
-static constexpr int ONES_GROUPS = 20;                     // groups per conditional-sum thread
+#ifndef ZK_TERN_G
+#define ZK_TERN_G 8                                        // 6: 364 entries (23 KB) per group, 8: 3 280 (205 KB), 9: 9 841 (615 KB)
+#endif
+static constexpr int TERN_G = ZK_TERN_G;
+static constexpr int pow3(int e) { return e == 0 ? 1 : 3 * pow3(e - 1); }
+static constexpr int TERN_CENTER = (pow3(TERN_G) - 1) / 2; // the all-zero pattern
+static constexpr int TERN_ENTRIES = TERN_CENTER;           // patterns CENTER + 1 .. 3^G - 1
+static constexpr int ONES_GROUPS = 128 / TERN_G;           // groups per conditional-sum thread (<= 128 bases: the four marker words)
+static_assert(pow3(TERN_G) <= 65536, "group patterns are parked as 16-bit words");
 static constexpr int ONES_CHUNK = TERN_G * ONES_GROUPS;    // base points per conditional-sum thread
 static constexpr int SORT_THREADS = 1024;
 

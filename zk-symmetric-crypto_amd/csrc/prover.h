@@ -67,6 +67,7 @@ class Algorithm {
     // of every base set of the key (the Pedersen bases stay whole: the commitment is needed in the middle of the solve).  Every rank
     // solves and transforms the whole batch, multiplies its slices (split_partials), the ranks exchange the five partial sums per
     // proof (RCCL / gloo all_gather by the caller) and each finishes the proof from the gathered sums (split_finish).
+    int comb_share = 1;      // replicas the library keeps on this device: the comb tables' memory budget is divided by it (cabi.cpp)
     int split_rank = 0, split_world = 1;
     size_t z_offset = 0;     // first coset point of this rank's slice of the quotient bases
     void split_partials(uint8_t *out384);                       // [B][384]: Ar, Bs1, K, Z (64 B each), Bs2 (128 B), affine Montgomery LE

@@ -463,13 +463,21 @@ static size_t comb_min_batch() {
     static const size_t v = [] { const char *e = getenv("ZKPROVE_COMB_MIN_BATCH"); return e ? (size_t)atol(e) : (size_t)256; }();
     return v;
 }
-static int comb_pick_k(size_t n) {
+// Largest clump size whose table fits the budget.  The budget has two sides: a fixed share of the device (0.21 of its memory -- the k = 19
+// table of a 2^16 domain, the k = 18 table of a 2^17 one -- divided by the replicas the library keeps on this device), and what is left
+// once the buffers this replica will still allocate (working sets, pattern copies) are set aside.  Decisions are serialised process-wide
+// so that each one sees the tables of the replicas before it.
+static std::mutex g_comb_budget_lock;
+static int comb_pick_k(size_t n, size_t still_needed, int share) {
     static const int forced = [] { const char *e = getenv("ZKPROVE_COMB_K"); return e ? atoi(e) : 0; }();
     if (forced) return forced;
     size_t free_b = 0, total_b = 0;
     ZK_HIP(hipMemGetInfo(&free_b, &total_b));
+    const double by_share = 0.21 * (double)total_b / (double)(share < 1 ? 1 : share);
+    const double by_free = free_b > still_needed ? 0.6 * (double)(free_b - still_needed) : 0.0;
+    const double budget = by_share < by_free ? by_share : by_free;
     for (int k = 19; k >= 12; k--)
-        if ((double)comb_table_bytes(n, k) <= 0.30 * (double)free_b) return k;
+        if ((double)comb_table_bytes(n, k) <= budget) return k;
     return 0;
 }
 bool Algorithm::comb_active() const {
@@ -480,7 +488,13 @@ void Algorithm::comb_prepare(size_t B) {
     Resident &R = *res;
     if (!pk.comb_tried && B >= comb_min_batch()) {
         pk.comb_tried = true;
-        const int k = comb_pick_k(pk.ze.n);
+        std::lock_guard<std::mutex> budget(g_comb_budget_lock);
+        // still to come for this replica: the second and third working set of the pipelined entries, the two pattern copies (~ the
+        // table's clump count x 254 x B words: bounded by the k = 12 figure), range accumulators, and slack for the allocator
+        const size_t N = (size_t)1 << prog.log_domain;
+        const size_t per_set = B * (prog.n_wires + 3 * N) * sizeof(Fr);
+        const size_t still_needed = 2 * per_set + 2 * ((pk.ze.n / 16 + 1) * 254 * B * sizeof(uint32_t)) + ((size_t)6 << 30);
+        const int k = comb_pick_k(pk.ze.n, still_needed, comb_share);
         bool ok = false;
         std::string why = "not enough free device memory";
         if (k) {
@@ -499,6 +513,10 @@ void Algorithm::comb_prepare(size_t B) {
         R.comb.reserve(pk.Zcomb, B, 2);
         R.comb_cap = B;
     }
+}
+
+void bsb22_challenge_device(const G1Affine *com_canonical, Fr *challenge_mont, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_bsb22_challenge, dim3(ceil_div(n, 64)), dim3(64), 0, s, com_canonical, challenge_mont, n);
 }
 
 // ------------------------------------------------------------------------------- pipeline
@@ -521,6 +539,48 @@ void Algorithm::resident_reserve(size_t B) {
     }
     Resident &R = *res;
     R.B = B;
+    if (B > R.cap) {
+        R.cap = B;
+        R.set[0].reserve(prog, B);
+        if (R.set[1].ready) R.set[1].reserve(prog, B);
+        if (R.set[2].ready) R.set[2].reserve(prog, B);
+        size_t max_entries = 0, max_nb = 0, max_part = 0;
+        auto acc = [&](size_t n, int c, int W) {
+            max_entries = std::max(max_entries, n * (size_t)W);
+            max_nb = std::max(max_nb, (size_t)1 << (c - 1));
+            max_part = std::max(max_part, msm_part_stride(n, c));
+        };
+        acc(pk.A.n, pk.A.c, pk.A.W); acc(pk.B1.n, pk.B1.c, pk.B1.W); acc(pk.K.n, pk.K.c, pk.K.W);      // (the quotient MSM's share: below)
+        acc(pk.B2.n, pk.B2.c, pk.B2.W);
+        if (has_commit) acc(pk.ped.n, pk.ped.c, pk.ped.W);
+        R.ms.reserve(B, max_entries, max_nb, max_part);
+        R.ms.reserve_compact(B, std::max({pk.A.n, pk.B1.n, pk.K.n, pk.B2.n, has_commit ? pk.ped.n : (size_t)1}));
+        {
+            const size_t Bs = std::min(B, SIDE_G2_MAX_B);
+            const size_t n_side = std::max(pk.B2.n, has_commit ? pk.ped_sigma.n : (size_t)1);
+            const int c_side = std::max(pk.B2.c, has_commit ? pk.ped_sigma.c : 1);
+            R.ms_g2.reserve(Bs, n_side * (size_t)std::max(pk.B2.W, has_commit ? pk.ped_sigma.W : 1), (size_t)1 << (c_side - 1),
+                            std::max(msm_part_stride(pk.B2.n, pk.B2.c), has_commit ? msm_part_stride(pk.ped_sigma.n, pk.ped_sigma.c) : (size_t)1));
+            {
+                const size_t na = std::max(pk.A.n, pk.B1.n);
+                R.ms_a.reserve(Bs, na * (size_t)pk.A.W, (size_t)1 << (pk.A.c - 1), std::max(msm_part_stride(pk.A.n, pk.A.c), msm_part_stride(pk.B1.n, pk.B1.c)));
+                R.ms_a.reserve_compact(Bs, na);
+                R.ms_a.reserve_sums(Bs, (size_t)1 << (pk.A.c - 1), 1);
+            }
+            R.ms_k.reserve(Bs, pk.K.n * (size_t)pk.K.W, (size_t)1 << (pk.K.c - 1), msm_part_stride(pk.K.n, pk.K.c));
+            R.ms_k.reserve_compact(Bs, pk.K.n);
+            R.ms_k.reserve_sums(Bs, (size_t)1 << (pk.K.c - 1), 1);
+            R.ms_g2.reserve_compact(Bs, n_side);
+            R.ms_g2.reserve_sums(Bs, has_commit ? (size_t)1 << (pk.ped_sigma.c - 1) : 1, (size_t)1 << (pk.B2.c - 1));
+        }
+        {
+            size_t nb1 = (size_t)1 << (std::max({pk.A.c, pk.B1.c, pk.K.c, has_commit ? pk.ped.c : 1}) - 1);
+            R.ms.reserve_sums(B, nb1, (size_t)1 << (pk.B2.c - 1));
+        }
+        R.m_ar.alloc(B); R.m_bs1.alloc(B); R.m_k.alloc(B); R.m_z.alloc(B); R.m_bs2.alloc(B);
+        R.ar_aff.alloc(B); R.bs1_aff.alloc(B); R.f_t.alloc(B); R.f_u.alloc(B); R.f_v.alloc(B);
+    }
+    // the comb tables of the quotient MSM are decided once the working buffers above exist (the budget looks at what is left)
     comb_prepare(B);
     // bucket pipeline of the quotient MSM: for every batch when there are no comb tables, else only for the batches too small for the comb
     const size_t nbz = (size_t)1 << (pk.Z.c - 1), ez = pk.Z.n * (size_t)pk.Z.W;
@@ -533,46 +593,8 @@ void Algorithm::resident_reserve(size_t B) {
         R.ms.reserve_tree(Bd, ez, nbz);
         R.ms.reserve_sums(Bd, nbz, 1);
     }
-    if (B <= R.cap) { for (auto &st : R.set) st.sb.B = B; R.ms.B = B; R.ms2.B = B; return; }
-    R.cap = B;
-    R.set[0].reserve(prog, B);
-    if (R.set[1].ready) R.set[1].reserve(prog, B);
-    if (R.set[2].ready) R.set[2].reserve(prog, B);
-    size_t max_entries = 0, max_nb = 0, max_part = 0;
-    auto acc = [&](size_t n, int c, int W) {
-        max_entries = std::max(max_entries, n * (size_t)W);
-        max_nb = std::max(max_nb, (size_t)1 << (c - 1));
-        max_part = std::max(max_part, msm_part_stride(n, c));
-    };
-    acc(pk.A.n, pk.A.c, pk.A.W); acc(pk.B1.n, pk.B1.c, pk.B1.W); acc(pk.K.n, pk.K.c, pk.K.W);      // (the quotient MSM's share: above)
-    acc(pk.B2.n, pk.B2.c, pk.B2.W);
-    if (has_commit) acc(pk.ped.n, pk.ped.c, pk.ped.W);
-    R.ms.reserve(B, max_entries, max_nb, max_part);
-    R.ms.reserve_compact(B, std::max({pk.A.n, pk.B1.n, pk.K.n, pk.B2.n, has_commit ? pk.ped.n : (size_t)1}));
-    {
-        const size_t Bs = std::min(B, SIDE_G2_MAX_B);
-        const size_t n_side = std::max(pk.B2.n, has_commit ? pk.ped_sigma.n : (size_t)1);
-        const int c_side = std::max(pk.B2.c, has_commit ? pk.ped_sigma.c : 1);
-        R.ms_g2.reserve(Bs, n_side * (size_t)std::max(pk.B2.W, has_commit ? pk.ped_sigma.W : 1), (size_t)1 << (c_side - 1),
-                        std::max(msm_part_stride(pk.B2.n, pk.B2.c), has_commit ? msm_part_stride(pk.ped_sigma.n, pk.ped_sigma.c) : (size_t)1));
-        {
-            const size_t na = std::max(pk.A.n, pk.B1.n);
-            R.ms_a.reserve(Bs, na * (size_t)pk.A.W, (size_t)1 << (pk.A.c - 1), std::max(msm_part_stride(pk.A.n, pk.A.c), msm_part_stride(pk.B1.n, pk.B1.c)));
-            R.ms_a.reserve_compact(Bs, na);
-            R.ms_a.reserve_sums(Bs, (size_t)1 << (pk.A.c - 1), 1);
-        }
-        R.ms_k.reserve(Bs, pk.K.n * (size_t)pk.K.W, (size_t)1 << (pk.K.c - 1), msm_part_stride(pk.K.n, pk.K.c));
-        R.ms_k.reserve_compact(Bs, pk.K.n);
-        R.ms_k.reserve_sums(Bs, (size_t)1 << (pk.K.c - 1), 1);
-        R.ms_g2.reserve_compact(Bs, n_side);
-        R.ms_g2.reserve_sums(Bs, has_commit ? (size_t)1 << (pk.ped_sigma.c - 1) : 1, (size_t)1 << (pk.B2.c - 1));
-    }
-    {
-        size_t nb1 = (size_t)1 << (std::max({pk.A.c, pk.B1.c, pk.K.c, has_commit ? pk.ped.c : 1}) - 1);
-        R.ms.reserve_sums(B, nb1, (size_t)1 << (pk.B2.c - 1));
-    }
-    R.m_ar.alloc(B); R.m_bs1.alloc(B); R.m_k.alloc(B); R.m_z.alloc(B); R.m_bs2.alloc(B);
-    R.ar_aff.alloc(B); R.bs1_aff.alloc(B); R.f_t.alloc(B); R.f_u.alloc(B); R.f_v.alloc(B);
+    for (auto &st : R.set) st.sb.B = B;
+    R.ms.B = B; R.ms2.B = B;
 }
 
 // inputs [B][n_inputs] (instance-major, as the host builds them), r / s / randomize [B] canonical -> set S, on stream st

@@ -14,6 +14,7 @@
 #include "curve.cuh"
 #include "hostutil.h"
 #include "common.h"
+#include "kernels.h"
 
 namespace zk {
 namespace {
@@ -23,7 +24,7 @@ namespace {
 // ---- Fp12 = Fp2[w] / (w^6 - xi), xi = 9 + u
 struct Fp12 {
     Fp2 c[6];
-    static Fp12 one() { Fp12 r; for (auto &x : r.c) x = Fp2::zero(); r.c[0] = Fp2::one(); return r; }
+    static ZK_HD Fp12 one() { Fp12 r; for (auto &x : r.c) x = Fp2::zero(); r.c[0] = Fp2::one(); return r; }
     bool is_one() const {
         if (!(c[0] == Fp2::one())) return false;
         for (int i = 1; i < 6; i++) if (!c[i].is_zero()) return false;
@@ -39,7 +40,9 @@ static void consts_init() {
         TWIST_B = Fp2{Fp::from_u32(3), Fp::zero()} * XI.inv();
     });
 }
-static Fp12 mul(const Fp12 &a, const Fp12 &b) {
+// (xi = 9 + u is formed in place: the same code runs in the batch verifier's device kernels, which cannot read host globals)
+static __host__ __device__ Fp12 mul(const Fp12 &a, const Fp12 &b) {
+    const Fp2 xi{Fp::from_u32(9), Fp::one()};
     Fp2 t[11];
     for (auto &x : t) x = Fp2::zero();
     for (int i = 0; i < 6; i++) {
@@ -51,7 +54,7 @@ static Fp12 mul(const Fp12 &a, const Fp12 &b) {
     }
     Fp12 r;
     for (int k = 0; k < 6; k++) r.c[k] = t[k];
-    for (int k = 6; k < 11; k++) r.c[k - 6] = r.c[k - 6] + t[k] * XI;
+    for (int k = 6; k < 11; k++) r.c[k - 6] = r.c[k - 6] + t[k] * xi;
     return r;
 }
 static Fp12 pow_words(const Fp12 &a, const uint32_t *e, int nbits) {
@@ -63,7 +66,7 @@ static Fp12 pow_words(const Fp12 &a, const uint32_t *e, int nbits) {
     return acc;
 }
 // line through twist point T with twist slope lam, at P in E(Fp): y_P - lam x_P w + (lam x_T - y_T) w^3
-static Fp12 line(const G2Affine &T, const Fp2 &lam, const G1Affine &P) {
+static __host__ __device__ Fp12 line(const G2Affine &T, const Fp2 &lam, const G1Affine &P) {
     Fp12 l;
     for (auto &x : l.c) x = Fp2::zero();
     l.c[0] = Fp2{P.y, Fp::zero()};
@@ -72,7 +75,9 @@ static Fp12 line(const G2Affine &T, const Fp2 &lam, const G1Affine &P) {
     l.c[3] = lam * T.x - T.y;
     return l;
 }
-static Fp12 miller(const G1Affine &P, const G2Affine &Q) {
+// ate Miller loop f_{t-1,Q}(P); degenerate = an addition step met T == +-Q (cannot happen for Q of order r)
+static __host__ __device__ Fp12 miller_core(const G1Affine &P, const G2Affine &Q, const uint32_t *loop_words, bool &degenerate) {
+    degenerate = false;
     if (P.is_inf() || Q.is_inf()) return Fp12::one();
     Fp12 f = Fp12::one();
     G2Affine T = Q;
@@ -83,8 +88,8 @@ static Fp12 miller(const G1Affine &P, const G2Affine &Q) {
         Fp2 x3 = lam.sqr() - T.x.dbl();
         Fp2 y3 = lam * (T.x - x3) - T.y;
         T = G2Affine{x3, y3};
-        if ((ATE_LOOP_WORDS[i >> 5] >> (i & 31)) & 1) {
-            if (T.x == Q.x) throw ZkError("degenerate addition in the miller loop");
+        if ((loop_words[i >> 5] >> (i & 31)) & 1) {
+            if (T.x == Q.x) { degenerate = true; return Fp12::one(); }
             Fp2 l2 = (T.y - Q.y) * (T.x - Q.x).inv();
             f = mul(f, line(T, l2, P));
             Fp2 xa = l2.sqr() - T.x - Q.x;
@@ -92,6 +97,12 @@ static Fp12 miller(const G1Affine &P, const G2Affine &Q) {
             T = G2Affine{xa, ya};
         }
     }
+    return f;
+}
+static Fp12 miller(const G1Affine &P, const G2Affine &Q) {
+    bool bad = false;
+    const Fp12 f = miller_core(P, Q, ATE_LOOP_WORDS, bad);
+    if (bad) throw ZkError("degenerate addition in the miller loop");
     return f;
 }
 static bool pairing_product_is_one(const std::vector<std::pair<G1Affine, G2Affine>> &pairs) {
@@ -227,7 +238,14 @@ static bool get_bytes(const Json *j, std::vector<uint8_t> &out) {
     return base64_decode(j->s, out);
 }
 
-static bool verify_impl(const uint8_t *data, size_t len) {
+// one decoded Verify request: cipher, public witness (small integers, without the constant one), proof bytes
+struct ParsedReq {
+    int alg = -1;
+    std::vector<uint32_t> pub;
+    std::vector<uint8_t> proof;
+};
+static bool parse_request(const uint8_t *data, size_t len, ParsedReq &rq) {
+
     consts_init();
     Json j;
     std::string err;
@@ -237,7 +255,8 @@ static bool verify_impl(const uint8_t *data, size_t len) {
     int alg = -1;
     for (int i = 0; i < 3; i++) if (jc->s == NAMES[i]) alg = i;
     if (alg < 0) return false;                                           // library.go:178-181: unknown cipher -> false
-    std::vector<uint8_t> proof, ct, in;
+    std::vector<uint8_t> &proof = rq.proof;
+    std::vector<uint8_t> ct, in;
     if (!get_bytes(jp, proof) || !js || js->t != Json::OBJ) return false;
     if (!get_bytes(js->get("ciphertext"), ct) || !get_bytes(js->get("input"), in)) { printf("failed to parse public signals JSON\n"); return false; }
     const Json *jb = js->get("blocks");
@@ -266,7 +285,7 @@ static bool verify_impl(const uint8_t *data, size_t len) {
     for (int b = 0; b < nblk; b++)
         if (nonces[b].size() != 12) { printf("block[%d] nonce must be 12 bytes, not %zu\n", b, nonces[b].size()); return false; }
     // public witness (without the constant one), as small integers
-    std::vector<uint32_t> pub;
+    std::vector<uint32_t> &pub = rq.pub;
     if (alg == 0) {
         auto bits = [&](uint32_t v) { for (int i = 0; i < 32; i++) pub.push_back((v >> i) & 1); };
         auto le32 = [](const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); };
@@ -281,40 +300,14 @@ static bool verify_impl(const uint8_t *data, size_t len) {
         for (uint8_t v : in) pub.push_back(v);
         for (uint8_t v : ct) pub.push_back(v);
     }
-    std::unique_lock<std::mutex> lk(g_vk_lock);
-    if (!g_vk[alg]) {
-        // the reference embeds generated/vk.* at build time (verifier/impl/library.go:92-160), so its `Verify` works with no set-up call.
-        // The drop-in equivalent: the same files vk.{chacha20,aes128,aes256} in $ZKPROVE_VK_DIR or, when that is unset, in the directory
-        // this shared object was loaded from (`make dropin` puts them beside bin/gnark/linux-x86_64-libverify.so).
-        static const char *EXT[3] = {"chacha20", "aes128", "aes256"};
-        std::vector<std::string> dirs;
-        if (const char *dir = getenv("ZKPROVE_VK_DIR")) dirs.push_back(dir);
-        else {
-            Dl_info di;
-            if (dladdr((const void *)&verify_impl, &di) && di.dli_fname) {
-                std::string so = di.dli_fname;
-                const size_t slash = so.rfind('/');
-                dirs.push_back(slash == std::string::npos ? std::string(".") : so.substr(0, slash));
-            }
-        }
-        for (const std::string &dir : dirs) {
-            const std::string path = dir + "/vk." + EXT[alg];
-            if (FILE *f = fopen(path.c_str(), "rb")) {
-                std::vector<uint8_t> buf;
-                uint8_t tmp[65536];
-                size_t n;
-                while ((n = fread(tmp, 1, sizeof(tmp), f)) > 0) buf.insert(buf.end(), tmp, tmp + n);
-                fclose(f);
-                std::unique_ptr<VerifyingKey> k(new VerifyingKey());
-                vk_parse(buf.data(), buf.size(), *k);
-                g_vk[alg] = std::move(k);
-                break;
-            }
-        }
-    }
-    if (!g_vk[alg]) { printf("verifying key for %s is not initialised\n", NAMES[alg]); return false; }
-    const VerifyingKey vk = *g_vk[alg];
-    lk.unlock();
+    rq.alg = alg;
+    return true;
+}
+// the verifying key of an algorithm (ZkpInitVerifier, else vk.<ext> from $ZKPROVE_VK_DIR or from beside the library); nullptr: none
+static const VerifyingKey *load_vk(int alg);
+static bool verify_parsed(const ParsedReq &rq, const VerifyingKey &vk) {
+    const std::vector<uint8_t> &proof = rq.proof;
+    const std::vector<uint32_t> &pub = rq.pub;
     // proof: Ar | Bs | Krs | u32 n | commitments | pok
     Cur c{proof.data(), proof.size()};
     G1Affine ar = c.g1();
@@ -367,6 +360,329 @@ static bool verify_impl(const uint8_t *data, size_t len) {
     return ok;
 }
 
+static const VerifyingKey *load_vk(int alg) {
+    std::unique_lock<std::mutex> lk(g_vk_lock);
+    if (!g_vk[alg]) {
+        // the reference embeds generated/vk.* at build time (verifier/impl/library.go:92-160), so its `Verify` works with no set-up call.
+        // The drop-in equivalent: the same files vk.{chacha20,aes128,aes256} in $ZKPROVE_VK_DIR or, when that is unset, in the directory
+        // this shared object was loaded from (`make dropin` puts them beside bin/gnark/linux-x86_64-libverify.so).
+        static const char *EXT[3] = {"chacha20", "aes128", "aes256"};
+        std::vector<std::string> dirs;
+        if (const char *dir = getenv("ZKPROVE_VK_DIR")) dirs.push_back(dir);
+        else {
+            Dl_info di;
+            if (dladdr((const void *)&load_vk, &di) && di.dli_fname) {
+                std::string so = di.dli_fname;
+                const size_t slash = so.rfind('/');
+                dirs.push_back(slash == std::string::npos ? std::string(".") : so.substr(0, slash));
+            }
+        }
+        for (const std::string &dir : dirs) {
+            const std::string path = dir + "/vk." + EXT[alg];
+            if (FILE *f = fopen(path.c_str(), "rb")) {
+                std::vector<uint8_t> buf;
+                uint8_t tmp[65536];
+                size_t n;
+                while ((n = fread(tmp, 1, sizeof(tmp), f)) > 0) buf.insert(buf.end(), tmp, tmp + n);
+                fclose(f);
+                std::unique_ptr<VerifyingKey> k(new VerifyingKey());
+                vk_parse(buf.data(), buf.size(), *k);
+                g_vk[alg] = std::move(k);
+                break;
+            }
+        }
+    }
+    return g_vk[alg].get();
+}
+static bool verify_impl(const uint8_t *data, size_t len) {
+    ParsedReq rq;
+    if (!parse_request(data, len, rq)) return false;
+    const VerifyingKey *vk = load_vk(rq.alg);
+    if (!vk) { printf("verifying key for %s is not initialised\n", NAMES[rq.alg]); return false; }
+    const VerifyingKey copy = *vk;          // ZkpInitVerifier may replace the key while this call runs
+    return verify_parsed(rq, copy);
+}
+
+
+// =====================================================================================================================
+// Batch verification on the GPU (optional half; the per-proof semantics are those of
+// gnark/libraries/verifier/impl/verifiers.go:73-89,142-158 -> groth16.Verify).
+//
+// n proofs of one circuit are checked with ONE pairing-product equation under random 128-bit coefficients rho_i, rho'_i:
+//     prod_i e(rho_i A_i, B_i) * e(-(sum rho_i) alpha, beta) * e(-sum rho_i kSum_i, gamma) * e(-sum rho_i C_i, delta)
+//            * e(sum rho'_i Com_i, GSigmaNeg) * e(sum rho'_i PoK_i, G) == 1
+// (the last two factors fold the Pedersen proofs of knowledge of the BSB22 commitments in; a false batch passes with probability
+// ~2^-128).  On the device: point decompression and the G2 subgroup check (msm.hip kernels), kSum_i = K_0 + sum_j pub_ij K_j as a
+// batched MSM over the verifying key's K (msm_batch: the 0 / 1 bits of the ChaCha20 public inputs take the conditional-sum path),
+// the BSB22 challenges, the rho multiples and their sums, and one Miller loop per pairing (thread = pairing).  The host multiplies
+// the n + 5 Miller values and does the one final exponentiation.  A batch that fails -- or holds a proof the device path does not take
+// (unusual encoding) -- is re-checked proof by proof with verify_parsed on the host threads, which also yields the per-proof answers.
+__device__ static const uint32_t ATE_LOOP_DEV[4] = {0xe87cfd46u, 0xf83e9682u, 0xeeb859fbu, 0x6f4d8248u};      // = ATE_LOOP_WORDS
+
+struct VbPair { G1Affine p; G2Affine q; };
+
+__global__ void k_vb_pub(const uint32_t *__restrict__ pub, size_t n, size_t npub, Fr *__restrict__ out) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * npub) return;
+    const size_t j = t / n, i = t % n;
+    out[t] = Fr::from_u32(pub[i * npub + j]);                 // [npub][n], Montgomery
+}
+__global__ void k_vb_canon(const G1Affine *__restrict__ in, G1Affine *__restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = G1Affine{in[i].x.from_mont(), in[i].y.from_mont()};
+}
+// blockIdx.y = task: 0: pairs[i].p = rho_i A_i   1: TK_i = rho_i (kSum_i + K_0 [+ ch_i K_c + Com_i])   2: TC_i = rho_i C_i
+//                    3: Tcom_i = rho'_i Com_i     4: Tpok_i = rho'_i PoK_i
+__global__ __launch_bounds__(64) void k_vb_scale(size_t n, const G1Affine *__restrict__ A, const G2Affine *__restrict__ Bq, const G1Affine *__restrict__ C,
+                                                 const G1XYZZ *__restrict__ ksum, const G1Affine *__restrict__ com, const G1Affine *__restrict__ pok,
+                                                 G1Affine K0, G1Affine Kc, const Fr *__restrict__ ch, const uint32_t *__restrict__ rho, VbPair *__restrict__ pairs,
+                                                 G1XYZZ *__restrict__ TK, G1XYZZ *__restrict__ TC, G1XYZZ *__restrict__ Tcom, G1XYZZ *__restrict__ Tpok) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int task = blockIdx.y;
+    uint32_t k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int w = 0; w < 4; w++) k[w] = rho[i * 8 + (task >= 3 ? 4 : 0) + w];
+    if (task == 0) {
+        pairs[i].p = scalar_mul(A[i], k, 128).to_affine();
+        pairs[i].q = Bq[i];
+    } else if (task == 1) {
+        G1XYZZ ks = ksum[i];
+        ks.madd(K0);
+        if (com) {
+            const Fr c = ch[i].from_mont();
+            ks.add(scalar_mul(Kc, c.l, 254));
+            ks.madd(com[i]);
+        }
+        TK[i] = scalar_mul_x(ks, k, 128);
+    } else if (task == 2) {
+        TC[i] = scalar_mul(C[i], k, 128);
+    } else if (task == 3) {
+        Tcom[i] = scalar_mul(com[i], k, 128);
+    } else {
+        Tpok[i] = scalar_mul(pok[i], k, 128);
+    }
+}
+// blockIdx.x = which list; 256 threads: strided partial sums, folded by thread 0
+__global__ __launch_bounds__(256) void k_vb_sum(const G1XYZZ *const *__restrict__ lists, size_t n, G1XYZZ *__restrict__ out) {
+    __shared__ G1XYZZ part[256];
+    const G1XYZZ *in = lists[blockIdx.x];
+    G1XYZZ acc = G1XYZZ::inf();
+    if (in)
+        for (size_t i = threadIdx.x; i < n; i += 256) acc.add(in[i]);
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if ((int)threadIdx.x < s) { G1XYZZ a = part[threadIdx.x]; a.add(part[threadIdx.x + s]); part[threadIdx.x] = a; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = part[0];
+}
+// the fixed pairings: thread 0: -(rho_sum alpha) vs beta, 1: -SK vs gamma, 2: -SC vs delta, 3: Scom vs GSigmaNeg, 4: Spok vs G
+__global__ void k_vb_fixed(size_t n, const G1XYZZ *__restrict__ sums, G1Affine alpha, const uint32_t *__restrict__ rho_sum, G2Affine beta, G2Affine gamma, G2Affine delta,
+                           G2Affine gsig, G2Affine g, int has_commit, VbPair *__restrict__ pairs) {
+    const int t = threadIdx.x;
+    if (t >= 5) return;
+    VbPair pr;
+    if (t == 0) { pr.p = scalar_mul(alpha, rho_sum, 254).to_affine(); pr.q = beta; }
+    else if (t == 1) { pr.p = sums[0].to_affine(); pr.q = gamma; }
+    else if (t == 2) { pr.p = sums[1].to_affine(); pr.q = delta; }
+    else if (t == 3) { pr.p = has_commit ? sums[2].to_affine() : G1Affine::inf(); pr.q = gsig; }
+    else { pr.p = has_commit ? sums[3].to_affine() : G1Affine::inf(); pr.q = g; }
+    if (t <= 2 && !pr.p.is_inf()) pr.p.y = pr.p.y.neg();
+    pairs[n + t] = pr;
+}
+__global__ __launch_bounds__(64) void k_vb_miller(const VbPair *__restrict__ pairs, size_t np, Fp12 *__restrict__ out, uint32_t *__restrict__ bad) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= np) return;
+    bool degenerate = false;
+    const VbPair pr = pairs[t];
+    out[t] = miller_core(pr.p, pr.q, ATE_LOOP_DEV, degenerate);
+    if (degenerate) atomicAdd(bad, 1u);
+}
+
+// device-side image of a verifying key: the K bases prepared for batched MSMs
+struct VkDevice {
+    const VerifyingKey *src = nullptr;      // identity of the key it was built from
+    uint64_t version = 0;
+    MsmBasesG1 K;                           // K_1 .. K_npub, row j = public input j
+    size_t npub = 0;
+    MsmScratch scratch;
+    size_t cap = 0;
+};
+static std::mutex g_vb_lock;                // one batch at a time (device buffers are shared)
+static VkDevice g_vkdev[3];
+static uint64_t g_vk_version[3] = {0, 0, 0};      // bumped by ZkpInitVerifier
+
+static constexpr int C_VK = 8;              // window bits of the (rare) non-0/1 public inputs: bytes and 32-bit counters of the AES circuits
+
+// true: the random-linear-combination check holds for proofs idx[]; false: it does not (or the device path declined)
+static bool verify_batch_device(int alg, const VerifyingKey &vk, const std::vector<ParsedReq> &reqs, const std::vector<size_t> &idx, double *ms_out) {
+    const size_t n = idx.size(), npub = reqs[idx[0]].pub.size();
+    const bool has_commit = !vk.ckeys.empty();
+    if (vk.K.size() != 1 + npub + (has_commit ? 1 : 0)) return false;
+    if (has_commit && (vk.ckeys.size() != 1 || vk.pub_committed.size() != 1 || !vk.pub_committed[0].empty())) return false;
+    std::lock_guard<std::mutex> lk(g_vb_lock);
+    bind_default_device();
+    hipStream_t st = 0;
+    VkDevice &vd = g_vkdev[alg];
+    if (vd.version != g_vk_version[alg] || vd.npub != npub || !vd.K.n) {
+        DevBuf<G1Affine> pts(npub);
+        ZK_HIP(hipMemcpy(pts.p, vk.K.data() + 1, npub * sizeof(G1Affine), hipMemcpyHostToDevice));
+        std::vector<uint32_t> rows(npub);
+        for (size_t j = 0; j < npub; j++) rows[j] = (uint32_t)j;
+        vd.K = MsmBasesG1();
+        msm_bases_build(vd.K, pts.p, npub, rows.data(), C_VK, st);
+        vd.npub = npub; vd.version = g_vk_version[alg]; vd.cap = 0;
+    }
+    if (vd.cap < n) {
+        vd.scratch.reserve(n, npub * (size_t)vd.K.W, (size_t)1 << (C_VK - 1), msm_part_stride(npub, C_VK));
+        vd.scratch.reserve_compact(n, npub);
+        vd.scratch.reserve_sums(n, (size_t)1 << (C_VK - 1), 1);
+        vd.cap = n;
+    }
+    hipEvent_t e0, e1;
+    ZK_HIP(hipEventCreate(&e0)); ZK_HIP(hipEventCreate(&e1));
+    ZK_HIP(hipEventRecord(e0, st));
+    // ---- proofs: compressed points gathered per kind
+    std::vector<uint8_t> hA(n * 32), hB(n * 64), hC(n * 32), hCom(has_commit ? n * 32 : 0), hPok(has_commit ? n * 32 : 0);
+    std::vector<uint32_t> hpub(n * npub);
+    for (size_t q = 0; q < n; q++) {
+        const ParsedReq &r = reqs[idx[q]];
+        const uint8_t *p = r.proof.data();
+        memcpy(&hA[q * 32], p, 32); memcpy(&hB[q * 64], p + 32, 64); memcpy(&hC[q * 32], p + 96, 32);
+        if (has_commit) { memcpy(&hCom[q * 32], p + 132, 32); memcpy(&hPok[q * 32], p + 164, 32); }
+        memcpy(&hpub[q * npub], r.pub.data(), npub * 4);
+    }
+    DevBuf<uint8_t> dA(n * 32), dB(n * 64), dC(n * 32), dCom(has_commit ? n * 32 : 1), dPok(has_commit ? n * 32 : 1);
+    DevBuf<G1Affine> A(n), C(n), Com(has_commit ? n : 1), Pok(has_commit ? n : 1), ComCanon(has_commit ? n : 1);
+    DevBuf<G2Affine> Bq(n);
+    DevBuf<uint32_t> bad(1), dpub(n * npub), drho(n * 8 + 8);
+    DevBuf<Fr> scal(n * npub + 1), ch(n);
+    DevBuf<G1XYZZ> ksum(n), TK(n), TC(n), Tcom(has_commit ? n : 1), Tpok(has_commit ? n : 1), sums(4);
+    DevBuf<VbPair> pairs(n + 5);
+    DevBuf<Fp12> fv(n + 5);
+    bad.zero(st);
+    dA.upload(hA.data(), hA.size(), st); dB.upload(hB.data(), hB.size(), st); dC.upload(hC.data(), hC.size(), st);
+    if (has_commit) { dCom.upload(hCom.data(), hCom.size(), st); dPok.upload(hPok.data(), hPok.size(), st); }
+    dpub.upload(hpub.data(), hpub.size(), st);
+    g1_decompress(A.p, dA.p, n, bad.p, st);
+    g1_decompress(C.p, dC.p, n, bad.p, st);
+    g2_decompress(Bq.p, dB.p, n, bad.p, st);
+    g2_validate(Bq.p, nullptr, n, bad.p, st);                   // on the twist AND in the order-r subgroup, as gnark-crypto's decoder demands
+    if (has_commit) { g1_decompress(Com.p, dCom.p, n, bad.p, st); g1_decompress(Pok.p, dPok.p, n, bad.p, st); }
+    // ---- kSum_i
+    hipLaunchKernelGGL(k_vb_pub, dim3(ceil_div(n * npub, 256)), dim3(256), 0, st, dpub.p, n, npub, scal.p);
+    msm_batch(vd.K, scal.p, n, vd.scratch, ksum.p, st);
+    if (has_commit) {
+        hipLaunchKernelGGL(k_vb_canon, dim3(ceil_div(n, 64)), dim3(64), 0, st, Com.p, ComCanon.p, n);
+        bsb22_challenge_device(ComCanon.p, ch.p, n, st);
+    }
+    // ---- random coefficients: 2 x 128 bits per proof, and sum rho_i mod r for the alpha term
+    std::vector<uint32_t> hrho(n * 8 + 8);
+    {
+        FILE *f = fopen("/dev/urandom", "rb");
+        if (!f) throw ZkError("cannot read /dev/urandom");
+        setvbuf(f, nullptr, _IONBF, 0);
+        const bool ok = fread(hrho.data(), 4, n * 8, f) == n * 8;
+        fclose(f);
+        if (!ok) throw ZkError("cannot read /dev/urandom");
+    }
+    {
+        unsigned __int128 acc_lo = 0;      // sum of n 128-bit values < 2^160: well below r, no reduction needed
+        uint64_t lo = 0, mid = 0, hi = 0;
+        for (size_t q = 0; q < n; q++) {
+            const uint64_t a = (uint64_t)hrho[q * 8] | ((uint64_t)hrho[q * 8 + 1] << 32), b = (uint64_t)hrho[q * 8 + 2] | ((uint64_t)hrho[q * 8 + 3] << 32);
+            acc_lo = (unsigned __int128)lo + a; lo = (uint64_t)acc_lo;
+            acc_lo = (unsigned __int128)mid + b + (uint64_t)(acc_lo >> 64); mid = (uint64_t)acc_lo;
+            hi += (uint64_t)(acc_lo >> 64);
+        }
+        uint32_t *rs = &hrho[n * 8];
+        rs[0] = (uint32_t)lo; rs[1] = (uint32_t)(lo >> 32); rs[2] = (uint32_t)mid; rs[3] = (uint32_t)(mid >> 32); rs[4] = (uint32_t)hi; rs[5] = (uint32_t)(hi >> 32); rs[6] = 0; rs[7] = 0;
+    }
+    drho.upload(hrho.data(), hrho.size(), st);
+    hipLaunchKernelGGL(k_vb_scale, dim3(ceil_div(n, 64), has_commit ? 5 : 3), dim3(64), 0, st, n, A.p, Bq.p, C.p, ksum.p, has_commit ? Com.p : (const G1Affine *)nullptr,
+                       has_commit ? Pok.p : (const G1Affine *)nullptr, vk.K[0], has_commit ? vk.K[1 + npub] : G1Affine::inf(), ch.p, drho.p, pairs.p, TK.p, TC.p, Tcom.p, Tpok.p);
+    const G1XYZZ *hl[4] = {TK.p, TC.p, has_commit ? Tcom.p : nullptr, has_commit ? Tpok.p : nullptr};
+    DevBuf<const G1XYZZ *> lists(4);
+    lists.upload(hl, 4, st);
+    hipLaunchKernelGGL(k_vb_sum, dim3(4), dim3(256), 0, st, lists.p, n, sums.p);
+    hipLaunchKernelGGL(k_vb_fixed, dim3(1), dim3(64), 0, st, n, sums.p, vk.alpha1, drho.p + n * 8, vk.beta2, vk.gamma2, vk.delta2,
+                       has_commit ? vk.ckeys[0].second : G2Affine::inf(), has_commit ? vk.ckeys[0].first : G2Affine::inf(), has_commit ? 1 : 0, pairs.p);
+    hipLaunchKernelGGL(k_vb_miller, dim3(ceil_div(n + 5, 64)), dim3(64), 0, st, pairs.p, n + 5, fv.p, bad.p);
+    ZK_HIP(hipGetLastError());
+    std::vector<Fp12> hf(n + 5);
+    uint32_t nbad = 0;
+    fv.download(hf.data(), n + 5, st);
+    bad.download(&nbad, 1, st);
+    ZK_HIP(hipEventRecord(e1, st));
+    ZK_HIP(hipStreamSynchronize(st));
+    float ms = 0;
+    ZK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (ms_out) *ms_out = ms;
+    if (nbad) return false;                   // an undecodable point / a G2 point outside the subgroup somewhere in the batch
+    // ---- host: product of the Miller values (tree over the host threads), one final exponentiation
+    size_t m = hf.size();
+    while (m > 1) {
+        const size_t half = (m + 1) / 2;
+        parallel_for(m / 2, [&](size_t i) { hf[i] = mul(hf[i], hf[i + half]); });
+        m = half;
+    }
+    return pow_words(hf[0], FINAL_EXP_WORDS, FINAL_EXP_BITS).is_one();
+}
+
+// proofs in the exact shape the prover emits: compressed A | B | C | u32 nCommit | [Com] | PoK, nothing at infinity but the ChaCha PoK
+static bool proof_fits_device_path(const std::vector<uint8_t> &p, bool has_commit) {
+    if (p.size() != (has_commit ? 196u : 164u)) return false;
+    auto comp = [&](size_t off) { return (p[off] >> 6) >= 2; };
+    if (!comp(0) || !comp(32) || !comp(96)) return false;
+    if (p[128] || p[129] || p[130] || p[131] != (has_commit ? 1 : 0)) return false;
+    if (has_commit) return comp(132) && comp(164);
+    return (p[132] >> 6) == 1;                // no commitment: the PoK slot holds the point at infinity
+}
+
+static std::string verify_batch_json(const char *data, size_t len, double *device_ms) {
+    consts_init();
+    std::vector<std::pair<size_t, size_t>> el;
+    size_t off = 0;
+    bool not_array = false;
+    if (!json_split_array(data, len, el, off, not_array)) return "[]";
+    const size_t n = el.size();
+    std::vector<ParsedReq> reqs(n);
+    std::vector<uint8_t> parsed(n, 0), result(n, 0), decided(n, 0);
+    parallel_for(n, [&](size_t i) {
+        try { parsed[i] = parse_request((const uint8_t *)data + el[i].first, el[i].second - el[i].first, reqs[i]) ? 1 : 0; } catch (const std::exception &) { parsed[i] = 0; }
+    });
+    // the requests of each algorithm form one device batch
+    for (int alg = 0; alg < 3; alg++) {
+        const VerifyingKey *vkp = nullptr;
+        std::vector<size_t> idx, host_only;
+        for (size_t i = 0; i < n; i++) if (parsed[i] && reqs[i].alg == alg) idx.push_back(i);
+        if (idx.empty()) continue;
+        vkp = load_vk(alg);
+        if (!vkp) { printf("verifying key for %s is not initialised\n", NAMES[alg]); for (size_t i : idx) decided[i] = 1; continue; }
+        const VerifyingKey vk = *vkp;
+        std::vector<size_t> dev;
+        for (size_t i : idx) (proof_fits_device_path(reqs[i].proof, !vk.ckeys.empty()) ? dev : host_only).push_back(i);
+        bool batch_ok = false;
+        int ndev = 0;
+        if (dev.size() >= 16 && hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0) {
+            try { batch_ok = verify_batch_device(alg, vk, reqs, dev, device_ms); } catch (const std::exception &e) { fprintf(stderr, "zkprove: batch verifier: %s\n", e.what()); }
+        }
+        if (batch_ok) { for (size_t i : dev) { result[i] = 1; decided[i] = 1; } }
+        else host_only.insert(host_only.end(), dev.begin(), dev.end());
+        // everything else (and every proof of a batch that failed) individually, as Verify does
+        parallel_for(host_only.size(), [&](size_t q) {
+            const size_t i = host_only[q];
+            try { result[i] = verify_parsed(reqs[i], vk) ? 1 : 0; } catch (const std::exception &) { result[i] = 0; }
+            decided[i] = 1;
+        });
+    }
+    std::string out = "[";
+    for (size_t i = 0; i < n; i++) { if (i) out += ","; out += result[i] ? "true" : "false"; }
+    return out + "]";
+}
+
 }  // namespace
 }  // namespace zk
 
@@ -382,6 +698,40 @@ unsigned char Verify(GoSlice params) {
 }
 void VFree(void *pointer) { free(pointer); }
 
+// Extension: a JSON array of Verify requests -> a JSON array of booleans, element i answering request i exactly as Verify would.
+// Requests of one circuit are checked together on the GPU (one pairing-product equation under random coefficients, see above);
+// free the result with VFree.
+ProveReturn VerifyBatch(GoSlice params) {
+    std::string out;
+    try {
+        out = zk::verify_batch_json((const char *)params.data, (size_t)params.len, nullptr);
+    } catch (const std::exception &e) {
+        printf("%s\n", e.what());
+        out = "[]";
+    }
+    ProveReturn r;
+    r.r0 = malloc(out.size() ? out.size() : 1);
+    memcpy(r.r0, out.data(), out.size());
+    r.r1 = (long long)out.size();
+    return r;
+}
+// the same, also reporting the device time of the batch check (milliseconds; 0 when no batch ran on the device)
+ProveReturn zkp_verify_batch_timed(GoSlice params, double *device_ms) {
+    if (device_ms) *device_ms = 0;
+    std::string out;
+    try {
+        out = zk::verify_batch_json((const char *)params.data, (size_t)params.len, device_ms);
+    } catch (const std::exception &e) {
+        printf("%s\n", e.what());
+        out = "[]";
+    }
+    ProveReturn r;
+    r.r0 = malloc(out.size() ? out.size() : 1);
+    memcpy(r.r0, out.data(), out.size());
+    r.r1 = (long long)out.size();
+    return r;
+}
+
 // algorithmID 0..2; vk = gnark VerifyingKey.WriteTo bytes.  Returns 1 on success.
 unsigned char ZkpInitVerifier(unsigned char algorithmID, GoSlice vk) {
     if (algorithmID >= 3) return 0;
@@ -391,6 +741,7 @@ unsigned char ZkpInitVerifier(unsigned char algorithmID, GoSlice vk) {
         zk::vk_parse((const uint8_t *)vk.data, (size_t)vk.len, *k);
         std::lock_guard<std::mutex> lk(zk::g_vk_lock);
         zk::g_vk[algorithmID] = std::move(k);
+        zk::g_vk_version[algorithmID]++;
         return 1;
     } catch (const std::exception &e) {
         printf("error reading verifying key: %s\n", e.what());
