@@ -145,6 +145,7 @@ def roofline_objects(alg, B, mean, value_per_gpu, manifest, zinfo):
             "launch_ms": zdur_ms, "algorithmic_bytes_per_launch": zbytes,
             "whole_path_GBps": value_per_gpu * BYTES_PER_PROOF[alg] / 1e9,
             "quotient_msm": {"comb": comb, "k_or_c": zinfo[1], "clumps_or_windows": zinfo[2], "table_MiB": zinfo[3], "mixed_adds_per_proof": zinfo[4]},
+            "wire_msms": {"wire_comb": bool(zinfo[5]), "non_ternary_positions_in_A": zinfo[6], "table_MiB": zinfo[7]},
             "point_adds_per_s": adds,
             "mixed_add_peak_per_s": mb.get("g1_mixed_add_per_s"), "fp_mul_peak_per_s": mb.get("fp_mul_per_s"),
             "mixed_add_isa_ceiling_per_s": mb.get("g1_mixed_add_isa_ceiling_per_s"),
@@ -343,7 +344,7 @@ def run_rank(args):
         lines = {}
         for alg, leg, r in algs:
             value = B * world * K / r["dt"]
-            zinfo = np.zeros(5, np.int64)
+            zinfo = np.zeros(8, np.int64)
             zk.lib.zkp_quotient_msm_info(alg, zinfo.ctypes.data)
             roof, rntt = roofline_objects(alg, B, r["mean"], value / world, manifest, [int(x) for x in zinfo])
             lines[alg] = {

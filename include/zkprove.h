@@ -117,9 +117,10 @@ int zkp_bench_fetch(int algorithmID, uint8_t *proofs, uint32_t *errs);
 int ZkpSetSplit(int rank, int world);
 int zkp_split_partials(int algorithmID, uint8_t *out384);
 int zkp_split_finish(int algorithmID, int world, const uint8_t *gathered);
-/* how the quotient MSM of the current resident batch runs: info5 = {1 comb path | 0 bucket pipeline, clump size k | window bits c,
- * clumps | windows, table MiB, mixed additions per proof of its walk} */
-int zkp_quotient_msm_info(int algorithmID, long *info5);
+/* how the MSMs of the current resident batch run: info8 = {1 comb path of the quotient MSM | 0 bucket pipeline, clump size k | window bits c,
+ * clumps | windows, table MiB, mixed additions per proof of its walk, 1 when the wire MSMs use wire combs for their non-0/+-1 positions,
+ * such positions in G1.A, wire-comb table MiB} */
+int zkp_quotient_msm_info(int algorithmID, long *info8);
 /* after a step: copy out the solved wire vectors [batch][n_wires][32] and the quotient-stage products
  * f_i = A(g w^i) * B(g w^i) [batch][N][32] (canonical LE, natural order; the scalars of the folded quotient MSM, see
  * csrc/keyfold.hip) -- parity tests only */
@@ -145,6 +146,9 @@ int zkp_msm_g1(long n, long batch, const uint8_t *points, const uint8_t *scalars
 int zkp_msm_g2(long n, long batch, const uint8_t *points, const uint8_t *scalars, uint8_t *out, int c);
 /* same as zkp_msm_g1 through the dense (quotient-MSM) sort path: no 0/+-1 fast path, two-level sort when c >= 9 */
 int zkp_msm_g1_dense(long n, long batch, const uint8_t *points, const uint8_t *scalars, uint8_t *out, int c);
+/* wire MSM (0 / +-1 fast path + bucket pipeline) with a wire comb attached: cls[n] = width class of each base's scalars (0: 0 / +-1,
+ * 1: < 2^8, 2: < 2^32, 3: any); group 1 = G1, 2 = G2; values wider than their class must still give the right sum (bucket hand-over) */
+int zkp_msm_wire_comb(int group, long n, long batch, const uint8_t *points, const uint8_t *scalars, uint8_t *out, int c, int k, const uint8_t *cls);
 /* same sum through the fixed-base bit-plane comb of the quotient MSM of large batches (csrc/msm_comb.hip): clumps of k bases, table
  * of their signed subset sums; mode 1 passes the scalars as products of two matrices (the prover's call shape).
  * returns 0, or 1 when the bases are degenerate for the comb (point at infinity, coinciding subset sum) and nothing was computed */

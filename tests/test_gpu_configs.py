@@ -80,6 +80,9 @@ def test_config3_aes256_full_size_batch_every_proof_verifies(zk, oracle):
     proofs, errs = rb.fetch()
     assert not errs.any()
     assert np.array_equal(proofs, single), "pipelined passes differ from the single pass in records %s" % np.nonzero((proofs != single).any(axis=1))[0][:10]
+    info = np.zeros(8, np.int64)
+    assert zk.lib.zkp_quotient_msm_info(alg, info.ctypes.data) == 0
+    assert info[0] == 1 and info[5] == 1 and info[6] > 1000, "a 1024-batch of the AES circuit must run the quotient comb and the wire combs: %s" % info
     ser = [zk.proof_serialize(proofs[k], True) for k in range(B)]
     assert len(set(ser)) == B and all(len(s) == 196 for s in ser)
 

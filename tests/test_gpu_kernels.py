@@ -173,6 +173,44 @@ def test_msm_comb_refuses_degenerate_bases(zk, oracle):
         assert zk.lib.zkp_msm_comb(n, batch, p.ctypes.data, sc.ctypes.data, got.ctypes.data, 8, 0) == 0
         assert np.array_equal(got, np.stack([oracle.msm_g1(p, sc[b]) for b in range(batch)]))
 
+@pytest.mark.parametrize("group,n,batch,k", [(1, 900, 70, 8), (2, 400, 66, 6), (1, 61, 65, 16)])
+def test_msm_wire_comb_matches_oracle(zk, oracle, group, n, batch, k):
+    """wire MSMs of the AES circuits at batches that fill wavefronts: positions calibrated as bytes / 32-bit words / full-width values go
+    through comb tables of their class (msm_comb.hip via msm_attach_wire_comb), the rest through the 0 / +-1 fast path; a value WIDER
+    than its position's class, and a non-ternary value at an uncalibrated position, must be handed to the bucket pipeline and still
+    give the exact sum"""
+    rng = np.random.default_rng(8300 + n + k)
+    pts = (oracle.g1_fixed_base if group == 1 else oracle.g2_fixed_base)(_rand_fr(rng, n))
+    cls = rng.choice([0, 0, 0, 0, 1, 2, 3, 3], size=n).astype(np.uint8)
+    cls[:4] = [3, 1, 2, 0]
+    sc = np.zeros((batch, n, 32), np.uint8)
+    le = lambda v: np.frombuffer(int(v).to_bytes(32, "little"), np.uint8)
+    for b in range(batch):
+        for i in range(n):
+            c = cls[i]
+            if c == 0:
+                v = [0, 0, 1, R - 1][int(rng.integers(0, 4))]
+            elif c == 1:
+                v = int(rng.integers(0, 256))
+            elif c == 2:
+                v = int(rng.integers(0, 1 << 32))
+            else:
+                v = int.from_bytes(rng.bytes(32), "little") % R
+            sc[b, i] = le(v)
+    # class violations and stray wide values, in a few instances only
+    sc[0, 1] = le(1 << 8)                   # byte position, 9 bits
+    sc[1, 2] = le((1 << 32) + 5)            # word position, 33 bits
+    sc[2, 1] = le(R - 2)                    # byte position, full width
+    sc[3, 3] = le(123456789)                # 0 / +-1 position, not ternary
+    sc[4, 0] = le(0)                        # wide position holding 0, 1, -1
+    sc[5, 0] = le(1); sc[6, 0] = le(R - 1)
+    msm = oracle.msm_g1 if group == 1 else oracle.msm_g2
+    exp = np.stack([msm(pts, sc[b]) for b in range(batch)])
+    got = np.zeros((batch, 64 * group), np.uint8)
+    rc = zk.lib.zkp_msm_wire_comb(group, n, batch, pts.ctypes.data, sc.ctypes.data, got.ctypes.data, 9, k, cls.ctypes.data)
+    assert rc == 0, zk.last_error()
+    assert np.array_equal(got, exp)
+
 def test_msm_dense_all_equal_scalars_overflows_lds_bins(zk, oracle):
     """adversarial input: identical scalars put every entry of a window into ONE bucket (bins far beyond the LDS capacity
     of the bin sort, one thread's piece spanning a single huge bucket)"""

@@ -363,7 +363,7 @@ def test_full_size_batch_every_proof_verifies(zk, oracle):
     proofs, errs = rb.fetch()
     assert not errs.any()
     assert np.array_equal(proofs, single), "pipelined passes differ from the single pass in records %s" % np.nonzero((proofs != single).any(axis=1))[0][:10]
-    info = np.zeros(5, np.int64)
+    info = np.zeros(8, np.int64)
     assert zk.lib.zkp_quotient_msm_info(alg, info.ctypes.data) == 0 and info[0] == 1, "a 1024-batch must take the comb path of the quotient MSM"
     ser = [zk.proof_serialize(proofs[k], False) for k in range(B)]
     assert len(set(ser)) == B

@@ -47,6 +47,7 @@ _sig("zkp_msm_g1", _i32, [_i64, _i64, _vp, _vp, _vp, _i32])
 _sig("zkp_msm_g2", _i32, [_i64, _i64, _vp, _vp, _vp, _i32])
 _sig("zkp_msm_g1_dense", _i32, [_i64, _i64, _vp, _vp, _vp, _i32])
 _sig("zkp_msm_comb", _i32, [_i64, _i64, _vp, _vp, _vp, _i32, _i32])
+_sig("zkp_msm_wire_comb", _i32, [_i32, _i64, _i64, _vp, _vp, _vp, _i32, _i32, _vp])
 _sig("zkp_bench_comb", _i32, [_i32, _i64, _i32, _i32, _vp])
 _sig("zkp_fold_quotient_bases", _i32, [_i32, _i64, _vp, _vp, _vp])
 _sig("zkp_fold_output_matrix", _i64, [_i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp])

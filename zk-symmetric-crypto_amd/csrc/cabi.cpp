@@ -286,6 +286,35 @@ void prepare(const Json &j, Prepared &p) {
     }
 }
 
+// Synthetic, CONSISTENT witness assignments for the wire-comb calibration of Algorithm::wire_comb_prepare (which wire positions ever
+// hold values other than 0 / +-1, and how wide): n requests with pseudo-random key / nonce / counter / plaintext through the same
+// cipher + packing code as real requests.  Fixed seed: the calibration, and with it the kernel schedule, is reproducible.
+void make_calibration(int alg, size_t n, std::vector<uint32_t> &inputs, std::vector<U256> &rnd) {
+    uint64_t st = 0xC0FFEE1234567ull + (uint64_t)alg;
+    auto next = [&] { st += 0x9E3779B97F4A7C15ull; uint64_t z = st; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); };
+    auto fill = [&](std::vector<uint8_t> &v, size_t len) { v.resize(len); for (auto &b : v) b = (uint8_t)next(); };
+    const int nblk = ALGS[alg].kind == 0 ? CHACHA_BLOCKS : AES_BLOCKS;
+    inputs.clear(); rnd.clear();
+    for (size_t i = 0; i < n; i++) {
+        Request rq;
+        rq.alg = alg;
+        fill(rq.key, alg == 1 ? 16 : 32);
+        std::vector<uint8_t> nonce;
+        fill(nonce, 12);
+        const uint32_t ctr = (uint32_t)next() & 0x7fffffffu;
+        for (int b = 0; b < nblk; b++) { rq.nonces.push_back(nonce); rq.counters.push_back(ctr + (uint32_t)b); }
+        fill(rq.input, ALGS[alg].kind == 0 ? 64 * CHACHA_BLOCKS : 16 * AES_BLOCKS);
+        std::vector<uint32_t> w;
+        std::vector<uint8_t> out;
+        build_witness(rq, w, out);
+        inputs.insert(inputs.end(), w.begin(), w.end());
+        U256 v;
+        for (int k = 0; k < 8; k++) v.l[k] = (uint32_t)next();
+        v.l[7] &= 0x0fffffffu;                   // < 2^252 < r
+        rnd.push_back(v);
+    }
+}
+
 // Prove prepared requests of ONE algorithm: one GPU batch per device replica (chunked and pipelined inside
 // Algorithm::prove_batch).  With more than one replica the requests are cut into contiguous slices, one per device, each driven
 // by its own host thread (which binds that device); the proofs are independent, so there is no exchange between devices and the
@@ -786,6 +815,7 @@ unsigned char InitAlgorithm(unsigned char algorithmID, GoSlice provingKey, GoSli
                 for (int d : devs) a->comb_share += (d == devs[k]);
                 a->comb_share -= 1;
                 a->load((const uint8_t *)provingKey.data, (size_t)provingKey.len, (const uint8_t *)r1cs.data, (size_t)r1cs.len);
+                make_calibration(algorithmID, 64, a->calib_inputs, a->calib_rnd);
                 reps[k] = std::move(a);
             } catch (const std::exception &e) {
                 fail[k] = e.what();
@@ -897,19 +927,27 @@ int zkp_split_finish(int id, int world, const uint8_t *gathered) {
     return 0;
     CABI_CATCH
 }
-// how the quotient MSM of the current resident batch runs: info[0] = 1 comb path (msm_comb.hip) / 0 bucket pipeline, [1] = clump size k
-// (comb) or window bits c (buckets), [2] = clumps (comb) or windows, [3] = table MiB, [4] = mixed additions per proof of its walk
-int zkp_quotient_msm_info(int id, long *info5) {
+// how the MSMs of the current resident batch run: info[0] = 1 comb path of the quotient MSM (msm_comb.hip) / 0 bucket pipeline, [1] = clump size k
+// (comb) or window bits c (buckets), [2] = clumps (comb) or windows, [3] = table MiB, [4] = mixed additions per proof of its walk,
+// [5] = 1 when the wire MSMs run their non-0/+-1 positions through wire combs, [6] = those positions in G1.A, [7] = wire-comb table MiB (all base sets)
+int zkp_quotient_msm_info(int id, long *info8) {
     CABI_TRY
     Algorithm *a = (id >= 0 && id < 3) ? get_alg(id) : nullptr;
     if (!a || !a->res) throw ZkError("algorithm not initialised / nothing uploaded");
     if (a->comb_active()) {
         const CombBases &cb = a->pk.Zcomb;
-        info5[0] = 1; info5[1] = cb.k; info5[2] = (long)cb.nclumps; info5[3] = (long)(cb.table.bytes() >> 20); info5[4] = (long)cb.nclumps * 254;
+        info8[0] = 1; info8[1] = cb.k; info8[2] = (long)cb.nclumps; info8[3] = (long)(cb.table.bytes() >> 20); info8[4] = (long)cb.nclumps * 254;
     } else {
         const MsmBasesG1 &z = a->pk.Z;
-        info5[0] = 0; info5[1] = z.c; info5[2] = z.W; info5[3] = (long)(z.table.bytes() >> 20); info5[4] = (long)z.n * z.W;
+        info8[0] = 0; info8[1] = z.c; info8[2] = z.W; info8[3] = (long)(z.table.bytes() >> 20); info8[4] = (long)z.n * z.W;
     }
+    info8[5] = a->wire_comb_on && a->res->B > 64 ? 1 : 0;
+    long pos = 0;
+    size_t bytes = 0;
+    for (auto &cb : a->pk.A.wcomb) pos += (long)cb->n;
+    for (const MsmBasesG1 *mb : {&a->pk.A, &a->pk.B1, &a->pk.K, &a->pk.ped, &a->pk.ped_sigma}) for (auto &cb : mb->wcomb) bytes += cb->table.bytes();
+    for (auto &cb : a->pk.B2.wcomb) bytes += cb->table.bytes();
+    info8[6] = pos; info8[7] = (long)(bytes >> 20);
     return 0;
     CABI_CATCH
 }

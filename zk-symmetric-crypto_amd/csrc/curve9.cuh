@@ -119,4 +119,12 @@ struct alignas(16) XYZZ9 {         // 144 bytes: bucket sums travel between the 
 using G1X9 = XYZZ9<Fp9>;
 using G2X9 = XYZZ9<Fp29>;
 
+// 9-limb counterparts of the coordinate fields
+template <class F>
+struct Nine;
+template <>
+struct Nine<Fp> { using F9 = Fp9; using X9 = G1X9; };
+template <>
+struct Nine<Fp2> { using F9 = Fp29; using X9 = G2X9; };
+
 }  // namespace zk

@@ -1,5 +1,6 @@
 // Internal C++ interface between the HIP kernel translation units and the prover host code.
 #pragma once
+#include <memory>
 #include <vector>
 #include "common.h"
 #include "curve.cuh"
@@ -26,6 +27,46 @@ struct NttDomain {
 void fr_to_mont(Fr *a, size_t total, hipStream_t s);
 void fr_from_mont(Fr *a, size_t total, hipStream_t s);
 
+// ------------------------------------------------------------------------------- comb MSM (msm_comb.hip)
+// Fixed-base bit-plane comb: per clump of k consecutive bases the table of all signed subset sums (2^(k-1) affine entries,
+// 2^261-Montgomery words, of the HALVED bases), see msm_comb.hip.  Used for the quotient MSM of large batches (T = 254 planes, scalars
+// = products formed on the fly) and, per width class, for the wire positions of the AES circuits that are not 0 / +-1 (MsmBases::wcomb).
+struct CombShape {
+    size_t n = 0, nclumps = 0, E = 0;      // bases, clumps, entries per clump
+    int k = 0, T = 254;                    // clump size, bit planes
+    DevBuf<uint32_t> rows;                 // wire comb: row of base j in the [row][B] scalar matrix
+    DevBuf<uint32_t> base_index;           // wire comb: index of base j in the owning MsmBases (for the bucket-pipeline hand-over)
+    bool ok = false;
+};
+template <class F>
+struct CombBasesT : CombShape {
+    DevBuf<Affine<F>> table;               // [nclumps][E]
+    DevBuf<Affine<F>> corr;                // (2^T - 1) * sum P_i / 2: the constant of the signed-bit form
+};
+using CombBases = CombBasesT<Fp>;
+struct CombScratch {
+    DevBuf<uint32_t> pat[2];               // [clump][T][B] table index | sign << 31; two copies: the next batch's is written while this one is walked
+    DevBuf<uint8_t> acc, r1;               // range accumulators [Q][T][B] and first-stage fold results [T/8][B] (XYZZ9 records)
+    void reserve(const CombBases &cb, size_t B, int nslots);
+};
+size_t comb_table_bytes(size_t n, int k);
+size_t comb_pattern_words(const CombShape &cb, size_t B);
+size_t comb_acc_bytes(const CombShape &cb, size_t B, size_t x9_bytes);
+size_t comb_r1_bytes(const CombShape &cb, size_t B, size_t x9_bytes);
+// false (table released): a base at infinity or a degenerate subset sum -- the caller keeps the bucket path
+bool comb_build(CombBases &cb, const G1Affine *d_points, size_t n, int k, hipStream_t s);
+bool comb_build_planes(CombBasesT<Fp> &cb, const G1Affine *d_points, size_t n, int k, int T, hipStream_t s);
+bool comb_build_planes(CombBasesT<Fp2> &cb, const G2Affine *d_points, size_t n, int k, int T, hipStream_t s);
+// scalars x[row][B] (y == nullptr) or the products x * y, Montgomery form -> pat
+void comb_patterns(const CombBases &cb, const Fr *x, const Fr *y, size_t B, uint32_t *pat, hipStream_t s);
+// wire scalars through cb.rows; values wider than cb.T planes go to the compact list (gen_*) of the bucket pipeline instead
+void comb_patterns_rows(const CombShape &cb, const Fr *scalars, size_t B, uint32_t *pat, uint32_t *gen_count, uint32_t *gen_idx, Fr *gen_val, size_t gen_stride, hipStream_t s);
+// out[b] = sum_i scalar_i(b) * P_i
+void comb_msm(const CombBases &cb, const uint32_t *pat, size_t B, CombScratch &sc, G1XYZZ *out, hipStream_t s, hipEvent_t *seg_events = nullptr);
+// the same into out[b * out_stride] (a partial-sum slot of msm_batch)
+void comb_msm_strided(const CombBasesT<Fp> &cb, const uint32_t *pat, size_t B, CombScratch &sc, G1XYZZ *out, size_t out_stride, hipStream_t s);
+void comb_msm_strided(const CombBasesT<Fp2> &cb, const uint32_t *pat, size_t B, CombScratch &sc, G2XYZZ *out, size_t out_stride, hipStream_t s);
+
 // ------------------------------------------------------------------------------------------ MSM
 // One fixed base set (a slice of the proving key) prepared for batched bucket MSMs.
 //   table[j * W + w] = 2^(c*w) * P_j   (affine, Montgomery)  -- precomputed window multiples so that
@@ -41,6 +82,13 @@ struct MsmBases {
     bool f9 = false;               // table / tern coordinates are in the 2^261-Montgomery form of field9.cuh (walked by the *9 kernels of msm.hip)
     bool dense = false;            // quotient MSM: all scalars wide, read from an instance-major copy [B][dense_stride]
     size_t dense_stride = 0;
+    // Wire comb (AES circuits; msm_comb.hip): the positions whose values are not 0 / +-1 in general -- found by a calibration solve,
+    // Algorithm::wire_comb_prepare -- by width class (8 / 32 / 254 bit planes), each with comb tables of its own.  Batches that fill
+    // whole wavefronts take these positions through the comb instead of sort -> buckets -> reduction; wide_mask tells the
+    // conditional-sum kernel to leave them alone.
+    DevBuf<Affine<F>> pts;         // the base points themselves (kept for the table build)
+    std::vector<std::unique_ptr<CombBasesT<F>>> wcomb;
+    DevBuf<uint8_t> wide_mask;     // [n]
 };
 using MsmBasesG1 = MsmBases<Fp>;
 using MsmBasesG2 = MsmBases<Fp2>;
@@ -59,6 +107,8 @@ struct MsmScratch {
     DevBuf<G1XYZZ> sums1;            // [B][nb] bucket sums G1
     DevBuf<G2XYZZ> sums2;            // [B][nb] bucket sums G2
     size_t B = 0;
+    CombScratch wire_comb;           // patterns / accumulators of the wire combs of the MSMs that share this scratch (one at a time)
+    void reserve_wire_comb(size_t pat_words, size_t acc_bytes, size_t r1_bytes) { wire_comb.pat[0].ensure(pat_words); wire_comb.acc.ensure(acc_bytes); wire_comb.r1.ensure(r1_bytes); }
     void reserve(size_t B, size_t max_entries_per_inst, size_t max_nb, size_t max_part);
     void reserve_sums(size_t B, size_t nb_g1, size_t nb_g2);
     DevBuf<uint32_t> gen_count, gen_idx;   // compact per-instance lists of the scalars that are neither 0 nor +-1
@@ -94,29 +144,6 @@ bool msm_dense_presort(const MsmBasesG1 &mb, const Fr *scalars, size_t B, MsmScr
 void fr_transpose_mul(const Fr *x, const Fr *y, Fr *out, size_t rows, size_t B, size_t stride, hipStream_t s);
 
 
-// ------------------------------------------------------------------------------- comb MSM (msm_comb.hip)
-// Fixed-base bit-plane comb for the quotient MSM of large batches: per clump of k consecutive bases the table of all signed subset
-// sums (2^(k-1) affine entries, 2^261-Montgomery words, of the HALVED bases), see msm_comb.hip.
-struct CombBases {
-    size_t n = 0, nclumps = 0, E = 0;      // bases, clumps, entries per clump
-    int k = 0;
-    DevBuf<G1Affine> table;                // [nclumps][E]
-    DevBuf<G1Affine> corr;                 // (2^254 - 1) * sum P_i / 2: the constant of the signed-bit form
-    bool ok = false;
-};
-struct CombScratch {
-    DevBuf<uint32_t> pat[2];               // [clump][254][B] table index | sign << 31; two copies: the next batch's is written while this one is walked
-    DevBuf<uint8_t> acc, r1;               // range accumulators [Q][254][B] and first-stage fold results [32][B] (G1X9 records)
-    void reserve(const CombBases &cb, size_t B, int nslots);
-};
-size_t comb_table_bytes(size_t n, int k);
-// false (table released): a base at infinity or a degenerate subset sum -- the caller keeps the bucket path
-bool comb_build(CombBases &cb, const G1Affine *d_points, size_t n, int k, hipStream_t s);
-// scalars x[row][B] (y == nullptr) or the products x * y, Montgomery form -> pat
-void comb_patterns(const CombBases &cb, const Fr *x, const Fr *y, size_t B, uint32_t *pat, hipStream_t s);
-// out[b] = sum_i scalar_i(b) * P_i
-void comb_msm(const CombBases &cb, const uint32_t *pat, size_t B, CombScratch &sc, G1XYZZ *out, hipStream_t s, hipEvent_t *seg_events = nullptr);
-
 // BSB22 challenges H2F(commitment.Marshal(), "bsb22-commitment") of n canonical affine commitments, Montgomery form (prover.hip)
 void bsb22_challenge_device(const G1Affine *com_canonical, Fr *challenge_mont, size_t n, hipStream_t s);
 
@@ -131,6 +158,14 @@ struct OutputTerm { uint32_t wire, cons, coeff; };
 // out_rows (ascending) = rows_k united with the wires of the terms; out_points[i] = K'_{out_rows[i]}.  d_coeffs: Montgomery.
 void fold_output_matrix(const G1Affine *d_zc, const G1Affine *d_k, const std::vector<uint32_t> &rows_k, std::vector<OutputTerm> terms,
                         const Fr *d_coeffs, DevBuf<G1Affine> &out_points, std::vector<uint32_t> &out_rows, hipStream_t s);
+
+// wire comb: cls[j] (host, per base of mb: 0 = 0 / +-1 only, 1 = < 2^8, 2 = < 2^32, 3 = any) -> tables per non-empty class, clumps of k
+// bases; false when a table cannot be built (degenerate bases): mb is left without a wire comb
+bool msm_attach_wire_comb(MsmBasesG1 &mb, const uint8_t *cls, int k, hipStream_t s);
+bool msm_attach_wire_comb(MsmBasesG2 &mb, const uint8_t *cls, int k, hipStream_t s);
+// scratch the wire combs of mb need at batch size B: pattern words, accumulator bytes, first-stage fold bytes (0 when mb has none)
+void msm_wire_comb_needs(const MsmBasesG1 &mb, size_t B, size_t &pat_words, size_t &acc_bytes, size_t &r1_bytes);
+void msm_wire_comb_needs(const MsmBasesG2 &mb, size_t B, size_t &pat_words, size_t &acc_bytes, size_t &r1_bytes);
 
 // number of XYZZ partial slots per instance that msm_batch needs in MsmScratch::part*
 size_t msm_part_stride(size_t n, int c);

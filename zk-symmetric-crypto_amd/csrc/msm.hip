@@ -52,6 +52,7 @@ static constexpr int ONES_GROUPS = 128 / TERN_G;           // groups per conditi
 static_assert(pow3(TERN_G) <= 65536, "group patterns are parked as 16-bit words");
 static constexpr int ONES_CHUNK = TERN_G * ONES_GROUPS;    // base points per conditional-sum thread
 static constexpr int SORT_THREADS = 1024;
+static constexpr int WCOMB_CLASSES = 3;                     // wire-comb width classes: 8, 32, 254 bit planes
 
 static bool tree_enabled();
 // G1 bucket accumulation on the 9 x 29-bit field (field9.cuh): on unless ZKPROVE_MSM_F9=0 (A/B runs) or the affine-tree experiment,
@@ -121,6 +122,10 @@ static void bases_build(MsmBases<F> &mb, const Affine<F> *d_points, size_t n, co
     mb.dense = (h_rows == nullptr);
     mb.scalar_row.alloc(n ? n : 1);
     if (n && h_rows) ZK_HIP(hipMemcpyAsync(mb.scalar_row.p, h_rows, n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    if (n && h_rows) {          // wire MSM: the points are kept for a later wire-comb table build (msm_attach_wire_comb)
+        mb.pts.alloc(n);
+        ZK_HIP(hipMemcpyAsync(mb.pts.p, d_points, n * sizeof(Affine<F>), hipMemcpyDeviceToDevice, s));
+    }
     size_t tot = n * mb.W;
     mb.table.alloc(tot ? tot : 1);
     const size_t ngroups = mb.dense ? 0 : (n + TERN_G - 1) / TERN_G;
@@ -498,12 +503,6 @@ __global__ __launch_bounds__(256) void k_msm_binsort(const uint32_t *__restrict_
 // Acc9: the 9 x 29-bit field (field9.cuh / curve9.cuh; Fp9 for G1, the tower Fp29 for G2) -- the table then holds the 2^261-Montgomery
 // form (bases_build), the bucket sums are XYZZ9 records read by k_msm_bucket_reduce9, which hands the canonical 2^256 form on.
 // 9-limb counterparts of the coordinate fields
-template <class F>
-struct Nine;
-template <>
-struct Nine<Fp> { using F9 = Fp9; using X9 = G1X9; };
-template <>
-struct Nine<Fp2> { using F9 = Fp29; using X9 = G2X9; };
 
 template <class F>
 struct AccWords {
@@ -702,7 +701,7 @@ template <class F>
 __global__ __launch_bounds__(256, ZK_FP2_WAVES(F)) void k_msm_ones(const Affine<F> *__restrict__ tern, const Fr *__restrict__ scalars, size_t B,
                                                   const uint32_t *__restrict__ rows, size_t n, XYZZ<F> *__restrict__ part,
                                                   size_t part_stride, size_t part_off, uint32_t *__restrict__ gen_count,
-                                                  uint32_t *__restrict__ gen_idx, Fr *__restrict__ gen_val) {
+                                                  uint32_t *__restrict__ gen_idx, Fr *__restrict__ gen_val, const uint8_t *__restrict__ wide_mask) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t nchunks = (n + ONES_CHUNK - 1) / ONES_CHUNK;
     if (t >= nchunks * B) return;
@@ -729,7 +728,7 @@ __global__ __launch_bounds__(256, ZK_FP2_WAVES(F)) void k_msm_ones(const Affine<
             for (int q = 0; q < TERN_G; q++, p3 *= 3) {
                 if (jb + q >= j1) break;
                 const Fr &s = sv[q];
-                if (s.is_zero()) continue;
+                if (s.is_zero() || (wide_mask && wide_mask[jb + q])) continue;      // a wire-comb position: not this kernel's
                 if (s == one) idx += p3;
                 else if (s == mone) idx -= p3;
                 else { const uint32_t k = (uint32_t)(g * TERN_G + q); gen[k >> 5] |= 1u << (k & 31); }
@@ -781,7 +780,7 @@ template <class F>
 __global__ __launch_bounds__(256, ZK_FP2_WAVES(F)) void k_msm_ones9(const Affine<F> *__restrict__ tern, const Fr *__restrict__ scalars, size_t B,
                                                                     const uint32_t *__restrict__ rows, size_t n, XYZZ<F> *__restrict__ part,
                                                                     size_t part_stride, size_t part_off, uint32_t *__restrict__ gen_count,
-                                                                    uint32_t *__restrict__ gen_idx, Fr *__restrict__ gen_val) {
+                                                                    uint32_t *__restrict__ gen_idx, Fr *__restrict__ gen_val, const uint8_t *__restrict__ wide_mask) {
     using F9 = typename Nine<F>::F9;
     using X9 = typename Nine<F>::X9;
     __shared__ uint16_t spat[ONES_GROUPS][256];
@@ -809,7 +808,7 @@ __global__ __launch_bounds__(256, ZK_FP2_WAVES(F)) void k_msm_ones9(const Affine
             for (int q = 0; q < TERN_G; q++, p3 *= 3) {
                 if (jb + q >= j1) break;
                 const Fr &sc = sv[q];
-                if (sc.is_zero()) continue;
+                if (sc.is_zero() || (wide_mask && wide_mask[jb + q])) continue;     // a wire-comb position: not this kernel's
                 if (sc == one) idx += p3;
                 else if (sc == mone) idx -= p3;
                 else { const uint32_t k = (uint32_t)(g * TERN_G + q); gen[k >> 5] |= 1u << (k & 31); }
@@ -1068,6 +1067,60 @@ static void msm_fold_parts(XYZZ<F> *part, size_t stride, size_t npart, XYZZ<F> *
     ZK_HIP(hipGetLastError());
 }
 
+// ------------------------------------------------------------------------------------------- wire comb
+template <class F>
+static void wire_comb_needs(const MsmBases<F> &mb, size_t B, size_t &pat_words, size_t &acc_bytes, size_t &r1_bytes) {
+    pat_words = acc_bytes = r1_bytes = 0;
+    for (auto &cb : mb.wcomb) {
+        pat_words = std::max(pat_words, comb_pattern_words(*cb, B));
+        acc_bytes = std::max(acc_bytes, comb_acc_bytes(*cb, B, sizeof(typename Nine<F>::X9)));
+        r1_bytes = std::max(r1_bytes, comb_r1_bytes(*cb, B, sizeof(typename Nine<F>::X9)));
+    }
+}
+void msm_wire_comb_needs(const MsmBasesG1 &mb, size_t B, size_t &p, size_t &a, size_t &r) { wire_comb_needs<Fp>(mb, B, p, a, r); }
+void msm_wire_comb_needs(const MsmBasesG2 &mb, size_t B, size_t &p, size_t &a, size_t &r) { wire_comb_needs<Fp2>(mb, B, p, a, r); }
+
+template <class F>
+__global__ __launch_bounds__(256) void k_gather_points(const Affine<F> *__restrict__ pts, const uint32_t *__restrict__ idx, size_t n, Affine<F> *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = pts[idx[i]];
+}
+template <class F>
+static bool attach_wire_comb(MsmBases<F> &mb, const uint8_t *cls, int k, hipStream_t s) {
+    static const int PLANES[WCOMB_CLASSES] = {8, 32, 254};
+    mb.wcomb.clear();
+    mb.wide_mask.release();
+    if (!mb.n || mb.dense || !mb.f9 || !mb.pts.n) return true;
+    std::vector<uint32_t> rows(mb.n);
+    ZK_HIP(hipMemcpy(rows.data(), mb.scalar_row.p, mb.n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    std::vector<uint8_t> mask(mb.n, 0);
+    std::vector<std::unique_ptr<CombBasesT<F>>> built;
+    for (int c = 0; c < WCOMB_CLASSES; c++) {
+        std::vector<uint32_t> idx, crow;
+        for (size_t j = 0; j < mb.n; j++)
+            if (cls[j] == c + 1) { idx.push_back((uint32_t)j); crow.push_back(rows[j]); mask[j] = 1; }
+        if (idx.empty()) continue;
+        std::unique_ptr<CombBasesT<F>> cb(new CombBasesT<F>());
+        DevBuf<uint32_t> didx(idx.size());
+        DevBuf<Affine<F>> sel(idx.size());
+        didx.upload(idx.data(), idx.size(), s);
+        hipLaunchKernelGGL(k_gather_points<F>, dim3(ceil_div(idx.size(), 256)), dim3(256), 0, s, mb.pts.p, didx.p, idx.size(), sel.p);
+        const int kk = (int)std::min<size_t>((size_t)k, std::max<size_t>(2, idx.size()));
+        if (!comb_build_planes(*cb, sel.p, idx.size(), kk, PLANES[c], s)) return false;
+        cb->rows.upload(crow.data(), crow.size(), s);
+        cb->base_index.upload(idx.data(), idx.size(), s);
+        ZK_HIP(hipStreamSynchronize(s));
+        built.push_back(std::move(cb));
+    }
+    if (built.empty()) return true;
+    mb.wide_mask.upload(mask.data(), mask.size(), s);
+    ZK_HIP(hipStreamSynchronize(s));
+    mb.wcomb = std::move(built);
+    return true;
+}
+bool msm_attach_wire_comb(MsmBasesG1 &mb, const uint8_t *cls, int k, hipStream_t s) { return attach_wire_comb<Fp>(mb, cls, k, s); }
+bool msm_attach_wire_comb(MsmBasesG2 &mb, const uint8_t *cls, int k, hipStream_t s) { return attach_wire_comb<Fp2>(mb, cls, k, s); }
+
 template <class F>
 static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, MsmScratch &sc, XYZZ<F> *out, hipStream_t s, hipEvent_t *seg_events) {
     const size_t n = mb.n;
@@ -1077,7 +1130,15 @@ static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, M
     const size_t nseg = nb / L;
     const size_t nchunks = mb.dense ? 0 : (n + ONES_CHUNK - 1) / ONES_CHUNK;      // the dense MSM has no conditional-sum partials
     const size_t max_entries = n * W;
-    const size_t npart = nchunks + nseg;
+    // wire combs: batches that fill whole wavefronts, scratch reserved (Algorithm::wire_comb_prepare), 9-limb tables
+    bool wcomb = !mb.dense && !mb.wcomb.empty() && mb.f9 && B > 64;
+    if (wcomb) {
+        size_t pw = 0, ab = 0, rb = 0;
+        wire_comb_needs(mb, B, pw, ab, rb);
+        wcomb = sc.wire_comb.pat[0].n >= pw && sc.wire_comb.acc.n >= ab && sc.wire_comb.r1.n >= rb;
+    }
+    const size_t nw = wcomb ? mb.wcomb.size() : 0;
+    const size_t npart = nchunks + nseg + nw;
     const size_t stride = msm_part_stride(n, c);      // level-0 partials followed by the fold levels
     if (sc.entries.n < B * max_entries + 1 || sc.bucket_start.n < B * (nb + 1) || PartSel<F>::cap(sc) < B * stride + 1)
         throw ZkError("msm scratch too small");
@@ -1122,10 +1183,16 @@ static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, M
         ZK_HIP(hipMemsetAsync(sc.gen_count.p, 0, B * sizeof(uint32_t), s));
         if (mb.f9)
             hipLaunchKernelGGL(k_msm_ones9<F>, dim3(ceil_div(nchunks * B, 256)), dim3(256), 0, s, mb.tern.p, scalars, B, mb.scalar_row.p, n, part, stride,
-                               (size_t)0, sc.gen_count.p, sc.gen_idx.p, sc.gen_val.p);
+                               (size_t)0, sc.gen_count.p, sc.gen_idx.p, sc.gen_val.p, wcomb ? mb.wide_mask.p : (const uint8_t *)nullptr);
         else
             hipLaunchKernelGGL(k_msm_ones<F>, dim3(ceil_div(nchunks * B, 256)), dim3(256), 0, s, mb.tern.p, scalars, B, mb.scalar_row.p, n, part,
-                               stride, (size_t)0, sc.gen_count.p, sc.gen_idx.p, sc.gen_val.p);
+                               stride, (size_t)0, sc.gen_count.p, sc.gen_idx.p, sc.gen_val.p, (const uint8_t *)nullptr);
+        // wire-comb positions: patterns (values too wide for their class join the compact list) -> walk -> fold into a partial-sum slot
+        for (size_t ci = 0; ci < nw; ci++) {
+            const CombBasesT<F> &cb = *mb.wcomb[ci];
+            comb_patterns_rows(cb, scalars, B, sc.wire_comb.pat[0].p, sc.gen_count.p, sc.gen_idx.p, sc.gen_val.p, n, s);
+            comb_msm_strided(cb, sc.wire_comb.pat[0].p, B, sc.wire_comb, part + nchunks + nseg + ci, stride, s);
+        }
         hipLaunchKernelGGL(k_msm_sort<false>, dim3((unsigned)B), dim3(SORT_THREADS), lds, s, (const Fr *)nullptr, (size_t)0, sc.gen_count.p, sc.gen_idx.p,
                            sc.gen_val.p, n, c, W, sc.bucket_start.p, sc.entries.p, max_entries);
     }
@@ -1149,7 +1216,7 @@ void msm_batch(const MsmBasesG2 &mb, const Fr *sc, size_t B, MsmScratch &scr, G2
 size_t msm_part_stride(size_t n, int c) {
     const uint32_t nb = 1u << (c - 1);
     const uint32_t L = nb > (1u << SEG_LOG_SMALL) ? (1u << SEG_LOG_SMALL) : nb;     // the small-batch segment length gives the most partials
-    size_t npart = (n + ONES_CHUNK - 1) / ONES_CHUNK + nb / L, total = 0;
+    size_t npart = (n + ONES_CHUNK - 1) / ONES_CHUNK + nb / L + WCOMB_CLASSES, total = 0;      // + one slot per wire-comb class
     for (size_t cnt = npart; cnt > 1; cnt = (cnt + FOLD_GROUP - 1) / FOLD_GROUP) total += cnt;
     return total + 2;
 }

@@ -21,58 +21,65 @@
 //   * the 254 (x Q) accumulators of a proof are folded by a Horner chain of doublings (254 doublings per proof against ~900 k
 //     additions of the walk).
 // Any correct schedule yields the same group element, so the result is bit-identical to the bucket path and to the oracle.
+//
+// The same machinery serves the WIRE MSMs of the AES circuits (G1 and G2; msm.hip, MsmBases::wcomb): the few thousand wire positions
+// whose values are not 0 / +-1 (bytes, 32-bit words, log-derivative inverses -- fixed by the circuit, found by a calibration solve at
+// the first large batch) get comb tables of their own, one per width class (8 / 32 / 254 bit planes); a value that does not fit its
+// class at run time is handed to the bucket pipeline instead, so the result never depends on the calibration.
 #include <algorithm>
 #include "kernels.h"
 #include "curve9.cuh"
 
 namespace zk {
 
-static constexpr int COMB_T = 254;              // bit planes: scalars are canonical, < r < 2^254
+static constexpr int COMB_T = 254;              // bit planes of the quotient MSM: scalars are canonical, < r < 2^254
 static constexpr int COMB_KMAX = 24;
-static constexpr int COMB_G = 4;                // clumps per table-build thread (one shared inversion)
 static constexpr int FOLD_BITS = 8;             // bit planes per thread of the first fold stage
-static constexpr int FOLD_GROUPS = (COMB_T + FOLD_BITS - 1) / FOLD_BITS;
+static inline int fold_groups(int T) { return (T + FOLD_BITS - 1) / FOLD_BITS; }
 
 __host__ __device__ static inline size_t zmin(size_t a, size_t b) { return a < b ? a : b; }
 // (r + 1) / 2: halving a point of the order-r group
 __device__ static const uint32_t HALF_SCALAR[8] = {0xf8000001u, 0xa1f0fac9u, 0x3cdcb848u, 0x9419f424u, 0x40c0ac2eu, 0xdc2822dbu, 0x7098d014u, 0x18322739u};
 
 // ----------------------------------------------------------------------------------------------- table build
-__global__ __launch_bounds__(64) void k_comb_halve(const G1Affine *__restrict__ pts, size_t n, G1Affine *__restrict__ out, uint32_t *__restrict__ bad) {
+template <class F>
+__global__ __launch_bounds__(64) void k_comb_halve(const Affine<F> *__restrict__ pts, size_t n, Affine<F> *__restrict__ out, uint32_t *__restrict__ bad) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const G1Affine p = pts[i];
-    if (p.is_inf()) { atomicAdd(bad, 1u); out[i] = G1Affine::inf(); return; }      // a base at infinity has no "+-1" form: bucket path
+    const Affine<F> p = pts[i];
+    if (p.is_inf()) { atomicAdd(bad, 1u); out[i] = Affine<F>::inf(); return; }      // a base at infinity has no "+-1" form: bucket path
     uint32_t k[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) k[j] = HALF_SCALAR[j];
     out[i] = scalar_mul(p, k, 254).to_affine();
 }
 // level 0 of every clump: the single entry +P'_top
-__global__ __launch_bounds__(256) void k_comb_seed(const G1Affine *__restrict__ half, size_t n, int k, size_t nclumps, size_t E, G1Affine *__restrict__ table) {
+template <class F>
+__global__ __launch_bounds__(256) void k_comb_seed(const Affine<F> *__restrict__ half, size_t n, int k, size_t nclumps, size_t E, Affine<F> *__restrict__ table) {
     const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nclumps) return;
     const size_t kc = zmin((size_t)k, n - c * k);
     table[c * E] = half[c * k + kc - 1];
 }
 // level j: entries [0, 2^j) of a clump hold the signed sums over its top base and bases 0..j-1; base j is added with both signs:
-// idx -> idx (minus) and idx + 2^j (plus).  Affine additions; the COMB_G clumps of a thread share one inversion (Montgomery's trick).
+// idx -> idx (minus) and idx + 2^j (plus).  Affine additions; the G clumps of a thread share one inversion (Montgomery's trick).
 // A coincidence x_S == x_P (a subset sum equal to +-P_j: impossible for an honest key, possible for crafted points) is counted in
 // *bad: the caller then keeps the bucket path for this key.
-__global__ __launch_bounds__(64) void k_comb_level(G1Affine *__restrict__ table, const G1Affine *__restrict__ half, size_t n, int k, size_t nclumps, size_t E, int j,
+template <class F, int G>
+__global__ __launch_bounds__(64) void k_comb_level(Affine<F> *__restrict__ table, const Affine<F> *__restrict__ half, size_t n, int k, size_t nclumps, size_t E, int j,
                                                    uint32_t *__restrict__ bad) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t per = (size_t)1 << j;
-    const size_t ngroups = (nclumps + COMB_G - 1) / COMB_G;
+    const size_t ngroups = (nclumps + G - 1) / G;
     if (t >= per * ngroups) return;
     const size_t idx = t & (per - 1), cg = t >> j;
-    G1Affine S[COMB_G], P[COMB_G];
-    Fp d[COMB_G], pre[COMB_G];
-    bool on[COMB_G];
-    Fp run = Fp::one();
+    Affine<F> S[G], P[G];
+    F d[G], pre[G];
+    bool on[G];
+    F run = F::one();
 #pragma unroll
-    for (int g = 0; g < COMB_G; g++) {
-        const size_t c = cg * COMB_G + g;
+    for (int g = 0; g < G; g++) {
+        const size_t c = cg * G + g;
         on[g] = false;
         if (c < nclumps) {
             const size_t kc = zmin((size_t)k, n - c * k);
@@ -87,15 +94,15 @@ __global__ __launch_bounds__(64) void k_comb_level(G1Affine *__restrict__ table,
         pre[g] = run;
         if (on[g]) run = run * d[g];
     }
-    Fp inv = run.inv();
+    F inv = run.inv();
 #pragma unroll
-    for (int g = COMB_G - 1; g >= 0; g--) {
+    for (int g = G - 1; g >= 0; g--) {
         if (!on[g]) continue;
-        const Fp di = inv * pre[g];          // 1 / d[g]
+        const F di = inv * pre[g];          // 1 / d[g]
         inv = inv * d[g];
-        const size_t c = cg * COMB_G + g;
-        const Fp lp = (P[g].y - S[g].y) * di, lm = (P[g].y + S[g].y).neg() * di;
-        G1Affine rp, rm;
+        const size_t c = cg * G + g;
+        const F lp = (P[g].y - S[g].y) * di, lm = (P[g].y + S[g].y).neg() * di;
+        Affine<F> rp, rm;
         rp.x = lp.sqr() - S[g].x - P[g].x;
         rp.y = lp * (S[g].x - rp.x) - S[g].y;
         rm.x = lm.sqr() - S[g].x - P[g].x;
@@ -113,27 +120,28 @@ __global__ __launch_bounds__(256) void k_comb_to_f9(Fp *__restrict__ coords, siz
     for (int j = 0; j < 8; j++) k.l[j] = Fp9Params::SCALE32[j];
     coords[i] = coords[i] * k;
 }
-// corr = (2^254 - 1) * sum_i P'_i, one workgroup: 256 partial sums over the all-plus entries of the clumps' tables (still in the
-// 2^256 form), folded by thread 0, which also does the scalar multiplication (once per key)
-__global__ __launch_bounds__(256) void k_comb_correction(const G1Affine *__restrict__ half, size_t n, G1Affine *__restrict__ corr) {
-    __shared__ G1XYZZ part[256];
-    G1XYZZ acc = G1XYZZ::inf();
-    for (size_t i = threadIdx.x; i < n; i += 256) acc.madd(half[i]);
+// corr = (2^T - 1) * sum_i P'_i, one workgroup: 128 partial sums, folded by thread 0, which also does the scalar multiplication
+// (once per key); left in the 2^261 form like the table
+template <class F>
+__global__ __launch_bounds__(128) void k_comb_correction(const Affine<F> *__restrict__ half, size_t n, int T, Affine<F> *__restrict__ corr) {
+    __shared__ XYZZ<F> part[128];
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (size_t i = threadIdx.x; i < n; i += 128) acc.madd(half[i]);
     part[threadIdx.x] = acc;
     __syncthreads();
     if (threadIdx.x != 0) return;
-    for (int i = 1; i < 256; i++) acc.add(part[i]);
-    const G1Affine total = acc.to_affine();
+    for (int i = 1; i < 128; i++) acc.add(part[i]);
+    const Affine<F> total = acc.to_affine();
     uint32_t k[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) k[j] = 0xffffffffu;
-    k[7] = 0x3fffffffu;                              // 2^254 - 1
-    G1Affine c = scalar_mul(total, k, 254).to_affine();
+    for (int j = 0; j < 8; j++) k[j] = j * 32 + 32 <= T ? 0xffffffffu : (j * 32 < T ? (1u << (T - j * 32)) - 1u : 0u);      // 2^T - 1
+    Affine<F> c = scalar_mul(total, k, T).to_affine();
     if (!c.is_inf()) {
         Fp s;
 #pragma unroll
         for (int j = 0; j < 8; j++) s.l[j] = Fp9Params::SCALE32[j];
-        c.x = c.x * s; c.y = c.y * s;
+        Fp *co = reinterpret_cast<Fp *>(&c);
+        for (size_t q = 0; q < sizeof(Affine<F>) / sizeof(Fp); q++) co[q] = co[q] * s;
     }
     corr[0] = c;
 }
@@ -143,31 +151,35 @@ size_t comb_table_bytes(size_t n, int k) {
     return nclumps * ((size_t)1 << (k - 1)) * sizeof(G1Affine);
 }
 
-bool comb_build(CombBases &cb, const G1Affine *d_points, size_t n, int k, hipStream_t s) {
+template <class F>
+static bool comb_build_impl(CombBasesT<F> &cb, const Affine<F> *d_points, size_t n, int k, int T, hipStream_t s) {
     cb.ok = false;
-    if (n == 0 || k < 2 || k > COMB_KMAX) return false;
-    cb.n = n; cb.k = k;
+    if (n == 0 || k < 2 || k > COMB_KMAX || T < 1 || T > COMB_T) return false;
+    cb.n = n; cb.k = k; cb.T = T;
     cb.nclumps = (n + k - 1) / k;
     cb.E = (size_t)1 << (k - 1);
-    DevBuf<G1Affine> half(n);
+    DevBuf<Affine<F>> half(n);
     DevBuf<uint32_t> bad(1);
     bad.zero(s);
-    hipLaunchKernelGGL(k_comb_halve, dim3(ceil_div(n, 64)), dim3(64), 0, s, d_points, n, half.p, bad.p);
+    hipLaunchKernelGGL(k_comb_halve<F>, dim3(ceil_div(n, 64)), dim3(64), 0, s, d_points, n, half.p, bad.p);
     uint32_t nbad = 0;
     bad.download(&nbad, 1, s);
     ZK_HIP(hipStreamSynchronize(s));
     if (nbad) return false;
     cb.table.alloc(cb.nclumps * cb.E);
     cb.corr.alloc(1);
-    hipLaunchKernelGGL(k_comb_seed, dim3(ceil_div(cb.nclumps, 256)), dim3(256), 0, s, half.p, n, k, cb.nclumps, cb.E, cb.table.p);
-    const size_t ngroups = (cb.nclumps + COMB_G - 1) / COMB_G;
+    hipLaunchKernelGGL(k_comb_seed<F>, dim3(ceil_div(cb.nclumps, 256)), dim3(256), 0, s, half.p, n, k, cb.nclumps, cb.E, cb.table.p);
+    constexpr int G = sizeof(F) == 32 ? 4 : 1;              // clumps per build thread (register budget)
+    const size_t ngroups = (cb.nclumps + G - 1) / G;
     for (int j = 0; j + 1 < k; j++)
-        hipLaunchKernelGGL(k_comb_level, dim3(ceil_div(ngroups << j, 64)), dim3(64), 0, s, cb.table.p, half.p, n, k, cb.nclumps, cb.E, j, bad.p);
-    hipLaunchKernelGGL(k_comb_correction, dim3(1), dim3(256), 0, s, half.p, n, cb.corr.p);
-    // the last clump may be shorter: its unused entries stay unwritten and are never indexed
-    const size_t coords = cb.nclumps * cb.E * 2;
+        hipLaunchKernelGGL((k_comb_level<F, G>), dim3(ceil_div(ngroups << j, 64)), dim3(64), 0, s, cb.table.p, half.p, n, k, cb.nclumps, cb.E, j, bad.p);
+    hipLaunchKernelGGL(k_comb_correction<F>, dim3(1), dim3(128), 0, s, half.p, n, T, cb.corr.p);
+    // the last clump may be shorter: its unused entries are never indexed (zeroed so that the scaling below reads defined memory)
+    const size_t per_point = sizeof(Affine<F>) / sizeof(Fp);
+    const size_t coords = cb.nclumps * cb.E * per_point;
     const size_t last_kc = n - (cb.nclumps - 1) * (size_t)k;
-    if (last_kc < (size_t)k) ZK_HIP(hipMemsetAsync(cb.table.p + (cb.nclumps - 1) * cb.E + ((size_t)1 << (last_kc - 1)), 0, (cb.E - ((size_t)1 << (last_kc - 1))) * sizeof(G1Affine), s));
+    if (last_kc < (size_t)k)
+        ZK_HIP(hipMemsetAsync(cb.table.p + (cb.nclumps - 1) * cb.E + ((size_t)1 << (last_kc - 1)), 0, (cb.E - ((size_t)1 << (last_kc - 1))) * sizeof(Affine<F>), s));
     hipLaunchKernelGGL(k_comb_to_f9, dim3(ceil_div(coords, 256)), dim3(256), 0, s, (Fp *)cb.table.p, coords);
     ZK_HIP(hipGetLastError());
     bad.download(&nbad, 1, s);
@@ -176,12 +188,40 @@ bool comb_build(CombBases &cb, const G1Affine *d_points, size_t n, int k, hipStr
     cb.ok = true;
     return true;
 }
+bool comb_build(CombBases &cb, const G1Affine *d_points, size_t n, int k, hipStream_t s) { return comb_build_impl<Fp>(cb, d_points, n, k, COMB_T, s); }
+bool comb_build_planes(CombBasesT<Fp> &cb, const G1Affine *d_points, size_t n, int k, int T, hipStream_t s) { return comb_build_impl<Fp>(cb, d_points, n, k, T, s); }
+bool comb_build_planes(CombBasesT<Fp2> &cb, const G2Affine *d_points, size_t n, int k, int T, hipStream_t s) { return comb_build_impl<Fp2>(cb, d_points, n, k, T, s); }
 
 // ------------------------------------------------------------------------------------------------ per batch
 // Bit planes of the scalars of one clump -> table indices.  Workgroup = 64 proofs (lanes) x one clump; the k canonical scalars of a
 // lane are parked in LDS ([j][word][lane]: conflict-free), then for every 32-bit word the 32 patterns are assembled bit by bit.
-//   y == nullptr: scalars = x[row * B + b];  else the quotient products x[row * B + b] * y[row * B + b] (Montgomery, [row][B])
 // pat[(clump * T + t) * B + b] = idx | neg << 31
+// this lane's k scalars are in lds[(j * W + w) * 64 + lane]: emit the T patterns of the clump
+__device__ __forceinline__ void comb_emit_patterns(const uint32_t *lds, int lane, int kc, int T, int W, size_t B, uint32_t *__restrict__ out) {
+    const uint32_t low_mask = (1u << (kc - 1)) - 1u;
+#pragma unroll 1
+    for (int w = 0; w < W; w++) {
+        uint32_t p[32];
+#pragma unroll
+        for (int i = 0; i < 32; i++) p[i] = 0;
+#pragma unroll 1
+        for (int j = 0; j < kc; j++) {
+            const uint32_t v = lds[(j * W + w) * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < 32; i++) p[i] |= ((v >> i) & 1u) << j;
+        }
+#pragma unroll
+        for (int i = 0; i < 32; i++) {
+            const int t = w * 32 + i;
+            if (t < T) {
+                const uint32_t top = (p[i] >> (kc - 1)) & 1u;
+                const uint32_t idx = (top ? p[i] : ~p[i]) & low_mask;
+                out[(size_t)t * B] = idx | ((top ^ 1u) << 31);
+            }
+        }
+    }
+}
+//   y == nullptr: scalars = x[row * B + b];  else the quotient products x[row * B + b] * y[row * B + b] (Montgomery, [row][B])
 __global__ __launch_bounds__(64) void k_comb_patterns(const Fr *__restrict__ x, const Fr *__restrict__ y, size_t B, size_t n, int k, uint32_t *__restrict__ pat) {
     extern __shared__ uint32_t lds[];
     const size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
@@ -197,109 +237,132 @@ __global__ __launch_bounds__(64) void k_comb_patterns(const Fr *__restrict__ x, 
 #pragma unroll
         for (int w = 0; w < 8; w++) lds[(j * 8 + w) * 64 + lane] = s.l[w];
     }
-    const uint32_t low_mask = (1u << (kc - 1)) - 1u;
-    uint32_t *out = pat + (c * COMB_T) * B + b;
-#pragma unroll 1
-    for (int w = 0; w < 8; w++) {
-        uint32_t p[32];
+    comb_emit_patterns(lds, lane, kc, COMB_T, 8, B, pat + (c * COMB_T) * B + b);
+}
+// wire scalars: base j of the comb reads row rows[j] of the [row][B] matrix.  A value that does not fit the comb's T bit planes (the
+// position was calibrated narrower than this instance's value) enters the comb as 0 and is appended to the instance's compact list
+// of the bucket pipeline (gen_idx = the base's index in the owning MsmBases), exactly as the conditional-sum kernel hands over the
+// scalars that are neither 0 nor +-1.
+__global__ __launch_bounds__(64) void k_comb_patterns_rows(const Fr *__restrict__ scalars, size_t B, size_t n, int k, int T, const uint32_t *__restrict__ rows,
+                                                           const uint32_t *__restrict__ base_index, uint32_t *__restrict__ pat, uint32_t *__restrict__ gen_count,
+                                                           uint32_t *__restrict__ gen_idx, Fr *__restrict__ gen_val, size_t gen_stride) {
+    extern __shared__ uint32_t lds[];
+    const size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
+    const size_t c = blockIdx.y;
+    const int lane = threadIdx.x;
+    const int kc = (int)zmin((size_t)k, n - c * k);
+    const int W = (T + 31) >> 5;
+    if (b >= B) return;
+    for (int j = 0; j < kc; j++) {
+        const size_t pos = c * k + j;
+        Fr s = scalars[(size_t)rows[pos] * B + b].from_mont();
+        uint32_t over = 0;
 #pragma unroll
-        for (int i = 0; i < 32; i++) p[i] = 0;
-#pragma unroll 1
-        for (int j = 0; j < kc; j++) {
-            const uint32_t v = lds[(j * 8 + w) * 64 + lane];
-#pragma unroll
-            for (int i = 0; i < 32; i++) p[i] |= ((v >> i) & 1u) << j;
+        for (int w = 0; w < 8; w++) {
+            const int lo = w * 32;
+            if (lo >= T) over |= s.l[w];
+            else if (lo + 32 > T) over |= s.l[w] >> (T - lo);
         }
-#pragma unroll
-        for (int i = 0; i < 32; i++) {
-            const int t = w * 32 + i;
-            if (t < COMB_T) {
-                const uint32_t top = (p[i] >> (kc - 1)) & 1u;
-                const uint32_t idx = (top ? p[i] : ~p[i]) & low_mask;
-                out[(size_t)t * B] = idx | ((top ^ 1u) << 31);
-            }
+        if (over) {
+            const uint32_t q = atomicAdd(&gen_count[b], 1u);
+            gen_idx[b * gen_stride + q] = base_index[pos];
+            gen_val[b * gen_stride + q] = s;
+            s = Fr::zero();
         }
+        for (int w = 0; w < W; w++) lds[(j * W + w) * 64 + lane] = s.l[w];
     }
+    comb_emit_patterns(lds, lane, kc, T, W, B, pat + (c * (size_t)T) * B + b);
 }
 
 // thread (q, t, b): acc = sum over the clumps of range q of +-T[clump][pattern(clump, t, b)]
 #ifndef ZK_COMB_WAVES
 #define ZK_COMB_WAVES 4
 #endif
-__global__ __launch_bounds__(64, ZK_COMB_WAVES) void k_comb_walk(const G1Affine *__restrict__ table, const uint32_t *__restrict__ pat, size_t B, size_t nclumps, size_t E,
-                                                                 uint32_t Q, G1X9 *__restrict__ acc_out) {
+#define ZK_COMB_BOUNDS(F) (sizeof(F) == 64 ? 2 : ZK_COMB_WAVES)
+template <class F>
+__global__ __launch_bounds__(64, ZK_COMB_BOUNDS(F)) void k_comb_walk(const Affine<F> *__restrict__ table, const uint32_t *__restrict__ pat, size_t B, size_t nclumps, size_t E,
+                                                                    int T, uint32_t Q, typename Nine<F>::X9 *__restrict__ acc_out) {
+    using F9 = typename Nine<F>::F9;
+    using X9 = typename Nine<F>::X9;
     const size_t tiles = (B + 63) / 64;
     const size_t blk = blockIdx.x;
-    const size_t bt = blk % tiles, t = (blk / tiles) % COMB_T, q = blk / (tiles * COMB_T);
+    const size_t bt = blk % tiles, t = (blk / tiles) % T, q = blk / (tiles * T);
     const size_t b = bt * 64 + threadIdx.x;
     if (b >= B) return;
     const size_t c0 = nclumps * q / Q, c1 = nclumps * (q + 1) / Q;
-    G1X9 acc = G1X9::inf();
+    X9 acc = X9::inf();
     if (c0 < c1) {
-        const uint32_t *pp = pat + (c0 * COMB_T + t) * B + b;
-        const size_t pstride = (size_t)COMB_T * B;
+        const uint32_t *pp = pat + (c0 * T + t) * B + b;
+        const size_t pstride = (size_t)T * B;
         uint32_t e = *pp;
-        G1Affine p = table[c0 * E + (e & 0x7fffffffu)];
+        Affine<F> p = table[c0 * E + (e & 0x7fffffffu)];
         for (size_t c = c0;;) {
             // only the next pattern WORD is fetched ahead; the table entry is loaded just in time (a point held across the addition
             // costs 16 live registers = a wavefront per SIMD, msm.hip accumulate_body)
             uint32_t e_next = 0;
             if (c + 1 < c1) e_next = pp[pstride];
-            acc.madd(Fp9::from_words(p.x), Fp9::cneg(Fp9::from_words(p.y), (e >> 31) ? -1 : 0));
+            acc.madd(F9::from_words(p.x), F9::cneg(F9::from_words(p.y), (e >> 31) ? -1 : 0));
             if (++c >= c1) break;
             pp += pstride;
             e = e_next;
             p = table[c * E + (e & 0x7fffffffu)];
         }
     }
-    acc_out[(q * COMB_T + t) * B + b] = acc;
+    acc_out[(q * T + t) * B + b] = acc;
 }
 
 // fold, stage 1: thread (g, b): Horner over the bit planes 8g+7 .. 8g of proof b (each plane = the sum of its Q range accumulators)
-__global__ __launch_bounds__(64) void k_comb_fold1(const G1X9 *__restrict__ acc, size_t B, uint32_t Q, G1X9 *__restrict__ r1) {
+template <class F>
+__global__ __launch_bounds__(64, ZK_COMB_BOUNDS(F)) void k_comb_fold1(const typename Nine<F>::X9 *__restrict__ acc, size_t B, int T, uint32_t Q, typename Nine<F>::X9 *__restrict__ r1) {
+    using X9 = typename Nine<F>::X9;
     const size_t tiles = (B + 63) / 64;
     const size_t g = blockIdx.x / tiles, b = (blockIdx.x % tiles) * 64 + threadIdx.x;
     if (b >= B) return;
-    const int t0 = (int)g * FOLD_BITS, t1 = (t0 + FOLD_BITS < COMB_T ? t0 + FOLD_BITS : COMB_T);
-    G1X9 r = G1X9::inf();
+    const int t0 = (int)g * FOLD_BITS, t1 = (t0 + FOLD_BITS < T ? t0 + FOLD_BITS : T);
+    X9 r = X9::inf();
 #pragma unroll 1
     for (int t = t1 - 1; t >= t0; t--) {
-        r = G1X9::dbl_of(r);
+        r = X9::dbl_of(r);
 #pragma unroll 1
-        for (uint32_t q = 0; q < Q; q++) r.add(acc[((size_t)q * COMB_T + t) * B + b]);
+        for (uint32_t q = 0; q < Q; q++) r.add(acc[((size_t)q * T + t) * B + b]);
     }
     r1[g * B + b] = r;
 }
-// stage 2: thread b: Horner over the FOLD_GROUPS partial results (8 doublings apart), + the constant of the signed-bit form
-__global__ __launch_bounds__(64) void k_comb_fold2(const G1X9 *__restrict__ r1, size_t B, const G1Affine *__restrict__ corr, G1XYZZ *__restrict__ out) {
+// stage 2: thread b: Horner over the partial results (8 doublings apart), + the constant of the signed-bit form; out[b * out_stride]
+template <class F>
+__global__ __launch_bounds__(64, ZK_COMB_BOUNDS(F)) void k_comb_fold2(const typename Nine<F>::X9 *__restrict__ r1, size_t B, int groups, const Affine<F> *__restrict__ corr,
+                                                                     XYZZ<F> *__restrict__ out, size_t out_stride) {
+    using F9 = typename Nine<F>::F9;
+    using X9 = typename Nine<F>::X9;
     const size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (b >= B) return;
-    G1X9 r = G1X9::inf();
+    X9 r = X9::inf();
 #pragma unroll 1
-    for (int g = FOLD_GROUPS - 1; g >= 0; g--) {
+    for (int g = groups - 1; g >= 0; g--) {
 #pragma unroll 1
-        for (int i = 0; i < FOLD_BITS; i++) r = G1X9::dbl_of(r);
+        for (int i = 0; i < FOLD_BITS; i++) r = X9::dbl_of(r);
         r.add(r1[(size_t)g * B + b]);
     }
-    const G1Affine c = corr[0];
-    if (!c.is_inf()) r.madd(Fp9::from_words(c.x), Fp9::from_words(c.y));
-    out[b] = r.to_xyzz();
+    const Affine<F> c = corr[0];
+    if (!c.is_inf()) r.madd(F9::from_words(c.x), F9::from_words(c.y));
+    out[b * out_stride] = r.to_xyzz();
 }
 
-static uint32_t comb_ranges(size_t B, size_t nclumps) {
+static uint32_t comb_ranges(size_t B, size_t nclumps, int T) {
     static const uint32_t forced = [] { const char *e = getenv("ZKPROVE_COMB_Q"); return e ? (uint32_t)atoi(e) : 0u; }();
     uint32_t Q = forced ? forced : 8;
-    // small batches: more ranges so that the launch still has ~1 M threads
-    while (!forced && (size_t)Q * COMB_T * B < (1u << 20) && Q < 256) Q *= 2;
+    // small batches / few planes: more ranges so that the launch still has ~1 M threads
+    while (!forced && (size_t)Q * T * B < (1u << 20) && Q < 256) Q *= 2;
     if (Q > nclumps) Q = (uint32_t)nclumps;
     return Q < 1 ? 1 : Q;
 }
+size_t comb_pattern_words(const CombShape &cb, size_t B) { return cb.nclumps * (size_t)cb.T * B; }
+size_t comb_acc_bytes(const CombShape &cb, size_t B, size_t x9_bytes) { return (size_t)comb_ranges(B, cb.nclumps, cb.T) * cb.T * B * x9_bytes; }
+size_t comb_r1_bytes(const CombShape &cb, size_t B, size_t x9_bytes) { return (size_t)fold_groups(cb.T) * B * x9_bytes; }
 void CombScratch::reserve(const CombBases &cb, size_t B, int nslots) {
-    const size_t per = cb.nclumps * COMB_T * B;
-    for (int i = 0; i < nslots && i < 2; i++) pat[i].ensure(per);
-    const uint32_t Q = comb_ranges(B, cb.nclumps);
-    acc.ensure((size_t)Q * COMB_T * B * sizeof(G1X9));
-    r1.ensure((size_t)FOLD_GROUPS * B * sizeof(G1X9));
+    for (int i = 0; i < nslots && i < 2; i++) pat[i].ensure(comb_pattern_words(cb, B));
+    acc.ensure(comb_acc_bytes(cb, B, sizeof(G1X9)));
+    r1.ensure(comb_r1_bytes(cb, B, sizeof(G1X9)));
 }
 void comb_patterns(const CombBases &cb, const Fr *x, const Fr *y, size_t B, uint32_t *pat, hipStream_t s) {
     static PerDeviceOnce once;
@@ -307,18 +370,39 @@ void comb_patterns(const CombBases &cb, const Fr *x, const Fr *y, size_t B, uint
     hipLaunchKernelGGL(k_comb_patterns, dim3(ceil_div(B, 64), (unsigned)cb.nclumps), dim3(64), (size_t)cb.k * 8 * 64 * 4, s, x, y, B, cb.n, cb.k, pat);
     ZK_HIP(hipGetLastError());
 }
-void comb_msm(const CombBases &cb, const uint32_t *pat, size_t B, CombScratch &sc, G1XYZZ *out, hipStream_t s, hipEvent_t *seg_events) {
-    if (!cb.ok) throw ZkError("comb MSM: table not built");
-    const uint32_t Q = comb_ranges(B, cb.nclumps);
-    if (sc.acc.n < (size_t)Q * COMB_T * B * sizeof(G1X9) || sc.r1.n < (size_t)FOLD_GROUPS * B * sizeof(G1X9)) throw ZkError("comb MSM: scratch too small");
-    const size_t tiles = (B + 63) / 64;
-    G1X9 *acc = reinterpret_cast<G1X9 *>(sc.acc.p), *r1 = reinterpret_cast<G1X9 *>(sc.r1.p);
-    if (seg_events) ZK_HIP(hipEventRecord(seg_events[0], s));
-    hipLaunchKernelGGL(k_comb_walk, dim3((unsigned)(tiles * COMB_T * Q)), dim3(64), 0, s, cb.table.p, pat, B, cb.nclumps, cb.E, Q, acc);
-    if (seg_events) ZK_HIP(hipEventRecord(seg_events[1], s));
-    hipLaunchKernelGGL(k_comb_fold1, dim3((unsigned)(tiles * FOLD_GROUPS)), dim3(64), 0, s, acc, B, Q, r1);
-    hipLaunchKernelGGL(k_comb_fold2, dim3((unsigned)tiles), dim3(64), 0, s, r1, B, cb.corr.p, out);
+void comb_patterns_rows(const CombShape &cb, const Fr *scalars, size_t B, uint32_t *pat, uint32_t *gen_count, uint32_t *gen_idx, Fr *gen_val, size_t gen_stride,
+                        hipStream_t s) {
+    static PerDeviceOnce once;
+    once.run([] { ZK_HIP(hipFuncSetAttribute((const void *)k_comb_patterns_rows, hipFuncAttributeMaxDynamicSharedMemorySize, COMB_KMAX * 8 * 64 * 4)); });
+    const int W = (cb.T + 31) >> 5;
+    hipLaunchKernelGGL(k_comb_patterns_rows, dim3(ceil_div(B, 64), (unsigned)cb.nclumps), dim3(64), (size_t)cb.k * W * 64 * 4, s, scalars, B, cb.n, cb.k, cb.T, cb.rows.p,
+                       cb.base_index.p, pat, gen_count, gen_idx, gen_val, gen_stride);
     ZK_HIP(hipGetLastError());
+}
+template <class F>
+static void comb_msm_impl(const CombBasesT<F> &cb, const uint32_t *pat, size_t B, CombScratch &sc, XYZZ<F> *out, size_t out_stride, hipStream_t s, hipEvent_t *seg_events) {
+    using X9 = typename Nine<F>::X9;
+    if (!cb.ok) throw ZkError("comb MSM: table not built");
+    const uint32_t Q = comb_ranges(B, cb.nclumps, cb.T);
+    const int groups = fold_groups(cb.T);
+    if (sc.acc.n < (size_t)Q * cb.T * B * sizeof(X9) || sc.r1.n < (size_t)groups * B * sizeof(X9)) throw ZkError("comb MSM: scratch too small");
+    const size_t tiles = (B + 63) / 64;
+    X9 *acc = reinterpret_cast<X9 *>(sc.acc.p), *r1 = reinterpret_cast<X9 *>(sc.r1.p);
+    if (seg_events) ZK_HIP(hipEventRecord(seg_events[0], s));
+    hipLaunchKernelGGL(k_comb_walk<F>, dim3((unsigned)(tiles * cb.T * Q)), dim3(64), 0, s, cb.table.p, pat, B, cb.nclumps, cb.E, cb.T, Q, acc);
+    if (seg_events) ZK_HIP(hipEventRecord(seg_events[1], s));
+    hipLaunchKernelGGL(k_comb_fold1<F>, dim3((unsigned)(tiles * groups)), dim3(64), 0, s, acc, B, cb.T, Q, r1);
+    hipLaunchKernelGGL(k_comb_fold2<F>, dim3((unsigned)tiles), dim3(64), 0, s, r1, B, groups, cb.corr.p, out, out_stride);
+    ZK_HIP(hipGetLastError());
+}
+void comb_msm(const CombBases &cb, const uint32_t *pat, size_t B, CombScratch &sc, G1XYZZ *out, hipStream_t s, hipEvent_t *seg_events) {
+    comb_msm_impl<Fp>(cb, pat, B, sc, out, 1, s, seg_events);
+}
+void comb_msm_strided(const CombBasesT<Fp> &cb, const uint32_t *pat, size_t B, CombScratch &sc, G1XYZZ *out, size_t out_stride, hipStream_t s) {
+    comb_msm_impl<Fp>(cb, pat, B, sc, out, out_stride, s, nullptr);
+}
+void comb_msm_strided(const CombBasesT<Fp2> &cb, const uint32_t *pat, size_t B, CombScratch &sc, G2XYZZ *out, size_t out_stride, hipStream_t s) {
+    comb_msm_impl<Fp2>(cb, pat, B, sc, out, out_stride, s, nullptr);
 }
 
 }  // namespace zk

@@ -93,6 +93,14 @@ class Algorithm {
     void enqueue_solve(struct SolveSet &S, MsmScratch &commit_scratch, hipStream_t st);
     void enqueue_main(struct SolveSet &S, hipStream_t st, hipEvent_t before_msm, hipStream_t tail);
     bool ahead_eligible() const;
+    // Wire comb of the AES circuits (msm.hip, MsmBases::wcomb): a calibration solve over `calib_inputs` (synthetic consistent witness
+    // assignments supplied by the request layer, cabi.cpp) classifies every wire position by the width of its values; the positions
+    // that are not 0 / +-1 get comb tables per base set.  Done once, with the first batch of at least comb_min_batch() proofs.
+    std::vector<uint32_t> calib_inputs;                     // [n][n_inputs]
+    std::vector<U256> calib_rnd;                            // [n] Randomize hint values
+    bool wire_comb_tried = false, wire_comb_on = false;
+    void wire_comb_prepare(size_t B);
+    void wire_comb_reserve(MsmScratch &sc, bool main_set, size_t B);
     bool comb_active() const;                               // the current resident batch takes the comb path for its quotient MSM
     void comb_prepare(size_t B);                            // lazy table build + scratch (resident_reserve)
     void enqueue_ntt_sort(struct SolveSet &S, hipStream_t sn, int slot, hipEvent_t slot_free = nullptr);

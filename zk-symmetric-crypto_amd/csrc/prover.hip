@@ -519,6 +519,90 @@ void bsb22_challenge_device(const G1Affine *com_canonical, Fr *challenge_mont, s
     hipLaunchKernelGGL(k_bsb22_challenge, dim3(ceil_div(n, 64)), dim3(64), 0, s, com_canonical, challenge_mont, n);
 }
 
+// ---------------------------------------------------------------------------- wire comb (calibration)
+// width class of the values of one wire position over the calibration batch: 0 = 0 / +-1 only, 1 = < 2^8, 2 = < 2^32, 3 = anything
+__global__ __launch_bounds__(256) void k_wire_class(const Fr *__restrict__ wires, size_t nw, size_t B, uint8_t *__restrict__ cls) {
+    const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nw) return;
+    const Fr one = Fr::one(), mone = Fr::one().neg();
+    uint32_t c = 0;
+    for (size_t b = 0; b < B; b++) {
+        const Fr v = wires[w * B + b];
+        if (v.is_zero() || v == one || v == mone) continue;
+        const Fr s = v.from_mont();
+        uint32_t hi = 0;
+        for (int k = 1; k < 8; k++) hi |= s.l[k];
+        const uint32_t k = hi ? 3u : (s.l[0] >> 8 ? 2u : 1u);
+        c = k > c ? k : c;
+    }
+    cls[w] = (uint8_t)c;
+}
+static int wire_comb_k() {
+    static const int v = [] { const char *e = getenv("ZKPROVE_WCOMB_K"); return e ? atoi(e) : 16; }();
+    return v;
+}
+void Algorithm::wire_comb_prepare(size_t B) {
+    if (!comb_enabled() || wire_comb_tried || split_world != 1 || B < comb_min_batch() || calib_inputs.empty() || !pk.A.f9 || !pk.B2.f9) return;
+    wire_comb_tried = true;
+    Resident &R = *res;
+    const size_t ni = prog.n_inputs, Bc = std::min(calib_inputs.size() / ni, R.cap), nw = prog.n_wires;
+    if (!Bc) return;
+    SolveSet &S = R.set[0];
+    const size_t B_saved = R.B;
+    // 1. calibration solve (set 0 is free: nothing has been uploaded for the batch being reserved yet)
+    R.B = Bc; S.sb.B = Bc; R.ms.B = Bc;
+    std::vector<U256> ones(Bc);
+    for (auto &v : ones) { memset(v.l, 0, 32); v.l[0] = 1; }
+    upload_set(S, Bc, calib_inputs.data(), ones.data(), ones.data(), calib_rnd.data(), R.stream);
+    enqueue_solve(S, R.ms, R.stream);
+    std::vector<uint32_t> errs(Bc);
+    ZK_HIP(hipMemcpyAsync(errs.data(), S.sb.err.p, Bc * sizeof(uint32_t), hipMemcpyDeviceToHost, R.stream));
+    DevBuf<uint8_t> dcls(nw);
+    hipLaunchKernelGGL(k_wire_class, dim3(ceil_div(nw, 256)), dim3(256), 0, R.stream, S.sb.wires.p, nw, Bc, dcls.p);
+    std::vector<uint8_t> cls(nw);
+    ZK_HIP(hipMemcpyAsync(cls.data(), dcls.p, nw, hipMemcpyDeviceToHost, R.stream));
+    ZK_HIP(hipStreamSynchronize(R.stream));
+    ZK_HIP(hipStreamSynchronize(R.copy_stream));
+    R.B = B_saved; S.sb.B = B_saved; R.ms.B = B_saved;
+    for (uint32_t e : errs)
+        if (e) { fprintf(stderr, "zkprove: wire-comb calibration: the synthetic witnesses did not solve (error word %u): wire MSMs keep the bucket pipeline\n", e); return; }
+    size_t nwide = 0;
+    for (uint8_t c : cls) nwide += c != 0;
+    if (!nwide) return;                    // every wire is 0 / +-1 (the ChaCha20 circuit): nothing to tabulate
+    // 2. tables per base set
+    auto attach = [&](auto &mb) -> bool {
+        if (!mb.n) return true;
+        std::vector<uint32_t> rows(mb.n);
+        ZK_HIP(hipMemcpy(rows.data(), mb.scalar_row.p, mb.n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        std::vector<uint8_t> c(mb.n);
+        for (size_t j = 0; j < mb.n; j++) c[j] = cls[rows[j]];
+        return msm_attach_wire_comb(mb, c.data(), wire_comb_k(), R.stream);
+    };
+    bool ok = attach(pk.A) && attach(pk.B1) && attach(pk.K) && attach(pk.B2);
+    if (ok && has_commit) ok = attach(pk.ped) && attach(pk.ped_sigma);
+    if (!ok) {
+        for (MsmBasesG1 *mb : {&pk.A, &pk.B1, &pk.K, &pk.ped, &pk.ped_sigma}) { mb->wcomb.clear(); mb->wide_mask.release(); }
+        pk.B2.wcomb.clear(); pk.B2.wide_mask.release();
+        fprintf(stderr, "zkprove: wire-comb tables not built (degenerate bases): wire MSMs keep the bucket pipeline\n");
+        return;
+    }
+    wire_comb_on = true;
+}
+// scratch of the wire combs that run on `sc`: the main-stream MSMs (A, B1, K, B2; and the Pedersen pair when it shares that scratch)
+// or the solve-stream ones (the Pedersen pair of the pipelined entries)
+void Algorithm::wire_comb_reserve(MsmScratch &sc, bool main_set, size_t B) {
+    if (!wire_comb_on) return;
+    size_t pw = 0, ab = 0, rb = 0;
+    auto need = [&](const auto &mb) {
+        size_t p = 0, a = 0, r = 0;
+        msm_wire_comb_needs(mb, B, p, a, r);
+        pw = std::max(pw, p); ab = std::max(ab, a); rb = std::max(rb, r);
+    };
+    if (main_set) { need(pk.A); need(pk.B1); need(pk.K); need(pk.B2); }
+    if (has_commit) { need(pk.ped); need(pk.ped_sigma); }
+    sc.reserve_wire_comb(pw, ab, rb);
+}
+
 // ------------------------------------------------------------------------------- pipeline
 void Algorithm::resident_reserve(size_t B) {
     bind_device(device);
@@ -582,6 +666,9 @@ void Algorithm::resident_reserve(size_t B) {
     }
     // the comb tables of the quotient MSM are decided once the working buffers above exist (the budget looks at what is left)
     comb_prepare(B);
+    wire_comb_prepare(B);
+    wire_comb_reserve(R.ms, true, R.cap);
+    if (R.ms2.entries.n) wire_comb_reserve(R.ms2, false, R.cap);
     // bucket pipeline of the quotient MSM: for every batch when there are no comb tables, else only for the batches too small for the comb
     const size_t nbz = (size_t)1 << (pk.Z.c - 1), ez = pk.Z.n * (size_t)pk.Z.W;
     const size_t Bd = pk.Zcomb.ok ? std::min(B, SIDE_G2_MAX_B) : B;
@@ -877,6 +964,7 @@ void Algorithm::ensure_second_set(int nsets) {
         R.ms2.reserve(R.cap, pk.ped.n * (size_t)pk.ped.W, (size_t)1 << (pk.ped.c - 1), msm_part_stride(pk.ped.n, pk.ped.c));
         R.ms2.reserve_compact(R.cap, pk.ped.n);
         R.ms2.reserve_sums(R.cap, (size_t)1 << (pk.ped.c - 1), 1);
+        wire_comb_reserve(R.ms2, false, R.cap);
     }
 }
 

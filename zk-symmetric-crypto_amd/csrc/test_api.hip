@@ -106,7 +106,8 @@ extern "C" int zkp_compute_h(int logn, long batch, long ncons, const uint8_t *a,
 }
 
 template <class F>
-static int msm_test(long n_, long batch, const uint8_t *points, const uint8_t *scalars, uint8_t *out, int c, bool dense = false) {
+static int msm_test(long n_, long batch, const uint8_t *points, const uint8_t *scalars, uint8_t *out, int c, bool dense = false, const uint8_t *wcomb_cls = nullptr,
+                    int wcomb_k = 0) {
     const size_t n = (size_t)n_, B = (size_t)batch;
     constexpr size_t PB = sizeof(Affine<F>);          // 64 or 128
     // points arrive canonical LE (x|y) resp. (x0|x1|y0|y1): upload and convert to Montgomery on device
@@ -129,6 +130,12 @@ static int msm_test(long n_, long batch, const uint8_t *points, const uint8_t *s
     sc.reserve_compact(B, n);
     if (dense) { sc.reserve_dense(B, n * mb.W); sc.reserve_tree(B, n * mb.W, (size_t)1 << (c - 1)); }
     sc.reserve_sums(B, sizeof(F) == 32 ? (size_t)1 << (c - 1) : 1, sizeof(F) == 32 ? 1 : (size_t)1 << (c - 1));
+    if (wcomb_cls) {           // wire comb over the positions of class 1..3 (msm.hip, msm_attach_wire_comb)
+        if (!msm_attach_wire_comb(mb, wcomb_cls, wcomb_k, 0)) return 1;
+        size_t pw = 0, ab = 0, rb = 0;
+        msm_wire_comb_needs(mb, B, pw, ab, rb);
+        sc.reserve_wire_comb(pw, ab, rb);
+    }
     DevBuf<XYZZ<F>> res(B);
     DevBuf<Affine<F>> aff(B);
     msm_batch(mb, ds.p, B, sc, res.p, 0);
@@ -141,6 +148,14 @@ static int msm_test(long n_, long batch, const uint8_t *points, const uint8_t *s
 extern "C" int zkp_msm_g1(long n, long batch, const uint8_t *points, const uint8_t *scalars, uint8_t *out, int c) {
     ZKP_TRY
     return msm_test<Fp>(n, batch, points, scalars, out, c);
+    ZKP_CATCH(-1)
+}
+// wire MSM with a wire comb attached: cls[n] = width class per base (0: 0 / +-1, 1: < 2^8, 2: < 2^32, 3: any), clumps of k bases.
+// group 1 = G1 (points n*64), 2 = G2 (points n*128).  returns 1 when a table cannot be built (degenerate bases)
+extern "C" int zkp_msm_wire_comb(int group, long n, long batch, const uint8_t *points, const uint8_t *scalars, uint8_t *out, int c, int k, const uint8_t *cls) {
+    ZKP_TRY
+    if (group == 2) return msm_test<Fp2>(n, batch, points, scalars, out, c, false, cls, k);
+    return msm_test<Fp>(n, batch, points, scalars, out, c, false, cls, k);
     ZKP_CATCH(-1)
 }
 // dense (quotient-MSM) path: every scalar goes through the bucket pipeline, scalars read instance-major
