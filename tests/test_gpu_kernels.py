@@ -155,23 +155,28 @@ def test_msm_comb_matches_oracle(zk, oracle, n, batch, k, mode):
         assert not got[1].any()
 
 
-def test_msm_comb_refuses_degenerate_bases(zk, oracle):
-    """a base at infinity, or two equal / opposite bases inside a clump (a subset sum at infinity), cannot be tabulated: the
-    builder reports it and the prover keeps the bucket path for such a key"""
+def test_msm_comb_tabulates_degenerate_bases_by_the_complete_rules(zk, oracle):
+    """a base at infinity, equal bases and opposite bases inside a clump (wires with identical constraint columns have EQUAL key points:
+    subset sums then double or cancel) are tabulated by the complete addition rules; the table then holds entries at infinity and the
+    walk variant that skips them is used -- the sum stays exact"""
     rng = np.random.default_rng(8200)
-    n, batch = 40, 2
+    n, batch = 40, 3
     pts = oracle.g1_fixed_base(_rand_fr(rng, n))
     sc = np.stack([_rand_fr(rng, n) for _ in range(batch)])
+    sc[2, 8:16] = 0
     got = np.zeros((batch, 64), np.uint8)
-    p_inf = pts.copy(); p_inf[7] = 0
-    assert zk.lib.zkp_msm_comb(n, batch, p_inf.ctypes.data, sc.ctypes.data, got.ctypes.data, 8, 0) == 1
-    p_top = pts.copy(); p_top[8] = p_top[15]                # clump 1 = bases 8..15: its first level adds base 8 to the top base 15
-    assert zk.lib.zkp_msm_comb(n, batch, p_top.ctypes.data, sc.ctypes.data, got.ctypes.data, 8, 0) == 1
-    # equal bases elsewhere in a clump are ordinary: no subset sum (they all contain the top base) meets +-P_j
-    p_eq = pts.copy(); p_eq[9] = p_eq[12]
-    for p in (pts, p_eq):
-        assert zk.lib.zkp_msm_comb(n, batch, p.ctypes.data, sc.ctypes.data, got.ctypes.data, 8, 0) == 0
-        assert np.array_equal(got, np.stack([oracle.msm_g1(p, sc[b]) for b in range(batch)]))
+    variants = {"plain": pts.copy()}
+    v = pts.copy(); v[7] = 0; variants["base at infinity"] = v
+    v = pts.copy(); v[8] = v[15]; variants["base equal to the clump's top base"] = v          # clump 1 = bases 8..15
+    v = pts.copy(); v[9] = v[12]; v[10] = v[12]; variants["three equal bases"] = v
+    v = pts.copy(); v[9, 32:] = np.frombuffer(((gf.P - int.from_bytes(bytes(pts[15, 32:]), "little")) % gf.P).to_bytes(32, "little"), np.uint8); v[9, :32] = pts[15, :32]
+    variants["base opposite to the top base"] = v
+    v = pts.copy(); v[8:16] = v[8]; variants["a clump of eight equal bases"] = v
+    for name, p in variants.items():
+        p = np.ascontiguousarray(p)
+        assert zk.lib.zkp_msm_comb(n, batch, p.ctypes.data, sc.ctypes.data, got.ctypes.data, 8, 0) == 0, name
+        assert np.array_equal(got, np.stack([oracle.msm_g1(p, sc[b]) for b in range(batch)])), name
+
 
 @pytest.mark.parametrize("group,n,batch,k", [(1, 900, 70, 8), (2, 400, 66, 6), (1, 61, 65, 16)])
 def test_msm_wire_comb_matches_oracle(zk, oracle, group, n, batch, k):

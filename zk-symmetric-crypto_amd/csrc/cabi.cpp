@@ -941,7 +941,7 @@ int zkp_quotient_msm_info(int id, long *info8) {
         const MsmBasesG1 &z = a->pk.Z;
         info8[0] = 0; info8[1] = z.c; info8[2] = z.W; info8[3] = (long)(z.table.bytes() >> 20); info8[4] = (long)z.n * z.W;
     }
-    info8[5] = a->wire_comb_on && a->res->B > 64 ? 1 : 0;
+    info8[5] = a->wire_comb_on && a->resident_batch() > 64 ? 1 : 0;
     long pos = 0;
     size_t bytes = 0;
     for (auto &cb : a->pk.A.wcomb) pos += (long)cb->n;

@@ -37,6 +37,7 @@ struct CombShape {
     DevBuf<uint32_t> rows;                 // wire comb: row of base j in the [row][B] scalar matrix
     DevBuf<uint32_t> base_index;           // wire comb: index of base j in the owning MsmBases (for the bucket-pipeline hand-over)
     bool ok = false;
+    bool has_inf = false;                  // the table holds entries at infinity (a base at infinity, equal / opposite bases in a clump): the walk skips them
 };
 template <class F>
 struct CombBasesT : CombShape {
@@ -53,7 +54,8 @@ size_t comb_table_bytes(size_t n, int k);
 size_t comb_pattern_words(const CombShape &cb, size_t B);
 size_t comb_acc_bytes(const CombShape &cb, size_t B, size_t x9_bytes);
 size_t comb_r1_bytes(const CombShape &cb, size_t B, size_t x9_bytes);
-// false (table released): a base at infinity or a degenerate subset sum -- the caller keeps the bucket path
+// (bases at infinity and clumps whose subset sums cancel or coincide are tabulated by the complete addition rules; has_inf then makes
+// the walk skip the entries at infinity)
 bool comb_build(CombBases &cb, const G1Affine *d_points, size_t n, int k, hipStream_t s);
 bool comb_build_planes(CombBasesT<Fp> &cb, const G1Affine *d_points, size_t n, int k, int T, hipStream_t s);
 bool comb_build_planes(CombBasesT<Fp2> &cb, const G2Affine *d_points, size_t n, int k, int T, hipStream_t s);

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(64) void k_comb_halve(const Affine<F> *__restrict__
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const Affine<F> p = pts[i];
-    if (p.is_inf()) { atomicAdd(bad, 1u); out[i] = Affine<F>::inf(); return; }      // a base at infinity has no "+-1" form: bucket path
+    if (p.is_inf()) { atomicAdd(bad, 1u); out[i] = Affine<F>::inf(); return; }      // counted: the table then holds entries at infinity (walk variant that skips them)
     uint32_t k[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) k[j] = HALF_SCALAR[j];
@@ -63,11 +63,21 @@ __global__ __launch_bounds__(256) void k_comb_seed(const Affine<F> *__restrict__
 }
 // level j: entries [0, 2^j) of a clump hold the signed sums over its top base and bases 0..j-1; base j is added with both signs:
 // idx -> idx (minus) and idx + 2^j (plus).  Affine additions; the G clumps of a thread share one inversion (Montgomery's trick).
-// A coincidence x_S == x_P (a subset sum equal to +-P_j: impossible for an honest key, possible for crafted points) is counted in
-// *bad: the caller then keeps the bucket path for this key.
+// The special cases -- a subset sum equal to +-P_j (doubling / cancellation: wires with identical constraint columns have EQUAL base
+// points), a subset sum or a base at infinity -- take the complete formulas with an inversion of their own and are counted in
+// *special: a table that holds an entry at infinity is walked by the kernel variant that skips such entries.
+template <class F>
+__device__ __noinline__ Affine<F> comb_affine_double(Affine<F> p) {
+    const F x2 = p.x.sqr();
+    const F lam = (x2.dbl() + x2) * p.y.dbl().inv();
+    Affine<F> r;
+    r.x = lam.sqr() - p.x.dbl();
+    r.y = lam * (p.x - r.x) - p.y;
+    return r;
+}
 template <class F, int G>
 __global__ __launch_bounds__(64) void k_comb_level(Affine<F> *__restrict__ table, const Affine<F> *__restrict__ half, size_t n, int k, size_t nclumps, size_t E, int j,
-                                                   uint32_t *__restrict__ bad) {
+                                                   uint32_t *__restrict__ special) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t per = (size_t)1 << j;
     const size_t ngroups = (nclumps + G - 1) / G;
@@ -87,8 +97,17 @@ __global__ __launch_bounds__(64) void k_comb_level(Affine<F> *__restrict__ table
                 S[g] = table[c * E + idx];
                 P[g] = half[c * k + j];
                 d[g] = P[g].x - S[g].x;
-                if (d[g].is_zero() || S[g].is_inf()) atomicAdd(bad, 1u);
-                else on[g] = true;
+                if (S[g].is_inf() || P[g].is_inf() || d[g].is_zero()) {
+                    // rare: S + P and S - P by the complete rules
+                    Affine<F> rp, rm;
+                    if (P[g].is_inf()) { rp = S[g]; rm = S[g]; }
+                    else if (S[g].is_inf()) { rp = P[g]; rm = P[g].neg(); }
+                    else if (P[g].y == S[g].y) { rp = comb_affine_double<F>(S[g]); rm = Affine<F>::inf(); }
+                    else { rp = Affine<F>::inf(); rm = comb_affine_double<F>(S[g]); }
+                    if (rp.is_inf() || rm.is_inf()) atomicAdd(special, 1u);
+                    table[c * E + idx] = rm;
+                    table[c * E + idx + per] = rp;
+                } else on[g] = true;
             }
         }
         pre[g] = run;
@@ -162,10 +181,6 @@ static bool comb_build_impl(CombBasesT<F> &cb, const Affine<F> *d_points, size_t
     DevBuf<uint32_t> bad(1);
     bad.zero(s);
     hipLaunchKernelGGL(k_comb_halve<F>, dim3(ceil_div(n, 64)), dim3(64), 0, s, d_points, n, half.p, bad.p);
-    uint32_t nbad = 0;
-    bad.download(&nbad, 1, s);
-    ZK_HIP(hipStreamSynchronize(s));
-    if (nbad) return false;
     cb.table.alloc(cb.nclumps * cb.E);
     cb.corr.alloc(1);
     hipLaunchKernelGGL(k_comb_seed<F>, dim3(ceil_div(cb.nclumps, 256)), dim3(256), 0, s, half.p, n, k, cb.nclumps, cb.E, cb.table.p);
@@ -182,9 +197,10 @@ static bool comb_build_impl(CombBasesT<F> &cb, const Affine<F> *d_points, size_t
         ZK_HIP(hipMemsetAsync(cb.table.p + (cb.nclumps - 1) * cb.E + ((size_t)1 << (last_kc - 1)), 0, (cb.E - ((size_t)1 << (last_kc - 1))) * sizeof(Affine<F>), s));
     hipLaunchKernelGGL(k_comb_to_f9, dim3(ceil_div(coords, 256)), dim3(256), 0, s, (Fp *)cb.table.p, coords);
     ZK_HIP(hipGetLastError());
+    uint32_t nbad = 0;
     bad.download(&nbad, 1, s);
     ZK_HIP(hipStreamSynchronize(s));
-    if (nbad) { cb.table.release(); return false; }
+    cb.has_inf = nbad != 0;           // bases at infinity / cancelling subset sums: entries at infinity exist, the walk must skip them
     cb.ok = true;
     return true;
 }
@@ -279,7 +295,7 @@ __global__ __launch_bounds__(64) void k_comb_patterns_rows(const Fr *__restrict_
 #define ZK_COMB_WAVES 4
 #endif
 #define ZK_COMB_BOUNDS(F) (sizeof(F) == 64 ? 2 : ZK_COMB_WAVES)
-template <class F>
+template <class F, bool MAY_INF>
 __global__ __launch_bounds__(64, ZK_COMB_BOUNDS(F)) void k_comb_walk(const Affine<F> *__restrict__ table, const uint32_t *__restrict__ pat, size_t B, size_t nclumps, size_t E,
                                                                     int T, uint32_t Q, typename Nine<F>::X9 *__restrict__ acc_out) {
     using F9 = typename Nine<F>::F9;
@@ -301,7 +317,7 @@ __global__ __launch_bounds__(64, ZK_COMB_BOUNDS(F)) void k_comb_walk(const Affin
             // costs 16 live registers = a wavefront per SIMD, msm.hip accumulate_body)
             uint32_t e_next = 0;
             if (c + 1 < c1) e_next = pp[pstride];
-            acc.madd(F9::from_words(p.x), F9::cneg(F9::from_words(p.y), (e >> 31) ? -1 : 0));
+            if (!MAY_INF || !p.is_inf()) acc.madd(F9::from_words(p.x), F9::cneg(F9::from_words(p.y), (e >> 31) ? -1 : 0));
             if (++c >= c1) break;
             pp += pstride;
             e = e_next;
@@ -348,12 +364,15 @@ __global__ __launch_bounds__(64, ZK_COMB_BOUNDS(F)) void k_comb_fold2(const type
     out[b * out_stride] = r.to_xyzz();
 }
 
+// clump ranges per (proof, plane): 8 at a full batch; more when the batch or the plane count is small (so that the walk still has
+// ~1 M threads), but never so many that a thread walks fewer than ~24 clumps -- the fold adds the Q range accumulators of a plane
+// one after the other, and with few clumps (the wire combs: 50 .. 400) a large Q turns the fold into the longer kernel
 static uint32_t comb_ranges(size_t B, size_t nclumps, int T) {
     static const uint32_t forced = [] { const char *e = getenv("ZKPROVE_COMB_Q"); return e ? (uint32_t)atoi(e) : 0u; }();
     uint32_t Q = forced ? forced : 8;
-    // small batches / few planes: more ranges so that the launch still has ~1 M threads
     while (!forced && (size_t)Q * T * B < (1u << 20) && Q < 256) Q *= 2;
-    if (Q > nclumps) Q = (uint32_t)nclumps;
+    const uint32_t cap = (uint32_t)(nclumps / 24);
+    if (Q > cap) Q = cap;
     return Q < 1 ? 1 : Q;
 }
 size_t comb_pattern_words(const CombShape &cb, size_t B) { return cb.nclumps * (size_t)cb.T * B; }
@@ -389,7 +408,8 @@ static void comb_msm_impl(const CombBasesT<F> &cb, const uint32_t *pat, size_t B
     const size_t tiles = (B + 63) / 64;
     X9 *acc = reinterpret_cast<X9 *>(sc.acc.p), *r1 = reinterpret_cast<X9 *>(sc.r1.p);
     if (seg_events) ZK_HIP(hipEventRecord(seg_events[0], s));
-    hipLaunchKernelGGL(k_comb_walk<F>, dim3((unsigned)(tiles * cb.T * Q)), dim3(64), 0, s, cb.table.p, pat, B, cb.nclumps, cb.E, cb.T, Q, acc);
+    if (cb.has_inf) hipLaunchKernelGGL((k_comb_walk<F, true>), dim3((unsigned)(tiles * cb.T * Q)), dim3(64), 0, s, cb.table.p, pat, B, cb.nclumps, cb.E, cb.T, Q, acc);
+    else hipLaunchKernelGGL((k_comb_walk<F, false>), dim3((unsigned)(tiles * cb.T * Q)), dim3(64), 0, s, cb.table.p, pat, B, cb.nclumps, cb.E, cb.T, Q, acc);
     if (seg_events) ZK_HIP(hipEventRecord(seg_events[1], s));
     hipLaunchKernelGGL(k_comb_fold1<F>, dim3((unsigned)(tiles * groups)), dim3(64), 0, s, acc, B, cb.T, Q, r1);
     hipLaunchKernelGGL(k_comb_fold2<F>, dim3((unsigned)tiles), dim3(64), 0, s, r1, B, groups, cb.corr.p, out, out_stride);

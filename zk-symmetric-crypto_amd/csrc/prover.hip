@@ -480,6 +480,7 @@ static int comb_pick_k(size_t n, size_t still_needed, int share) {
         if ((double)comb_table_bytes(n, k) <= budget) return k;
     return 0;
 }
+size_t Algorithm::resident_batch() const { return res ? res->B : 0; }
 bool Algorithm::comb_active() const {
     return pk.Zcomb.ok && res && split_world == 1 && res->B > SIDE_G2_MAX_B && res->comb_cap >= res->B;
 }
