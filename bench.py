@@ -303,7 +303,7 @@ def run_rank(args):
                 good += gold[str(r)] == hsh
         return {"match": (good == compared) if compared else None, "ranks_compared": compared, "of_ranks": world, "sha256_rank0": digests[0]}
 
-    def abi_leg(alg, nreq):
+    def abi_leg(alg, nreq, vk):
         """what the reference's own harness times (gnark/libraries/core_test.go:121-150: prover.Prove(json) in a loop): JSON requests in,
         JSON responses out, through the exported C ABI -- request decoding, ciphers, witness packing, PCIe and proof serialisation inside
         the timed region.  One ProveBatch call of nreq requests (best of 2) and the median of 15 synchronous single Prove() calls."""
@@ -327,8 +327,24 @@ def run_rank(args):
             zk.prove_raw(one)
             lat.append(time.perf_counter() - t0)
         lat.sort()
+        # the verifier side of the same ABI: VerifyBatch over the first 1024 responses (one pairing-product check on the GPU)
+        ver = None
+        try:
+            if zk.init_verifier(alg, vk):
+                nv = min(1024, nreq)
+                vreqs = [{"cipher": reqs[i]["cipher"], "proof": resl[i]["proof"],
+                          "publicSignals": {"ciphertext": resl[i]["ciphertext"], "blocks": [{"nonce": b["nonce"], "counter": b["counter"]} for b in reqs[i]["blocks"]],
+                                            "input": reqs[i]["input"]}} for i in range(nv)]
+                vbody = json.dumps(vreqs).encode()
+                zk.verify_batch_raw(vbody)                                    # warm-up: device image of vk.K
+                t0 = time.perf_counter()
+                vres, vms = zk.verify_batch_raw(vbody, timed=True)
+                vdt = time.perf_counter() - t0
+                ver = {"proofs": nv, "all_true": all(vres) and len(vres) == nv, "wall_ms": vdt * 1e3, "device_ms": vms, "proofs_per_s": nv / vdt}
+        except Exception as e:
+            ver = {"error": repr(e)}
         return {"proofs_per_s": nreq / best, "requests_per_call": nreq, "ok": ok, "seconds_per_call": best,
-                "single_prove_ms": lat[len(lat) // 2] * 1e3, "single_prove_ms_min": lat[0] * 1e3,
+                "single_prove_ms": lat[len(lat) // 2] * 1e3, "single_prove_ms_min": lat[0] * 1e3, "verify_batch": ver,
                 "what": "ProveBatch(JSON array) -> JSON array and Prove(JSON) -> JSON through the C ABI; host decoding, ciphers, witness packing, PCIe, serialisation included"}
 
     manifest = profile_manifest()
@@ -385,9 +401,9 @@ def run_rank(args):
         if args.abi_requests != 0 and world == 1:
             # after every timed region: the ABI-inclusive rates (not `value`: the contract times resident inputs)
             try:
-                out["abi"] = abi_leg(args.alg, args.abi_requests if args.abi_requests > 0 else (8192 if args.alg == 0 else 4096))
+                out["abi"] = abi_leg(args.alg, args.abi_requests if args.abi_requests > 0 else (8192 if args.alg == 0 else 4096), head.vk)
                 if 2 in lines and args.alg != 2:
-                    out["aes256_ctr"]["abi"] = abi_leg(2, args.abi_requests if args.abi_requests > 0 else 4096)
+                    out["aes256_ctr"]["abi"] = abi_leg(2, args.abi_requests if args.abi_requests > 0 else 4096, algs[1][1].vk)
             except Exception as e:
                 out["abi"] = {"error": repr(e)}
         if args.cpu_proofs != 0 and world == 1:

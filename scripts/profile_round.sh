@@ -1,15 +1,16 @@
 # usage (on the GPU box): bash scripts/profile_round.sh <tag>      -> raw rocprofv3 output + bench lines under gpurun_out/<tag>/
 set -x
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG; rm -rf $O; mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err
-python bench.py --alg 1 --cpu-proofs 0 --steps 5 > $O/bench_aes128.json 2> /dev/null
-python bench.py --no-pipeline --cpu-proofs 0 --steps 5 > $O/bench_single_stream.json 2> /dev/null
+python bench.py --alg 1 --cpu-proofs 0 --steps 5 --abi-requests 0 > $O/bench_aes128.json 2> /dev/null
+python bench.py --no-pipeline --cpu-proofs 0 --steps 5 --abi-requests 0 > $O/bench_single_stream.json 2> /dev/null
+ZKPROVE_COMB=0 python bench.py --cpu-proofs 0 --steps 5 --abi-requests 0 > $O/bench_bucket_pipeline.json 2> /dev/null
 python scripts/gpu_microbench.py $O/microbench.json > $O/microbench.txt 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cc -o cc -- python3 bench.py --cpu-proofs 0 --no-aes256 > $O/bench_chacha_under_rocprof.json 2> $O/stats_cc.log
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_aes -o aes -- python3 bench.py --cpu-proofs 0 --alg 2 > $O/bench_aes_under_rocprof.json 2> $O/stats_aes.log
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python3 bench.py --steps 1 --warmup 1 --cpu-proofs 0 --no-pipeline --no-aes256 > /dev/null 2> $O/pmc_fetch.log
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- python3 bench.py --steps 1 --warmup 1 --cpu-proofs 0 --no-pipeline --no-aes256 > /dev/null 2> $O/pmc_write.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cc -o cc -- python3 bench.py --cpu-proofs 0 --no-aes256 --abi-requests 0 > $O/bench_chacha_under_rocprof.json 2> $O/stats_cc.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_aes -o aes -- python3 bench.py --cpu-proofs 0 --alg 2 --abi-requests 0 > $O/bench_aes_under_rocprof.json 2> $O/stats_aes.log
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python3 bench.py --steps 1 --warmup 1 --cpu-proofs 0 --no-pipeline --no-aes256 --abi-requests 0 > /dev/null 2> $O/pmc_fetch.log
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- python3 bench.py --steps 1 --warmup 1 --cpu-proofs 0 --no-pipeline --no-aes256 --abi-requests 0 > /dev/null 2> $O/pmc_write.log
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*.db" -delete
 ls -R $O | head -40

@@ -44,6 +44,35 @@ int main() {
         ok &= Fp9::mul(u, Fp9::zero()).is_zero_mod() && (a == c) == Fp9::sqr(u).is_zero_mod();
         if (!ok && bad++ < 5) printf("field mismatch at iteration %d\n", it);
     }
+    // the extremes of the value model (field9.cuh header): the state X of an accumulator at its lower edge (-3.5 M), U2 at its
+    // upper edge (9M/8): P = U2 - X = 4.625 M, P^2 = 21.4 M^2 -- the largest sum of products any call site forms -- must still reduce
+    // exactly, and to_words must take X itself (its input range is (-4M, 4M))
+    for (int it = 0; it < 2000; it++) {
+        Fp small = rnd(rng, 0), small2 = rnd(rng, 0);
+        small.l[7] = 0; small2.l[7] = 0;                                                  // < 2^224: "a little above the edge"
+        Fp half, eighth;
+        for (int i = 0; i < 8; i++) {
+            half.l[i] = (FpParams::M[i] >> 1) | (i < 7 ? FpParams::M[i + 1] << 31 : 0);       // (M - 1) / 2
+            eighth.l[i] = (FpParams::M[i] >> 3) | (i < 7 ? FpParams::M[i + 1] << 29 : 0);     // floor(M / 8)
+        }
+        const Fp9 S9 = Fp9::from_words(small), T9 = Fp9::from_words(small2);
+        const Fp9 Xe = Fp9::norm(Fp9::add(Fp9::sub(S9, Fp9::constant(Fp9Params::M4)), Fp9::from_words(half)));            // small - 4M + (M-1)/2  ~ -3.5 M
+        const Fp9 Ue = Fp9::norm(Fp9::sub(Fp9::add(Fp9::constant(Fp9Params::M), Fp9::from_words(eighth)), T9));            // M + M/8 - small2  ~ 9M/8
+        // the same residues on the 8 x 32 field (values in the 2^261 form on both sides: compare through to_words)
+        const Fp xw = small + half, uw = eighth - small2;
+        bool ok = Fp9::to_words(Xe) == xw && Fp9::to_words(Ue) == uw;
+        const Fp9 Pv = Fp9::sub(Ue, Xe);                                                                                    // 1-lazy, ~ 4.625 M
+        // products of the 2^261 form: compare with the 2^256 form through the conversions (x9 = X * 2^5 as integers mod M)
+        const Fp xf = Fp9::to_field(Xe), uf = Fp9::to_field(Ue);
+        ok &= Fp9::to_field(Fp9::sqr(Pv)) == (uf - xf) * (uf - xf);
+        ok &= Fp9::to_field(Fp9::mul(Pv, Xe)) == (uf - xf) * xf;
+        ok &= Fp9::to_field(Fp9::mulsub(Pv, Pv, Xe, Ue)) == (uf - xf) * (uf - xf) - xf * uf;
+        Fp9 r0, r1, r2;
+        Fp9::mul3(r0, Pv, Pv, r1, Xe, Pv, r2, Ue, Pv);
+        ok &= Fp9::to_field(r0) == (uf - xf) * (uf - xf) && Fp9::to_field(r1) == xf * (uf - xf) && Fp9::to_field(r2) == uf * (uf - xf);
+        ok &= Fp9::to_field(Fp9::x3(r0, r1, r2)) == (uf - xf) * (uf - xf) - xf * (uf - xf) - (uf * (uf - xf)).dbl();
+        if (!ok && bad++ < 5) printf("extreme-value mismatch at iteration %d\n", it);
+    }
     // curve: chains of mixed additions with negated points, repeated points (doubling), cancellations, then general additions
     G1Affine g{Fp::one(), Fp::one() + Fp::one()};
     std::vector<G1Affine> pts;

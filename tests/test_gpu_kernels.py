@@ -130,7 +130,8 @@ def test_msm_g1_dense_path_matches_oracle(zk, oracle, n, batch, c):
     assert np.array_equal(got, exp)
 
 
-@pytest.mark.parametrize("n,batch,k,mode", [(1, 1, 4, 0), (5, 3, 2, 0), (37, 3, 5, 0), (300, 65, 8, 1), (1000, 2, 16, 0), (2500, 130, 11, 1), (4099, 1, 13, 0)])
+@pytest.mark.parametrize("n,batch,k,mode", [(1, 1, 4, 0), (5, 3, 2, 0), (37, 3, 5, 0), (300, 65, 8, 1), (1000, 2, 16, 0), (2500, 130, 11, 1), (4099, 1, 13, 0),
+                                             (1000, 3, 16, 1), (900, 66, 19, 1), (530, 2, 18, 1)])
 def test_msm_comb_matches_oracle(zk, oracle, n, batch, k, mode):
     """quotient MSM of large batches: fixed-base bit-plane comb (csrc/msm_comb.hip) -- clumps of k bases incl. a short last clump,
     signed subset-sum tables of the halved bases, one accumulator per (proof, bit plane, clump range), Horner fold"""
@@ -365,7 +366,9 @@ def test_msm_affine_tree_production_cut_matches_oracle(piece, cases):
     production cut; bases at infinity, P + P and P - P pairs included.  Bit-exact against the oracle."""
     import json, os, subprocess, sys
     import helpers as H
-    env = dict(os.environ, ZKPROVE_MSM_TREE="1")
+    exp = os.path.join(H.ROOT, "zk-symmetric-crypto_amd", "libzkprove_exp.so")          # the tree is built with -DZK_EXPERIMENTS only
+    assert os.path.exists(exp), "libzkprove_exp.so missing: run `make -C zk-symmetric-crypto_amd experiments`"
+    env = dict(os.environ, ZKPROVE_MSM_TREE="1", ZKPROVE_LIB=exp)
     if piece:
         env["ZKPROVE_MSM_PIECE"] = piece
     res = subprocess.run([sys.executable, "-c", _TREE_SCRIPT.format(root=H.ROOT, R=R, cases=cases)], env=env, capture_output=True, text=True, timeout=900)
@@ -414,11 +417,15 @@ def test_msm_doubling_and_cancellation_inside_a_bucket(zk, oracle, group):
     ({"ZKPROVE_MSM_F9": "0"}, "test_msm_g1_matches_oracle or test_msm_g2_matches_oracle or doubling"),
 ], ids=["transforms_9limb", "buckets_8x32"])
 def test_alternative_field_paths_stay_bit_exact(env, select):
-    """The paths an environment switch selects at library load are parity-tested too: the opt-in 9-limb butterflies of the transforms
-    (ZKPROVE_NTT_F9=1, slower, see csrc/ntt.hip) and the 8 x 32 bucket walk kept for A/B runs (ZKPROVE_MSM_F9=0).  Same tests,
-    own process (the switches are read once)."""
+    """The alternatives that were measured and lost -- the 9-limb butterflies of the transforms (ZKPROVE_NTT_F9=1, csrc/ntt.hip), the
+    bucket kernels on the 8 x 32 field (ZKPROVE_MSM_F9=0) and the batch-affine tree (ZKPROVE_MSM_TREE=1) -- are not in the product
+    library: they are compiled with -DZK_EXPERIMENTS into libzkprove_exp.so (make experiments), which this test loads through
+    ZKPROVE_LIB and keeps bit-exact.  Same tests, own process (the switches are read once)."""
     import os, subprocess, sys
     import helpers as H
+    exp = os.path.join(H.ROOT, "zk-symmetric-crypto_amd", "libzkprove_exp.so")
+    assert os.path.exists(exp), "libzkprove_exp.so missing: run `make -C zk-symmetric-crypto_amd experiments` (__graft_entry__.build() does)"
+    env = dict(env, ZKPROVE_LIB=exp)
     res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(H.ROOT, "tests", "test_gpu_kernels.py"), "-x", "-q", "-m", "gpu", "-k", "(%s) and not alternative_field_paths" % select,      # never itself: the child would spawn a child
                           "-p", "no:cacheprovider"], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600, cwd=H.ROOT)
     assert res.returncode == 0 and " passed" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]

@@ -12,7 +12,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzkprove.so")
+# ZKPROVE_LIB: another build of the same library (tests load libzkprove_exp.so, the -DZK_EXPERIMENTS build, through it)
+LIB_PATH = os.environ.get("ZKPROVE_LIB") or os.path.join(_HERE, "libzkprove.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

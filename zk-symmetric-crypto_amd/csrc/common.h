@@ -69,6 +69,18 @@ int default_device();
 void set_default_device(int dev);
 void bind_device(int dev);                       // throws ZkError
 inline void bind_default_device() { bind_device(default_device()); }
+// Scope guard of the prover's entry points: binds the replica's device on the calling thread and puts the thread's previous device
+// back on exit -- the current device is state of the HOST application's thread (torch, another HIP user), not of this library.
+struct DeviceScope {
+    int prev = -1;
+    explicit DeviceScope(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        bind_device(dev);
+    }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceScope(const DeviceScope &) = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
+};
 
 // hipFuncSetAttribute is per device: run fn the first time each device passes through
 struct PerDeviceOnce {

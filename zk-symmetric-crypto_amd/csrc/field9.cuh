@@ -16,8 +16,10 @@
 // A reduction (mont_lockstep) needs, per column, 9 * sum_t A_t * B_t + 9 * 2^58 < 2^63 where A_t, B_t bound the limb magnitudes of
 // the t-th product's operands: one product may take (strict or 1-lazy) x (2-lazy), two fused products (1-lazy x 1-lazy) each.  Callers
 // state their bounds where they use lazy operands.  Values: the result of a reduction lies in (S / 2^261, S / 2^261 + M) for the
-// integer S = sum of products; all call sites keep |S| < 20 M^2, so results stay within (-M/8, M + M/8) (M / 2^261 < 2^-7.4),
-// sums of a few of them within (-4M, 4M), and |v| < 2^258 everywhere (the top limb never leaves 32 bits).
+// integer S = sum of products; all call sites keep |S| < 22 M^2 (the largest: P^2 in XYZZ9::madd / add, P = U2 - X with the state X in
+// (-3.52 M, 1.5 M) and U2 in (-M/8, 9M/8), |P| < 4.65 M), so results stay within (-0.14 M, M + 0.14 M) (M / 2^261 < 2^-7.4), sums of
+// a few of them within (-4M, 4M) -- the input range of to_words; X, the widest state, stays within (-3.52 M, 1.5 M) -- and
+// |v| < 2^258 everywhere (the top limb never leaves 32 bits).  tests/host/field9_check.cpp drives these extremes on the host build.
 //
 // Replaces the same gnark-crypto v0.19.2 fp / fr element arithmetic as field.cuh (ecc/bn254/fp/element.go Mul / Add / Sub reached
 // from MultiExp's bucket additions, provers.go:179,269).

@@ -23,8 +23,13 @@
 // parity tests compare bit-for-bit with the oracle.
 #include <algorithm>
 #include "kernels.h"
-#include "msm_tree.cuh"
 #include "curve9.cuh"
+// Build flag ZK_EXPERIMENTS (make experiments -> libzkprove_exp.so): the measured-and-lost alternatives stay buildable and parity-tested
+// without being part of the product library -- the batch-affine reduction tree (msm_tree.cuh, ZKPROVE_MSM_TREE=1) and the bucket / conditional
+// -sum kernels on the 8 x 32 field (ZKPROVE_MSM_F9=0, ZKPROVE_MSM_F9_G2=0).  The product walks the 9 x 29-bit field only.
+#ifdef ZK_EXPERIMENTS
+#include "msm_tree.cuh"
+#endif
 
 namespace zk {
 
@@ -54,6 +59,7 @@ static constexpr int ONES_CHUNK = TERN_G * ONES_GROUPS;    // base points per co
 static constexpr int SORT_THREADS = 1024;
 static constexpr int WCOMB_CLASSES = 3;                     // wire-comb width classes: 8, 32, 254 bit planes
 
+#ifdef ZK_EXPERIMENTS
 static bool tree_enabled();
 // G1 bucket accumulation on the 9 x 29-bit field (field9.cuh): on unless ZKPROVE_MSM_F9=0 (A/B runs) or the affine-tree experiment,
 // which reads the table in the 2^256 form, is selected
@@ -67,6 +73,11 @@ static bool f9_g2_enabled() {
     static const bool all = [] { const char *e = getenv("ZKPROVE_MSM_F9"); return !(e && e[0] == '0'); }();
     return on && all;
 }
+#else
+static constexpr bool tree_enabled() { return false; }
+static constexpr bool f9_enabled() { return true; }
+static constexpr bool f9_g2_enabled() { return true; }
+#endif
 
 // ------------------------------------------------------------------------------ table precompute
 template <class F>
@@ -181,8 +192,8 @@ static uint32_t accumulate_lanes(size_t max_entries, size_t B) {
     const uint32_t nlanes = (uint32_t)((max_entries + piece - 1) / piece);
     return nlanes < 1 ? 1 : nlanes;
 }
-static bool tree_enabled();
 void MsmScratch::reserve_tree(size_t B_, size_t max_entries, size_t nb) {
+#ifdef ZK_EXPERIMENTS
     if (!tree_enabled()) return;                 // tens of GB at batch 1024: only for the experiment
     const size_t Bm = B_ > VIRT_MIN ? B_ : VIRT_MIN;
     // the finest cut any batch size uses decides the wavefront count and the per-piece slack of the buffers
@@ -199,6 +210,9 @@ void MsmScratch::reserve_tree(size_t B_, size_t max_entries, size_t nb) {
     treeB1.ensure(needB);
     fin1.ensure(Bm * nb);
     tree_scratch.ensure((waves + 1) * TREE_CH * 64 * tree_slot_bytes<Fp>());
+#else
+    (void)B_; (void)max_entries; (void)nb;
+#endif
 }
 void MsmScratch::reserve_compact(size_t B_, size_t max_sparse_n) {
     gen_count.ensure(B_ + 1);
@@ -504,6 +518,7 @@ __global__ __launch_bounds__(256) void k_msm_binsort(const uint32_t *__restrict_
 // form (bases_build), the bucket sums are XYZZ9 records read by k_msm_bucket_reduce9, which hands the canonical 2^256 form on.
 // 9-limb counterparts of the coordinate fields
 
+#ifdef ZK_EXPERIMENTS
 template <class F>
 struct AccWords {
     using Out = XYZZ<F>;
@@ -516,6 +531,7 @@ struct AccWords {
     }
     __device__ __forceinline__ XYZZ<F> result() const { return a.canon(); }
 };
+#endif  // ZK_EXPERIMENTS
 template <class F>
 struct Acc9 {
     using F9 = typename Nine<F>::F9;
@@ -587,6 +603,7 @@ __device__ __forceinline__ void accumulate_body(const Affine<F> *__restrict__ ta
 // Fp2 kernels: 2 wavefronts per SIMD (the unconstrained allocation takes 256 VGPRs plus a few AGPRs = 1 wavefront per SIMD, with
 // nothing to hide a 128-byte gather behind)
 #define ZK_FP2_WAVES(F) (sizeof(F) == 64 ? 2 : 1)
+#ifdef ZK_EXPERIMENTS
 template <class F, bool DENSE>
 __global__ __launch_bounds__(64, ZK_FP2_WAVES(F)) void k_msm_accumulate(const Affine<F> *__restrict__ table, const uint32_t *__restrict__ bucket_start,
                                                        const uint32_t *__restrict__ entries, size_t max_entries, int c, size_t B,
@@ -608,6 +625,7 @@ __global__ __launch_bounds__(64, ZK_FP2_WAVES(F)) void k_msm_accumulate(const Af
 ZK_ACC_G1(true)
 ZK_ACC_G1(false)
 #undef ZK_ACC_G1
+#endif  // ZK_EXPERIMENTS
 // the 9-limb walks (the default; ZKPROVE_MSM_F9=0 keeps the 8 x 32 ones above for comparison)
 #ifndef ZK_ACC9_WAVES
 #define ZK_ACC9_WAVES 4
@@ -620,6 +638,7 @@ __global__ __launch_bounds__(64, ZK_ACC9_BOUNDS(F)) void k_msm_accumulate9(const
     accumulate_body<F, DENSE, Acc9<F>>(table, bucket_start, entries, max_entries, c, B, nlanes, sums);
 }
 
+#ifdef ZK_EXPERIMENTS
 // thread (b, seg): running-sum reduction of buckets [seg*L, seg*L + L) of instance b
 template <class F>
 __global__ __launch_bounds__(64) void k_msm_bucket_reduce(const XYZZ<F> *__restrict__ sums, const uint32_t *__restrict__ bucket_start, int c, size_t B,
@@ -654,6 +673,7 @@ __global__ __launch_bounds__(64) void k_msm_bucket_reduce(const XYZZ<F> *__restr
     part[b * part_stride + part_off + seg] = tot;
 }
 
+#endif  // ZK_EXPERIMENTS
 // the same running-sum reduction over the G1X9 bucket records of k_msm_accumulate9; the segment total leaves in the canonical
 // 2^256 form, the rare s0 * run correction is done there as above
 template <class F>
@@ -697,6 +717,7 @@ __global__ __launch_bounds__(64, ZK_FP2_WAVES(F)) void k_msm_bucket_reduce9(cons
 // group's pattern index, (2) one mixed addition per non-empty group with the group's precomputed signed subset sum --
 // 20 additions per wavefront and chunk where adding the +-1 bases one by one took ~77 (49 % of the ChaCha wire scalars
 // are +-1, and a wavefront runs the maximum over its lanes).
+#ifdef ZK_EXPERIMENTS
 template <class F>
 __global__ __launch_bounds__(256, ZK_FP2_WAVES(F)) void k_msm_ones(const Affine<F> *__restrict__ tern, const Fr *__restrict__ scalars, size_t B,
                                                   const uint32_t *__restrict__ rows, size_t n, XYZZ<F> *__restrict__ part,
@@ -773,6 +794,7 @@ __global__ __launch_bounds__(256, ZK_FP2_WAVES(F)) void k_msm_ones(const Affine<
     part[b * part_stride + part_off + chunk] = acc;
 }
 
+#endif  // ZK_EXPERIMENTS
 // k_msm_ones on the 9-limb field (field9.cuh): same classification, the group patterns are parked in LDS so that the
 // additions are ONE rolled loop around one expanded mixed addition (twenty unrolled copies would be 300 KB of code); tern holds the
 // 2^261-Montgomery form (bases_build), the chunk total leaves in the canonical 2^256 form
@@ -888,6 +910,7 @@ __global__ __launch_bounds__(64, ZK_FP2_WAVES(F)) void k_sum_groups(const XYZZ<F
     out[b * out_stride + g] = acc;
 }
 
+#ifdef ZK_EXPERIMENTS
 // Dense (quotient) MSM: ZKPROVE_MSM_TREE=1 selects the affine reduction tree (msm_tree.cuh, gnark's batch-affine idea) instead of the
 // extended-Jacobian walk.  It is bit-exact (tests) but measured SLOWER on MI355X (126 vs 110 ms per 1024-batch, profiles/r02_tree_*):
 // Montgomery's trick needs two passes over every pair, which triples the random 64-byte traffic (4.4 G gathers + 100 GB of
@@ -917,6 +940,7 @@ static void launch_tree_g1(const MsmBasesG1 &mb, MsmScratch &sc, const uint32_t 
                        bs_p, c, Bv, part, stride, part_off, L);
 }
 
+#endif  // ZK_EXPERIMENTS
 // accumulation + bucket reduction of one sorted MSM: buckets -> nseg segment totals in part[part_off ..]
 template <class F, bool DENSE>
 static void launch_accumulate_reduce(const MsmBases<F> &mb, const uint32_t *bs_p, const uint32_t *ent_p, size_t max_entries, int c, size_t B, uint32_t nlanes,
@@ -935,11 +959,15 @@ static void launch_accumulate_reduce(const MsmBases<F> &mb, const uint32_t *bs_p
         hipLaunchKernelGGL(k_msm_bucket_reduce9<F>, rgrid, dim3(64), 0, s, sums9, bs_p, c, B, part, stride, part_off, L);
         return;
     }
+#ifdef ZK_EXPERIMENTS
     if (sums_cap < B * (size_t)nb) throw ZkError("msm bucket-sum scratch too small");
     if (seg_events) ZK_HIP(hipEventRecord(seg_events[0], s));
     hipLaunchKernelGGL((k_msm_accumulate<F, DENSE>), grid, dim3(64), 0, s, mb.table.p, bs_p, ent_p, max_entries, c, B, nlanes, sums);
     if (seg_events) ZK_HIP(hipEventRecord(seg_events[1], s));
     hipLaunchKernelGGL(k_msm_bucket_reduce<F>, rgrid, dim3(64), 0, s, sums, bs_p, c, B, part, stride, part_off, L);
+#else
+    throw ZkError("msm: base set without the 9-limb tables");
+#endif
 }
 
 template <class F>
@@ -984,9 +1012,12 @@ static void msm_dense_split(const MsmBases<F> &mb, const Fr *scalars, size_t B, 
         hipLaunchKernelGGL(k_msm_binsort, dim3(1u << (c - 1 - FINE_BITS), (unsigned)Bv), dim3(256), 0, s, sc.coarse_base.p, sc.entries2.p, sc.entries.p,
                            max_entries, c, sc.bucket_start.p);
         const uint32_t nlanes = accumulate_lanes(max_entries, Bv);
+#ifdef ZK_EXPERIMENTS
         if (tree_enabled() && sc.treeA1.n) {
             launch_tree_g1(mb, sc, sc.bucket_start.p, sc.entries.p, max_entries, c, Bv, nlanes, part, stride, (size_t)0, L, s, seg_events);
-        } else {
+        } else
+#endif
+        {
             launch_accumulate_reduce<F, true>(mb, sc.bucket_start.p, sc.entries.p, max_entries, c, Bv, nlanes, sums, SumsSel<F>::cap(sc), part, stride, (size_t)0, L, s,
                                               seg_events);
         }
@@ -1184,9 +1215,13 @@ static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, M
         if (mb.f9)
             hipLaunchKernelGGL(k_msm_ones9<F>, dim3(ceil_div(nchunks * B, 256)), dim3(256), 0, s, mb.tern.p, scalars, B, mb.scalar_row.p, n, part, stride,
                                (size_t)0, sc.gen_count.p, sc.gen_idx.p, sc.gen_val.p, wcomb ? mb.wide_mask.p : (const uint8_t *)nullptr);
+#ifdef ZK_EXPERIMENTS
         else
             hipLaunchKernelGGL(k_msm_ones<F>, dim3(ceil_div(nchunks * B, 256)), dim3(256), 0, s, mb.tern.p, scalars, B, mb.scalar_row.p, n, part,
                                stride, (size_t)0, sc.gen_count.p, sc.gen_idx.p, sc.gen_val.p, (const uint8_t *)nullptr);
+#else
+        else throw ZkError("msm: base set without the 9-limb tables");
+#endif
         // wire-comb positions: patterns (values too wide for their class join the compact list) -> walk -> fold into a partial-sum slot
         for (size_t ci = 0; ci < nw; ci++) {
             const CombBasesT<F> &cb = *mb.wcomb[ci];
@@ -1197,6 +1232,7 @@ static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, M
                            sc.gen_val.p, n, c, W, sc.bucket_start.p, sc.entries.p, max_entries);
     }
     const uint32_t nlanes = accumulate_lanes(max_entries, B);
+#ifdef ZK_EXPERIMENTS
     if constexpr (sizeof(F) == 32) {
         if (mb.dense && tree_enabled() && sc.treeA1.n) {
             launch_tree_g1(mb, sc, bs_p, ent_p, max_entries, c, B, nlanes, part, stride, nchunks, L, s, seg_events);
@@ -1204,6 +1240,7 @@ static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, M
             return;
         }
     }
+#endif
     XYZZ<F> *sums = SumsSel<F>::get(sc);
     if (mb.dense) launch_accumulate_reduce<F, true>(mb, bs_p, ent_p, max_entries, c, B, nlanes, sums, SumsSel<F>::cap(sc), part, stride, nchunks, L, s, seg_events);
     else launch_accumulate_reduce<F, false>(mb, sc.bucket_start.p, sc.entries.p, max_entries, c, B, nlanes, sums, SumsSel<F>::cap(sc), part, stride, nchunks, L, s,

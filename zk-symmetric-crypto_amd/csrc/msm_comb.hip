@@ -237,6 +237,61 @@ __device__ __forceinline__ void comb_emit_patterns(const uint32_t *lds, int lane
         }
     }
 }
+// 32 x 32 bit-matrix transpose in registers (Hacker's Delight 7-3): with a[31 - j] = word of scalar j on entry, a[31 - i] holds on
+// exit the pattern of bit plane i (bit j = bit i of scalar j) -- 480 operations per word instead of 2 per (scalar, plane) pair
+__device__ __forceinline__ void comb_transpose32(uint32_t (&a)[32]) {
+    uint32_t m = 0x0000FFFFu;
+#pragma unroll
+    for (int j = 16; j != 0; j >>= 1, m ^= (m << j)) {
+#pragma unroll
+        for (int k = 0; k < 32; k = (k + j + 1) & ~j) {
+            const uint32_t t = (a[k] ^ (a[k + j] >> j)) & m;
+            a[k] ^= t;
+            a[k + j] ^= (t << j);
+        }
+    }
+}
+// Quotient patterns with the clump's K products held in REGISTERS (8 K words; the LDS form below parks them in 32 K bytes per lane,
+// which leaves one wavefront per SIMD) and the bit planes extracted by the transpose above.  K = compile-time clump size.
+template <int K>
+__global__ __launch_bounds__(64) void k_comb_patterns_reg(const Fr *__restrict__ x, const Fr *__restrict__ y, size_t B, size_t n, uint32_t *__restrict__ pat) {
+    const size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
+    const size_t c = blockIdx.y;
+    const int kc = (int)zmin((size_t)K, n - c * K);
+    if (b >= B) return;
+    uint32_t sw[K][8];
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        if (j < kc) {
+            const size_t row = c * K + j;
+            const Fr s = (x[row * B + b] * y[row * B + b]).from_mont();
+#pragma unroll
+            for (int w = 0; w < 8; w++) sw[j][w] = s.l[w];
+        } else {
+#pragma unroll
+            for (int w = 0; w < 8; w++) sw[j][w] = 0;
+        }
+    }
+    const uint32_t low_mask = (1u << (kc - 1)) - 1u;
+    uint32_t *out = pat + (c * COMB_T) * B + b;
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+        uint32_t a[32];
+#pragma unroll
+        for (int j = 0; j < 32; j++) a[31 - j] = j < K ? sw[j][w] : 0u;
+        comb_transpose32(a);
+#pragma unroll
+        for (int i = 0; i < 32; i++) {
+            const int t = w * 32 + i;
+            if (t < COMB_T) {
+                const uint32_t p = a[31 - i];
+                const uint32_t top = (p >> (kc - 1)) & 1u;
+                const uint32_t idx = (top ? p : ~p) & low_mask;
+                out[(size_t)t * B] = idx | ((top ^ 1u) << 31);
+            }
+        }
+    }
+}
 //   y == nullptr: scalars = x[row * B + b];  else the quotient products x[row * B + b] * y[row * B + b] (Montgomery, [row][B])
 __global__ __launch_bounds__(64) void k_comb_patterns(const Fr *__restrict__ x, const Fr *__restrict__ y, size_t B, size_t n, int k, uint32_t *__restrict__ pat) {
     extern __shared__ uint32_t lds[];
@@ -384,6 +439,19 @@ void CombScratch::reserve(const CombBases &cb, size_t B, int nslots) {
     r1.ensure(comb_r1_bytes(cb, B, sizeof(G1X9)));
 }
 void comb_patterns(const CombBases &cb, const Fr *x, const Fr *y, size_t B, uint32_t *pat, hipStream_t s) {
+    static const bool reg_form = [] { const char *e = getenv("ZKPROVE_COMB_PAT_REG"); return !(e && e[0] == '0'); }();
+    if (y && reg_form && cb.k >= 16 && cb.k <= 20) {
+        const dim3 grid(ceil_div(B, 64), (unsigned)cb.nclumps);
+        switch (cb.k) {
+            case 16: hipLaunchKernelGGL(k_comb_patterns_reg<16>, grid, dim3(64), 0, s, x, y, B, cb.n, pat); break;
+            case 17: hipLaunchKernelGGL(k_comb_patterns_reg<17>, grid, dim3(64), 0, s, x, y, B, cb.n, pat); break;
+            case 18: hipLaunchKernelGGL(k_comb_patterns_reg<18>, grid, dim3(64), 0, s, x, y, B, cb.n, pat); break;
+            case 19: hipLaunchKernelGGL(k_comb_patterns_reg<19>, grid, dim3(64), 0, s, x, y, B, cb.n, pat); break;
+            default: hipLaunchKernelGGL(k_comb_patterns_reg<20>, grid, dim3(64), 0, s, x, y, B, cb.n, pat); break;
+        }
+        ZK_HIP(hipGetLastError());
+        return;
+    }
     static PerDeviceOnce once;
     once.run([] { ZK_HIP(hipFuncSetAttribute((const void *)k_comb_patterns, hipFuncAttributeMaxDynamicSharedMemorySize, COMB_KMAX * 8 * 64 * 4)); });
     hipLaunchKernelGGL(k_comb_patterns, dim3(ceil_div(B, 64), (unsigned)cb.nclumps), dim3(64), (size_t)cb.k * 8 * 64 * 4, s, x, y, B, cb.n, cb.k, pat);
@@ -399,22 +467,40 @@ void comb_patterns_rows(const CombShape &cb, const Fr *scalars, size_t B, uint32
     ZK_HIP(hipGetLastError());
 }
 template <class F>
-static void comb_msm_impl(const CombBasesT<F> &cb, const uint32_t *pat, size_t B, CombScratch &sc, XYZZ<F> *out, size_t out_stride, hipStream_t s, hipEvent_t *seg_events) {
+static void comb_walk_impl(const CombBasesT<F> &cb, const uint32_t *pat, size_t B, CombScratch &sc, hipStream_t s, hipEvent_t *seg_events) {
     using X9 = typename Nine<F>::X9;
     if (!cb.ok) throw ZkError("comb MSM: table not built");
     const uint32_t Q = comb_ranges(B, cb.nclumps, cb.T);
     const int groups = fold_groups(cb.T);
     if (sc.acc.n < (size_t)Q * cb.T * B * sizeof(X9) || sc.r1.n < (size_t)groups * B * sizeof(X9)) throw ZkError("comb MSM: scratch too small");
     const size_t tiles = (B + 63) / 64;
-    X9 *acc = reinterpret_cast<X9 *>(sc.acc.p), *r1 = reinterpret_cast<X9 *>(sc.r1.p);
+    X9 *acc = reinterpret_cast<X9 *>(sc.acc.p);
     if (seg_events) ZK_HIP(hipEventRecord(seg_events[0], s));
     if (cb.has_inf) hipLaunchKernelGGL((k_comb_walk<F, true>), dim3((unsigned)(tiles * cb.T * Q)), dim3(64), 0, s, cb.table.p, pat, B, cb.nclumps, cb.E, cb.T, Q, acc);
     else hipLaunchKernelGGL((k_comb_walk<F, false>), dim3((unsigned)(tiles * cb.T * Q)), dim3(64), 0, s, cb.table.p, pat, B, cb.nclumps, cb.E, cb.T, Q, acc);
     if (seg_events) ZK_HIP(hipEventRecord(seg_events[1], s));
+    ZK_HIP(hipGetLastError());
+}
+template <class F>
+static void comb_fold_impl(const CombBasesT<F> &cb, size_t B, CombScratch &sc, XYZZ<F> *out, size_t out_stride, hipStream_t s) {
+    using X9 = typename Nine<F>::X9;
+    const uint32_t Q = comb_ranges(B, cb.nclumps, cb.T);
+    const int groups = fold_groups(cb.T);
+    const size_t tiles = (B + 63) / 64;
+    X9 *acc = reinterpret_cast<X9 *>(sc.acc.p), *r1 = reinterpret_cast<X9 *>(sc.r1.p);
     hipLaunchKernelGGL(k_comb_fold1<F>, dim3((unsigned)(tiles * groups)), dim3(64), 0, s, acc, B, cb.T, Q, r1);
     hipLaunchKernelGGL(k_comb_fold2<F>, dim3((unsigned)tiles), dim3(64), 0, s, r1, B, groups, cb.corr.p, out, out_stride);
     ZK_HIP(hipGetLastError());
 }
+template <class F>
+static void comb_msm_impl(const CombBasesT<F> &cb, const uint32_t *pat, size_t B, CombScratch &sc, XYZZ<F> *out, size_t out_stride, hipStream_t s, hipEvent_t *seg_events) {
+    comb_walk_impl<F>(cb, pat, B, sc, s, seg_events);
+    comb_fold_impl<F>(cb, B, sc, out, out_stride, s);
+}
+// the two halves of comb_msm on their own: the walk (VALU bound) and the fold (a chain of ~280 dependent doublings / additions per
+// proof: latency bound), so that a caller may put the fold on another stream
+void comb_walk(const CombBases &cb, const uint32_t *pat, size_t B, CombScratch &sc, hipStream_t s, hipEvent_t *seg_events) { comb_walk_impl<Fp>(cb, pat, B, sc, s, seg_events); }
+void comb_fold(const CombBases &cb, size_t B, CombScratch &sc, G1XYZZ *out, hipStream_t s) { comb_fold_impl<Fp>(cb, B, sc, out, 1, s); }
 void comb_msm(const CombBases &cb, const uint32_t *pat, size_t B, CombScratch &sc, G1XYZZ *out, hipStream_t s, hipEvent_t *seg_events) {
     comb_msm_impl<Fp>(cb, pat, B, sc, out, 1, s, seg_events);
 }

@@ -97,8 +97,13 @@ void NttDomain::init(int logn_, hipStream_t s) {
     // operands and packing the result -- 23.5 vs 23.3 ms; the same with two butterflies per call so that the two products run in lockstep --
     // 24.5 vs 22.3 ms on the pipelined passes, the callee's registers push the kernel past 256 VGPRs; both dropped.  ZKPROVE_NTT_DIAG=2 runs the passes without any arithmetic: 13.8 ms of
     // the 23.3 are loads, LDS exchange and stores at 3.7 TB/s, hidden under the butterflies.)
+    // (Built only with -DZK_EXPERIMENTS -- `make experiments`, libzkprove_exp.so -- where the parity tests keep it bit-exact.)
+#ifdef ZK_EXPERIMENTS
     static const bool want9 = [] { const char *e = getenv("ZKPROVE_NTT_F9"); return e && e[0] == '1'; }();
     f9 = want9;
+#else
+    f9 = false;
+#endif
     if (f9) {
         tw_fwd9.alloc(n / 2 + 1); tw_inv9.alloc(n / 2 + 1); coset_pre9.alloc(n); coset_post9.alloc(n);
         const size_t h = n / 2 ? n / 2 : 1;
@@ -138,6 +143,7 @@ struct NttWords {
         u = a;
     }
 };
+#ifdef ZK_EXPERIMENTS
 // timing diagnostics (ZKPROVE_NTT_DIAG, results are WRONG): 1 = butterflies without the product, 2 = without anything (loads,
 // LDS exchange and stores only) -- what the passes cost apart from the arithmetic
 template <int LEVEL>
@@ -233,6 +239,8 @@ struct Ntt9 {
         v = fold(d);
     }
 };
+
+#endif  // ZK_EXPERIMENTS
 
 // ---------------------------------------------------------------------------------------------
 // DIF pass: K stages starting at block length `len` (natural -> towards bit-reversed).
@@ -744,20 +752,32 @@ const Fr *NttDomain::table9(const Fr *t) const {
 }
 void NttDomain::dif(Fr *data, size_t B, bool inverse, const Fr *postmul, hipStream_t s) const {
     const Fr *tw = inverse ? tw_inv.p : tw_fwd.p;
+#ifdef ZK_EXPERIMENTS
     static const int diag = [] { const char *e = getenv("ZKPROVE_NTT_DIAG"); return e ? atoi(e) : 0; }();
-    if (diag == 1) dif_passes<NttDiag<1>>(logn, data, B, tw, postmul, s);
-    else if (diag == 2) dif_passes<NttDiag<2>>(logn, data, B, tw, postmul, s);
-    else if (f9) dif_passes<Ntt9>(logn, data, B, table9(tw), table9(postmul), s);
-    else dif_passes<NttWords>(logn, data, B, tw, postmul, s);
+    if (diag == 1 || diag == 2 || f9) {
+        if (diag == 1) dif_passes<NttDiag<1>>(logn, data, B, tw, postmul, s);
+        else if (diag == 2) dif_passes<NttDiag<2>>(logn, data, B, tw, postmul, s);
+        else dif_passes<Ntt9>(logn, data, B, table9(tw), table9(postmul), s);
+        ZK_HIP(hipGetLastError());
+        return;
+    }
+#endif
+    dif_passes<NttWords>(logn, data, B, tw, postmul, s);
     ZK_HIP(hipGetLastError());
 }
 void NttDomain::dit(Fr *data, size_t B, bool inverse, const Fr *premul, hipStream_t s) const {
     const Fr *tw = inverse ? tw_inv.p : tw_fwd.p;
+#ifdef ZK_EXPERIMENTS
     static const int diag = [] { const char *e = getenv("ZKPROVE_NTT_DIAG"); return e ? atoi(e) : 0; }();
-    if (diag == 1) dit_passes<NttDiag<1>>(logn, data, B, tw, premul, s);
-    else if (diag == 2) dit_passes<NttDiag<2>>(logn, data, B, tw, premul, s);
-    else if (f9) dit_passes<Ntt9>(logn, data, B, table9(tw), table9(premul), s);
-    else dit_passes<NttWords>(logn, data, B, tw, premul, s);
+    if (diag == 1 || diag == 2 || f9) {
+        if (diag == 1) dit_passes<NttDiag<1>>(logn, data, B, tw, premul, s);
+        else if (diag == 2) dit_passes<NttDiag<2>>(logn, data, B, tw, premul, s);
+        else dit_passes<Ntt9>(logn, data, B, table9(tw), table9(premul), s);
+        ZK_HIP(hipGetLastError());
+        return;
+    }
+#endif
+    dit_passes<NttWords>(logn, data, B, tw, premul, s);
     ZK_HIP(hipGetLastError());
 }
 

@@ -151,7 +151,10 @@ struct Algorithm::Resident {
 
 Algorithm::Algorithm() {}
 Algorithm::~Algorithm() {
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     (void)hipSetDevice(device);
+    struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore{prev};
     if (res) {
         for (auto &e : res->ev) if (e) (void)hipEventDestroy(e);
         for (auto &st : res->set) for (hipEvent_t e : {st.solved, st.consumed, st.uploaded, st.t0, st.t1, st.t2, st.t3, st.sorted, st.zdone}) if (e) (void)hipEventDestroy(e);
@@ -163,7 +166,7 @@ Algorithm::~Algorithm() {
 }
 
 void Algorithm::load(const uint8_t *pkb, size_t pk_len, const uint8_t *r1cs_bytes, size_t r1cs_len) {
-    bind_device(device);
+    DeviceScope on_device(device);
     r1cs_parse(r1cs_bytes, r1cs_len, cs);
     hipStream_t st = 0;
     prog.build(cs, st);
@@ -606,7 +609,7 @@ void Algorithm::wire_comb_reserve(MsmScratch &sc, bool main_set, size_t B) {
 
 // ------------------------------------------------------------------------------- pipeline
 void Algorithm::resident_reserve(size_t B) {
-    bind_device(device);
+    DeviceScope on_device(device);
     if (!res) {
         res.reset(new Resident());
         // the solve stage and the proof tail are chains of small latency-bound kernels: on high-priority streams they slip in
@@ -807,7 +810,15 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm,
         ZK_HIP(hipStreamWaitEvent(st, S.sorted, 0));
         R.used_comb = S.comb;
         if (S.comb) {
-            comb_msm(pk.Zcomb, R.comb.pat[S.zslot].p, B, R.comb, R.m_z.p, st, &R.ev[8]);
+            // the walk here; its fold (a latency-bound chain of doublings per proof) on the tail stream, in front of the tail's last
+            // stage, which is its only reader -- the main stream goes straight on to the next batch's MSMs
+            static const bool fold_on_tail = [] { const char *e = getenv("ZKPROVE_COMB_FOLD_TAIL"); return !(e && e[0] == '0'); }();
+            comb_walk(pk.Zcomb, R.comb.pat[S.zslot].p, B, R.comb, st, &R.ev[8]);
+            if (fold_on_tail) {
+                ZK_HIP(hipEventRecord(S.zdone, st));
+                ZK_HIP(hipStreamWaitEvent(tail, S.zdone, 0));
+                comb_fold(pk.Zcomb, B, R.comb, R.m_z.p, tail);
+            } else comb_fold(pk.Zcomb, B, R.comb, R.m_z.p, st);
         } else {
             R.ms.presorted = true;
             R.ms.zslot = S.zslot;
@@ -931,7 +942,7 @@ void Algorithm::collect_times(SolveSet &S, PhaseTimes *times) {
 }
 
 void Algorithm::resident_prove(PhaseTimes *times) {
-    bind_device(device);
+    DeviceScope on_device(device);
     Resident &R = *res;
     hipStream_t st = R.stream;
     R.last_set = 0;
@@ -972,7 +983,7 @@ void Algorithm::ensure_second_set(int nsets) {
 // nsteps batches back to back (the same resident inputs are re-proved each time), the SOLVE stage of batch k+1 overlapped
 // with the NTT + MSM stage of batch k.  times (optional) = phase times of the LAST batch; total = whole call / nsteps.
 void Algorithm::resident_prove_pipelined(int nsteps, PhaseTimes *times) {
-    bind_device(device);
+    DeviceScope on_device(device);
     Resident &R = *res;
     if (nsteps <= 0) return;
     hipStream_t M = R.stream, S = R.stream2, F = R.stream3;
@@ -1063,7 +1074,7 @@ __global__ __launch_bounds__(64) void k_split_sum(const SplitRecord *__restrict_
 }
 void Algorithm::split_partials(uint8_t *out384) {
     std::lock_guard<std::mutex> lk(mu);
-    bind_device(device);
+    DeviceScope on_device(device);
     if (!res) throw ZkError("split_partials: nothing uploaded");
     Resident &R = *res;
     const size_t B = R.B;
@@ -1082,7 +1093,7 @@ void Algorithm::split_partials(uint8_t *out384) {
 }
 void Algorithm::split_finish(int world, const uint8_t *gathered) {
     std::lock_guard<std::mutex> lk(mu);
-    bind_device(device);
+    DeviceScope on_device(device);
     if (!res) throw ZkError("split_finish: nothing uploaded");
     Resident &R = *res;
     const size_t B = R.B;
@@ -1098,7 +1109,7 @@ void Algorithm::split_finish(int world, const uint8_t *gathered) {
 }
 
 void Algorithm::resident_download(ProofPoints *out, uint32_t *errs) {
-    bind_device(device);
+    DeviceScope on_device(device);
     Resident &R = *res;
     SolveSet &S = R.set[R.last_set];
     ZK_HIP(hipMemcpy(out, S.out.p, R.B * sizeof(ProofPoints), hipMemcpyDeviceToHost));
@@ -1111,7 +1122,7 @@ void Algorithm::resident_download(ProofPoints *out, uint32_t *errs) {
 void Algorithm::prove_batch(size_t batch, const uint32_t *inputs, const U256 *r, const U256 *s, const U256 *randomize, ProofPoints *out,
                             uint32_t *errs, PhaseTimes *times) {
     std::unique_lock<std::mutex> lk(mu);
-    bind_device(device);
+    DeviceScope on_device(device);
     const size_t ni = prog.n_inputs;
     const size_t nchunks = (batch + max_chunk - 1) / max_chunk;
     if (nchunks <= 1) {
@@ -1147,7 +1158,7 @@ void Algorithm::prove_batch(size_t batch, const uint32_t *inputs, const U256 *r,
 // and downloads on the copy stream.  The feed is asked for chunk k only after chunk k-NS has been handed back.
 void Algorithm::prove_stream(ChunkFeed &feed, PhaseTimes *times) {
     std::lock_guard<std::mutex> lk(mu);
-    bind_device(device);
+    DeviceScope on_device(device);
     const size_t ni = prog.n_inputs;
     resident_reserve(max_chunk);
     Resident &R = *res;
@@ -1214,7 +1225,7 @@ void Algorithm::prove_stream(ChunkFeed &feed, PhaseTimes *times) {
 // parity-test hook: solved wires and quotient-stage products (A*B on the coset g<w>, natural order) of the last resident
 // batch, canonical form
 void Algorithm::debug_fetch(uint8_t *wires_out, uint8_t *h_out) {
-    bind_device(device);
+    DeviceScope on_device(device);
     Resident &R = *res;
     const size_t B = R.B, nw = prog.n_wires, N = (size_t)1 << prog.log_domain;
     std::vector<Fr> tmp;

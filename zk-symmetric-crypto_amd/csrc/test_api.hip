@@ -251,7 +251,7 @@ extern "C" int zkp_bench_comb(int logn, long batch, int k, int iters, double *ou
     double acc[3] = {0, 0, 0};
     for (int it = 0; it < iters + 1; it++) {
         ZK_HIP(hipEventRecord(e[0], 0));
-        comb_patterns(cb, x.p, nullptr, B, sc.pat[0].p, 0);
+        comb_patterns(cb, x.p, x.p, B, sc.pat[0].p, 0);          // the prover's call shape: products of two matrices
         ZK_HIP(hipEventRecord(e[1], 0));
         comb_msm(cb, sc.pat[0].p, B, sc, res.p, 0, &e[2]);
         ZK_HIP(hipEventRecord(e[4], 0));
@@ -583,6 +583,7 @@ extern "C" double zkp_bench_to_coset(int logn, long batch, int iters) {
     ZKP_CATCH(-1.0)
 }
 
+#ifdef ZK_EXPERIMENTS
 // ---- debug harness: device tree kernel vs. host emulation of the same code on host-sorted input (prints per-bucket diffs)
 #include "msm_tree.cuh"
 #include <random>
@@ -652,3 +653,4 @@ extern "C" int zkp_debug_tree(int n, int c, int piece, int dbg) {
     return bad;
     ZKP_CATCH(-1)
 }
+#endif  // ZK_EXPERIMENTS
