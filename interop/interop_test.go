@@ -96,7 +96,51 @@ func runCase(t *testing.T, id uint8, ext, cipher string, keyLen, nBlocks, blockL
 	json.Unmarshal(ref, &refOut)
 	req2, _ := json.Marshal(&verifier.InputVerifyParams{Cipher: cipher, Proof: refOut.Proof, PublicSignals: signals})
 	if C.Verify(goSlice(req2)) != 1 {
-		t.Fatalf("%s: libzkprove Verify rejected a gnark proof (set ZKPROVE_VK_DIR to verifier/impl/generated)", cipher)
+		t.Fatalf("%s: libzkprove Verify rejected a gnark proof (put generated/vk.* beside the library or set ZKPROVE_VK_DIR)", cipher)
+	}
+	// the batch entries (extensions of the ABI): ProveBatch -> every proof accepted by the reference verifier; VerifyBatch over a
+	// mix of libzkprove and gnark proofs -> all true, and false exactly for a tampered member (the GPU batch check falls back to
+	// per-proof verification when a member fails)
+	const n = 24
+	arr := []json.RawMessage{}
+	for i := 0; i < n; i++ {
+		arr = append(arr, params)
+	}
+	body, _ := json.Marshal(arr)
+	rb := C.ProveBatch(goSlice(body))
+	var outs []*prover.OutputParams
+	if err := json.Unmarshal(C.GoBytes(rb.r0, C.int(rb.r1)), &outs); err != nil || len(outs) != n {
+		t.Fatalf("%s: ProveBatch answered %s", cipher, C.GoString((*C.char)(rb.r0)))
+	}
+	C.Free(rb.r0)
+	vreqs := []json.RawMessage{}
+	for _, o := range outs {
+		sig, _ := json.Marshal(&verifier.PublicSignalsJSON{Ciphertext: o.Ciphertext, Blocks: vblocks, Input: input})
+		r, _ := json.Marshal(&verifier.InputVerifyParams{Cipher: cipher, Proof: o.Proof, PublicSignals: sig})
+		if !verifier.Verify(r) {
+			t.Fatalf("%s: reference verifier rejected a ProveBatch proof", cipher)
+		}
+		vreqs = append(vreqs, r)
+	}
+	vreqs = append(vreqs, req2) // gnark's own proof
+	bad, _ := json.Marshal(&verifier.InputVerifyParams{Cipher: cipher, Proof: outs[0].Proof, PublicSignals: signals}) // proof 0 under the first request's signals is fine ...
+	_ = bad
+	tampered := append([]byte{}, input...)
+	tampered[0] ^= 1
+	sigT, _ := json.Marshal(&verifier.PublicSignalsJSON{Ciphertext: out.Ciphertext, Blocks: vblocks, Input: tampered})
+	reqT, _ := json.Marshal(&verifier.InputVerifyParams{Cipher: cipher, Proof: out.Proof, PublicSignals: sigT})
+	vreqs = append(vreqs, reqT) // ... a flipped input byte is not
+	vbody, _ := json.Marshal(vreqs)
+	rv := C.VerifyBatch(goSlice(vbody))
+	var oks []bool
+	if err := json.Unmarshal(C.GoBytes(rv.r0, C.int(rv.r1)), &oks); err != nil || len(oks) != len(vreqs) {
+		t.Fatalf("%s: VerifyBatch answered %s", cipher, C.GoString((*C.char)(rv.r0)))
+	}
+	C.VFree(rv.r0)
+	for i, ok := range oks {
+		if ok != (i != len(oks)-1) {
+			t.Fatalf("%s: VerifyBatch element %d = %v", cipher, i, ok)
+		}
 	}
 }
 
