@@ -121,6 +121,8 @@ int zkp_split_finish(int algorithmID, int world, const uint8_t *gathered);
  * clumps | windows, table MiB, mixed additions per proof of its walk, 1 when the wire MSMs use wire combs for their non-0/+-1 positions,
  * such positions in G1.A, wire-comb table MiB} */
 int zkp_quotient_msm_info(int algorithmID, long *info8);
+/* after a step: {sum, max, instances with any} of the entries the last main-stream wire MSM handed to the bucket pipeline (diagnostic) */
+int zkp_debug_leftovers(int algorithmID, long *out3);
 /* after a step: copy out the solved wire vectors [batch][n_wires][32] and the quotient-stage products
  * f_i = A(g w^i) * B(g w^i) [batch][N][32] (canonical LE, natural order; the scalars of the folded quotient MSM, see
  * csrc/keyfold.hip) -- parity tests only */

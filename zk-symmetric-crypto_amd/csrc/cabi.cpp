@@ -951,6 +951,14 @@ int zkp_quotient_msm_info(int id, long *info8) {
     return 0;
     CABI_CATCH
 }
+int zkp_debug_leftovers(int id, long *out3) {
+    CABI_TRY
+    Algorithm *a = (id >= 0 && id < 3) ? get_alg(id) : nullptr;
+    if (!a || !a->res) throw ZkError("algorithm not initialised / nothing uploaded");
+    a->debug_leftovers(out3);
+    return 0;
+    CABI_CATCH
+}
 int zkp_debug_fetch(int id, uint8_t *wires, uint8_t *h) {
     CABI_TRY
     Algorithm *a = (id >= 0 && id < 3) ? get_alg(id) : nullptr;

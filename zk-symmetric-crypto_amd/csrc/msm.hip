@@ -269,6 +269,9 @@ __global__ __launch_bounds__(SORT_THREADS) void k_msm_sort(const Fr *__restrict_
     uint32_t *scan = lds + nb;
     const size_t b = blockIdx.x;
     const int tid = threadIdx.x;
+    // wire MSMs: gen_count[B] is the batch total of the compact lists; 0 (the normal case once the wire combs take the wide positions,
+    // and always for the ChaCha20 circuit) means no instance has anything for the bucket pipeline: its kernels return at once
+    if (!DENSE && gen_count[gridDim.x] == 0) return;
     const size_t cnt = DENSE ? n : (size_t)gen_count[b];
     uint32_t *bs = bucket_start + b * (nb + 1);
     if (cnt == 0) {     // nothing for the bucket pipeline: publish an empty histogram and leave
@@ -549,9 +552,10 @@ struct Acc9 {
 template <class F, bool DENSE, class ACC>
 __device__ __forceinline__ void accumulate_body(const Affine<F> *__restrict__ table, const uint32_t *__restrict__ bucket_start,
                                                 const uint32_t *__restrict__ entries, size_t max_entries, int c, size_t B,
-                                                uint32_t nlanes, typename ACC::Out *__restrict__ sums) {
+                                                uint32_t nlanes, typename ACC::Out *__restrict__ sums, const uint32_t *__restrict__ skip_if_zero = nullptr) {
     const uint32_t nb = 1u << (c - 1);
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (skip_if_zero && *skip_if_zero == 0) return;                 // empty compact lists (k_msm_sort did not run either)
     if (t >= (size_t)nlanes * B) return;
     const size_t b = t / nlanes;
     const uint32_t lane = (uint32_t)(t % nlanes);
@@ -634,8 +638,8 @@ ZK_ACC_G1(false)
 template <class F, bool DENSE>
 __global__ __launch_bounds__(64, ZK_ACC9_BOUNDS(F)) void k_msm_accumulate9(const Affine<F> *__restrict__ table, const uint32_t *__restrict__ bucket_start,
                                                                           const uint32_t *__restrict__ entries, size_t max_entries, int c, size_t B,
-                                                                          uint32_t nlanes, typename Nine<F>::X9 *__restrict__ sums) {
-    accumulate_body<F, DENSE, Acc9<F>>(table, bucket_start, entries, max_entries, c, B, nlanes, sums);
+                                                                          uint32_t nlanes, typename Nine<F>::X9 *__restrict__ sums, const uint32_t *__restrict__ skip_if_zero) {
+    accumulate_body<F, DENSE, Acc9<F>>(table, bucket_start, entries, max_entries, c, B, nlanes, sums, skip_if_zero);
 }
 
 #ifdef ZK_EXPERIMENTS
@@ -679,7 +683,7 @@ __global__ __launch_bounds__(64) void k_msm_bucket_reduce(const XYZZ<F> *__restr
 template <class F>
 __global__ __launch_bounds__(64, ZK_FP2_WAVES(F)) void k_msm_bucket_reduce9(const typename Nine<F>::X9 *__restrict__ sums, const uint32_t *__restrict__ bucket_start,
                                                                            int c, size_t B, XYZZ<F> *__restrict__ part, size_t part_stride, size_t part_off,
-                                                                           uint32_t L) {
+                                                                           uint32_t L, const uint32_t *__restrict__ skip_if_zero) {
     using X9 = typename Nine<F>::X9;
     const uint32_t nb = 1u << (c - 1);
     const uint32_t nseg = nb / L;
@@ -687,6 +691,7 @@ __global__ __launch_bounds__(64, ZK_FP2_WAVES(F)) void k_msm_bucket_reduce9(cons
     if (t >= (size_t)nseg * B) return;
     const size_t b = t / nseg;
     const uint32_t seg = (uint32_t)(t % nseg);
+    if (skip_if_zero && *skip_if_zero == 0) { part[b * part_stride + part_off + seg] = XYZZ<F>::inf(); return; }      // empty lists: the segment totals are the identity
     const uint32_t *bs = bucket_start + b * (nb + 1);
     const X9 *in = sums + b * nb;
     X9 run9 = X9::inf(), tot9 = X9::inf();
@@ -767,6 +772,7 @@ __global__ __launch_bounds__(256, ZK_FP2_WAVES(F)) void k_msm_ones(const Affine<
             m &= m - 1;
             const size_t j = j0 + wd * 32 + bit;
             const uint32_t q = atomicAdd(&gen_count[b], 1u);
+            atomicAdd(&gen_count[B], 1u);                      // batch total: the bucket-pipeline kernels leave at once when it stays 0
             gen_idx[b * n + q] = (uint32_t)j;
             gen_val[b * n + q] = scalars[(size_t)rows[j] * B + b].from_mont();
         }
@@ -846,6 +852,7 @@ __global__ __launch_bounds__(256, ZK_FP2_WAVES(F)) void k_msm_ones9(const Affine
             m &= m - 1;
             const size_t j = j0 + wd * 32 + bit;
             const uint32_t q = atomicAdd(&gen_count[b], 1u);
+            atomicAdd(&gen_count[B], 1u);                      // batch total: the bucket-pipeline kernels leave at once when it stays 0
             gen_idx[b * n + q] = (uint32_t)j;
             gen_val[b * n + q] = scalars[(size_t)rows[j] * B + b].from_mont();
         }
@@ -945,7 +952,7 @@ static void launch_tree_g1(const MsmBasesG1 &mb, MsmScratch &sc, const uint32_t 
 template <class F, bool DENSE>
 static void launch_accumulate_reduce(const MsmBases<F> &mb, const uint32_t *bs_p, const uint32_t *ent_p, size_t max_entries, int c, size_t B, uint32_t nlanes,
                                      XYZZ<F> *sums, size_t sums_cap, XYZZ<F> *part, size_t stride, size_t part_off, uint32_t L, hipStream_t s,
-                                     hipEvent_t *seg_events) {
+                                     hipEvent_t *seg_events, const uint32_t *skip_if_zero = nullptr) {
     const uint32_t nb = 1u << (c - 1);
     const size_t nseg = nb / L;
     const dim3 grid(ceil_div((size_t)nlanes * B, 64)), rgrid(ceil_div(nseg * B, 64));
@@ -954,9 +961,9 @@ static void launch_accumulate_reduce(const MsmBases<F> &mb, const uint32_t *bs_p
         if (sums_cap * sizeof(XYZZ<F>) < B * (size_t)nb * sizeof(X9)) throw ZkError("msm bucket-sum scratch too small");
         X9 *sums9 = reinterpret_cast<X9 *>(sums);
         if (seg_events) ZK_HIP(hipEventRecord(seg_events[0], s));
-        hipLaunchKernelGGL((k_msm_accumulate9<F, DENSE>), grid, dim3(64), 0, s, mb.table.p, bs_p, ent_p, max_entries, c, B, nlanes, sums9);
+        hipLaunchKernelGGL((k_msm_accumulate9<F, DENSE>), grid, dim3(64), 0, s, mb.table.p, bs_p, ent_p, max_entries, c, B, nlanes, sums9, skip_if_zero);
         if (seg_events) ZK_HIP(hipEventRecord(seg_events[1], s));
-        hipLaunchKernelGGL(k_msm_bucket_reduce9<F>, rgrid, dim3(64), 0, s, sums9, bs_p, c, B, part, stride, part_off, L);
+        hipLaunchKernelGGL(k_msm_bucket_reduce9<F>, rgrid, dim3(64), 0, s, sums9, bs_p, c, B, part, stride, part_off, L, skip_if_zero);
         return;
     }
 #ifdef ZK_EXPERIMENTS
@@ -1210,8 +1217,8 @@ static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, M
                                (const uint32_t *)nullptr, (const Fr *)nullptr, n, c, W, bs_p, ent_p, max_entries);
         }
     } else {
-        if (sc.gen_count.n < B || sc.gen_idx.n < B * n || sc.gen_val.n < B * n) throw ZkError("msm compact-list scratch too small");
-        ZK_HIP(hipMemsetAsync(sc.gen_count.p, 0, B * sizeof(uint32_t), s));
+        if (sc.gen_count.n < B + 1 || sc.gen_idx.n < B * n || sc.gen_val.n < B * n) throw ZkError("msm compact-list scratch too small");
+        ZK_HIP(hipMemsetAsync(sc.gen_count.p, 0, (B + 1) * sizeof(uint32_t), s));      // [B] = the batch total
         if (mb.f9)
             hipLaunchKernelGGL(k_msm_ones9<F>, dim3(ceil_div(nchunks * B, 256)), dim3(256), 0, s, mb.tern.p, scalars, B, mb.scalar_row.p, n, part, stride,
                                (size_t)0, sc.gen_count.p, sc.gen_idx.p, sc.gen_val.p, wcomb ? mb.wide_mask.p : (const uint8_t *)nullptr);
@@ -1244,7 +1251,7 @@ static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, M
     XYZZ<F> *sums = SumsSel<F>::get(sc);
     if (mb.dense) launch_accumulate_reduce<F, true>(mb, bs_p, ent_p, max_entries, c, B, nlanes, sums, SumsSel<F>::cap(sc), part, stride, nchunks, L, s, seg_events);
     else launch_accumulate_reduce<F, false>(mb, sc.bucket_start.p, sc.entries.p, max_entries, c, B, nlanes, sums, SumsSel<F>::cap(sc), part, stride, nchunks, L, s,
-                                            seg_events);
+                                            seg_events, mb.f9 ? sc.gen_count.p + B : (const uint32_t *)nullptr);
     msm_fold_parts<F>(part, stride, npart, out, B, s);
 }
 void msm_batch(const MsmBasesG1 &mb, const Fr *sc, size_t B, MsmScratch &scr, G1XYZZ *out, hipStream_t s, hipEvent_t *ev) { msm_batch_impl<Fp>(mb, sc, B, scr, out, s, ev); }

@@ -336,6 +336,7 @@ __global__ __launch_bounds__(64) void k_comb_patterns_rows(const Fr *__restrict_
         }
         if (over) {
             const uint32_t q = atomicAdd(&gen_count[b], 1u);
+            atomicAdd(&gen_count[B], 1u);                      // batch total (msm.hip: the bucket pipeline leaves at once when it stays 0)
             gen_idx[b * gen_stride + q] = base_index[pos];
             gen_val[b * gen_stride + q] = s;
             s = Fr::zero();

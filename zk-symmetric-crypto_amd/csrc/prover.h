@@ -101,6 +101,7 @@ class Algorithm {
     bool wire_comb_tried = false, wire_comb_on = false;
     void wire_comb_prepare(size_t B);
     void wire_comb_reserve(MsmScratch &sc, bool main_set, size_t B);
+    void debug_leftovers(long *out3);                       // {sum, max, instances with any} of the compact bucket-pipeline list left by the last main-stream wire MSM
     size_t resident_batch() const;                          // instances of the current resident batch (0: none)
     bool comb_active() const;                               // the current resident batch takes the comb path for its quotient MSM
     void comb_prepare(size_t B);                            // lazy table build + scratch (resident_reserve)
