@@ -1191,7 +1191,6 @@ void Algorithm::prove_batch(size_t batch, const uint32_t *inputs, const U256 *r,
 void Algorithm::prove_stream(ChunkFeed &feed, PhaseTimes *times) {
     std::lock_guard<std::mutex> lk(mu);
     DeviceScope on_device(device);
-    const size_t ni = prog.n_inputs;
     resident_reserve(max_chunk);
     Resident &R = *res;
     // two working sets; three when chunks are prepared ahead (as in resident_prove_pipelined: the side chain of chunk k then runs beside
