@@ -262,16 +262,17 @@ template <bool DENSE>
 __global__ __launch_bounds__(SORT_THREADS) void k_msm_sort(const Fr *__restrict__ dense, size_t dense_stride, const uint32_t *__restrict__ gen_count,
                                                            const uint32_t *__restrict__ gen_idx, const Fr *__restrict__ gen_val, size_t n, int c,
                                                            int W, uint32_t *__restrict__ bucket_start, uint32_t *__restrict__ entries,
-                                                           size_t max_entries) {
+                                                           size_t max_entries, const uint32_t *__restrict__ skip_if_zero) {
     extern __shared__ uint32_t lds[];
     const uint32_t nb = 1u << (c - 1);
     uint32_t *hist = lds;
     uint32_t *scan = lds + nb;
     const size_t b = blockIdx.x;
     const int tid = threadIdx.x;
-    // wire MSMs: gen_count[B] is the batch total of the compact lists; 0 (the normal case once the wire combs take the wide positions,
-    // and always for the ChaCha20 circuit) means no instance has anything for the bucket pipeline: its kernels return at once
-    if (!DENSE && gen_count[gridDim.x] == 0) return;
+    // wire MSMs (9-limb kernels): *skip_if_zero = gen_count[B] is the batch total of the compact lists; 0 (the normal case once the wire
+    // combs take the wide positions, and always for the ChaCha20 circuit) means no instance has anything for the bucket pipeline: its
+    // kernels -- this one, k_msm_accumulate9 and k_msm_bucket_reduce9 -- return at once
+    if (skip_if_zero && *skip_if_zero == 0) return;
     const size_t cnt = DENSE ? n : (size_t)gen_count[b];
     uint32_t *bs = bucket_start + b * (nb + 1);
     if (cnt == 0) {     // nothing for the bucket pipeline: publish an empty histogram and leave
@@ -1214,7 +1215,7 @@ static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, M
             dense_two_level_sort(mb, scalars, B, sc, ent_p, bs_p, s);
         } else {
             hipLaunchKernelGGL(k_msm_sort<true>, dim3((unsigned)B), dim3(SORT_THREADS), lds, s, scalars, mb.dense_stride, (const uint32_t *)nullptr,
-                               (const uint32_t *)nullptr, (const Fr *)nullptr, n, c, W, bs_p, ent_p, max_entries);
+                               (const uint32_t *)nullptr, (const Fr *)nullptr, n, c, W, bs_p, ent_p, max_entries, (const uint32_t *)nullptr);
         }
     } else {
         if (sc.gen_count.n < B + 1 || sc.gen_idx.n < B * n || sc.gen_val.n < B * n) throw ZkError("msm compact-list scratch too small");
@@ -1236,7 +1237,7 @@ static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, M
             comb_msm_strided(cb, sc.wire_comb.pat[0].p, B, sc.wire_comb, part + nchunks + nseg + ci, stride, s);
         }
         hipLaunchKernelGGL(k_msm_sort<false>, dim3((unsigned)B), dim3(SORT_THREADS), lds, s, (const Fr *)nullptr, (size_t)0, sc.gen_count.p, sc.gen_idx.p,
-                           sc.gen_val.p, n, c, W, sc.bucket_start.p, sc.entries.p, max_entries);
+                           sc.gen_val.p, n, c, W, sc.bucket_start.p, sc.entries.p, max_entries, mb.f9 ? sc.gen_count.p + B : (const uint32_t *)nullptr);
     }
     const uint32_t nlanes = accumulate_lanes(max_entries, B);
 #ifdef ZK_EXPERIMENTS
