@@ -701,7 +701,16 @@ static void launch_dit(Fr *data, size_t B, int logn, int logS, const Fr *tw, con
 }
 
 // stage schedule: as many 6-stage LDS passes as possible, then one 5- or 4-stage LDS pass, then register passes
+// Experiment (-DZK_EXPERIMENTS, ZKPROVE_NTT_EIGHT=1; VERDICT r2 task 5): 8-stage (4,4) LDS passes -- 256 elements x 8 instances per 64 KiB
+// tile, 16 elements per thread -- so that N = 2^16 takes TWO round trips through HBM per transform instead of three.  Bit-exact and
+// SLOWER: 38.0 vs 22.4 ms for the four transforms of a 1024-batch (the tile's rows shrink to 256-byte segments, 225-245 VGPRs leave two
+// wavefronts per SIMD, no software pipelining), 9 414 vs 10 918 proofs/s on one box.  The step is bound by VALU work, of which the
+// transforms' share (~16 ms) does not depend on the pass structure, so the three-pass (3,3) tiling stays.
 static int next_pass(int rem) {
+#ifdef ZK_EXPERIMENTS
+    static const bool eight = [] { const char *e = getenv("ZKPROVE_NTT_EIGHT"); return e && e[0] == '1'; }();
+    if (eight && rem >= 8 && rem % 8 == 0) return 8;
+#endif
     if (rem >= 6) return 6;
     return rem;     // 5, 4 -> LDS (3,2)/(2,2); 3, 2, 1 -> register kernels
 }
@@ -713,6 +722,9 @@ static void dif_passes(int logn, Fr *data, size_t B, const Fr *tw, const Fr *pos
         const bool last = loglen - k == 0;
         const Fr *pm = last ? postmul : nullptr;
         switch (k) {
+#ifdef ZK_EXPERIMENTS
+            case 8: launch_dif_lds<P, 4, 4>(data, B, logn, loglen, tw, pm, last, s); break;
+#endif
             case 6: launch_dif_lds<P, 3, 3>(data, B, logn, loglen, tw, pm, last, s); break;
             case 5: launch_dif_lds<P, 3, 2>(data, B, logn, loglen, tw, pm, last, s); break;
             case 4: launch_dif_lds<P, 2, 2>(data, B, logn, loglen, tw, pm, last, s); break;
@@ -731,6 +743,9 @@ static void dit_passes(int logn, Fr *data, size_t B, const Fr *tw, const Fr *pre
         const Fr *pm = (logS == 0) ? premul : nullptr;
         const bool last = logS + k == logn;
         switch (k) {
+#ifdef ZK_EXPERIMENTS
+            case 8: launch_dit_lds<P, 4, 4>(data, B, logn, logS, tw, pm, last, s); break;
+#endif
             case 6: launch_dit_lds<P, 3, 3>(data, B, logn, logS, tw, pm, last, s); break;
             case 5: launch_dit_lds<P, 3, 2>(data, B, logn, logS, tw, pm, last, s); break;
             case 4: launch_dit_lds<P, 2, 2>(data, B, logn, logS, tw, pm, last, s); break;
