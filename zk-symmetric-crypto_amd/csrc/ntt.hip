@@ -756,6 +756,135 @@ static void dit_passes(int logn, Fr *data, size_t B, const Fr *tw, const Fr *pre
         logS += k;
     }
 }
+// ---------------------------------------------------------------------------------------------
+// Small batches (a single Prove() call: B = 1 .. 16).  The tiled kernels above put 32 INSTANCES on the lanes of a tile, so one proof
+// keeps 1 lane in 32 busy and the four transforms of a Prove() call cost 2.2 ms of pure launch latency.  Here the lanes are the
+// butterflies: a workgroup owns a tile of 2^K elements (stride S) of ONE instance in LDS and runs all K stages on it, 2^(K-1) threads,
+// one butterfly per thread and stage; N = 2^16 is two launches per transform (8 + 8 stages).  Same stage / twiddle indexing as
+// k_ntt_dif / k_ntt_dit, same weak-form arithmetic, hence bit-identical results.
+template <class P, int K>
+__global__ __launch_bounds__(1 << (K > 1 ? K - 1 : 0)) void k_ntt_dif_small(Fr *__restrict__ data, size_t B, int logn, int loglen, const Fr *__restrict__ tw,
+                                                                           const Fr *__restrict__ postmul, int last) {
+    using E = typename P::E;
+    constexpr int N = 1 << K, HALF = N / 2 ? N / 2 : 1;
+    __shared__ E lds[N];
+    const int tid = threadIdx.x;
+    const size_t g = blockIdx.x, b = blockIdx.y;
+    const int logS = loglen - K;
+    const size_t S = (size_t)1 << logS;
+    const size_t blk = g >> logS, p = g & (S - 1);
+    const size_t base = (blk << loglen) + p;
+    for (int e = tid; e < N; e += HALF) lds[e] = P::load(data[(base + ((size_t)e << logS)) * B + b]);
+    __syncthreads();
+#pragma unroll 1
+    for (int st = 0; st < K; st++) {
+        const int half = 1 << (K - 1 - st);
+        const int m = ((tid / half) * 2 * half) + (tid % half);
+        const size_t j = p + ((size_t)(m % half) << logS);
+        const int twshift = logn - (loglen - st);
+        E u = lds[m], v = lds[m + half];
+        P::dif(u, v, (j == 0 && !P::F9) ? nullptr : &tw[j << twshift]);
+        lds[m] = u; lds[m + half] = v;
+        __syncthreads();
+    }
+    for (int e = tid; e < N; e += HALF) {
+        const size_t idx = base + ((size_t)e << logS);
+        E v = lds[e];
+        if (postmul) v = P::mul(v, postmul[idx]);
+        data[idx * B + b] = P::store(v, last != 0);
+    }
+}
+template <class P, int K>
+__global__ __launch_bounds__(1 << (K > 1 ? K - 1 : 0)) void k_ntt_dit_small(Fr *__restrict__ data, size_t B, int logn, int logS, const Fr *__restrict__ tw,
+                                                                           const Fr *__restrict__ premul, int last) {
+    using E = typename P::E;
+    constexpr int N = 1 << K, HALF = N / 2 ? N / 2 : 1;
+    __shared__ E lds[N];
+    const int tid = threadIdx.x;
+    const size_t g = blockIdx.x, b = blockIdx.y;
+    const size_t S = (size_t)1 << logS;
+    const size_t blk = g >> logS, p = g & (S - 1);
+    const size_t base = (blk << (logS + K)) + p;
+    for (int e = tid; e < N; e += HALF) {
+        const size_t idx = base + ((size_t)e << logS);
+        E v = P::load(data[idx * B + b]);
+        if (premul) v = P::mul(v, premul[idx]);
+        lds[e] = v;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int st = 0; st < K; st++) {
+        const int h = 1 << st;
+        const int m = ((tid >> st) << (st + 1)) | (tid & (h - 1));
+        const size_t j = p + ((size_t)(m & (h - 1)) << logS);
+        const int twshift = logn - (logS + st + 1);
+        E u = lds[m], v = lds[m + h];
+        P::dit(u, v, (j == 0 && !P::F9) ? nullptr : &tw[j << twshift]);
+        lds[m] = u; lds[m + h] = v;
+        __syncthreads();
+    }
+    for (int e = tid; e < N; e += HALF) data[(base + ((size_t)e << logS)) * B + b] = P::store(lds[e], last != 0);
+}
+static constexpr size_t NTT_SMALL_B = 16;
+static constexpr int NTT_SMALL_K = 9;           // stages per small-batch pass: 512 elements = 16 KiB of LDS, 256 threads
+template <class P, int K>
+static void launch_dif_small(Fr *data, size_t B, int logn, int loglen, const Fr *tw, const Fr *postmul, bool last, hipStream_t s) {
+    hipLaunchKernelGGL((k_ntt_dif_small<P, K>), dim3((unsigned)(((size_t)1 << logn) >> K), (unsigned)B), dim3(K > 1 ? 1 << (K - 1) : 1), 0, s, data, B, logn, loglen, tw,
+                       postmul, (int)last);
+}
+template <class P, int K>
+static void launch_dit_small(Fr *data, size_t B, int logn, int logS, const Fr *tw, const Fr *premul, bool last, hipStream_t s) {
+    hipLaunchKernelGGL((k_ntt_dit_small<P, K>), dim3((unsigned)(((size_t)1 << logn) >> K), (unsigned)B), dim3(K > 1 ? 1 << (K - 1) : 1), 0, s, data, B, logn, logS, tw,
+                       premul, (int)last);
+}
+// balanced split of the stages into passes of at most NTT_SMALL_K
+static int next_small_pass(int rem) {
+    const int passes = (rem + NTT_SMALL_K - 1) / NTT_SMALL_K;
+    return (rem + passes - 1) / passes;
+}
+template <class P>
+static void dif_passes_small(int logn, Fr *data, size_t B, const Fr *tw, const Fr *postmul, hipStream_t s) {
+    int loglen = logn;
+    while (loglen > 0) {
+        const int k = next_small_pass(loglen);
+        const bool last = loglen - k == 0;
+        const Fr *pm = last ? postmul : nullptr;
+        switch (k) {
+            case 9: launch_dif_small<P, 9>(data, B, logn, loglen, tw, pm, last, s); break;
+            case 8: launch_dif_small<P, 8>(data, B, logn, loglen, tw, pm, last, s); break;
+            case 7: launch_dif_small<P, 7>(data, B, logn, loglen, tw, pm, last, s); break;
+            case 6: launch_dif_small<P, 6>(data, B, logn, loglen, tw, pm, last, s); break;
+            case 5: launch_dif_small<P, 5>(data, B, logn, loglen, tw, pm, last, s); break;
+            case 4: launch_dif_small<P, 4>(data, B, logn, loglen, tw, pm, last, s); break;
+            case 3: launch_dif_small<P, 3>(data, B, logn, loglen, tw, pm, last, s); break;
+            case 2: launch_dif_small<P, 2>(data, B, logn, loglen, tw, pm, last, s); break;
+            default: launch_dif_small<P, 1>(data, B, logn, loglen, tw, pm, last, s); break;
+        }
+        loglen -= k;
+    }
+}
+template <class P>
+static void dit_passes_small(int logn, Fr *data, size_t B, const Fr *tw, const Fr *premul, hipStream_t s) {
+    int logS = 0;
+    while (logS < logn) {
+        const int k = next_small_pass(logn - logS);
+        const Fr *pm = (logS == 0) ? premul : nullptr;
+        const bool last = logS + k == logn;
+        switch (k) {
+            case 9: launch_dit_small<P, 9>(data, B, logn, logS, tw, pm, last, s); break;
+            case 8: launch_dit_small<P, 8>(data, B, logn, logS, tw, pm, last, s); break;
+            case 7: launch_dit_small<P, 7>(data, B, logn, logS, tw, pm, last, s); break;
+            case 6: launch_dit_small<P, 6>(data, B, logn, logS, tw, pm, last, s); break;
+            case 5: launch_dit_small<P, 5>(data, B, logn, logS, tw, pm, last, s); break;
+            case 4: launch_dit_small<P, 4>(data, B, logn, logS, tw, pm, last, s); break;
+            case 3: launch_dit_small<P, 3>(data, B, logn, logS, tw, pm, last, s); break;
+            case 2: launch_dit_small<P, 2>(data, B, logn, logS, tw, pm, last, s); break;
+            default: launch_dit_small<P, 1>(data, B, logn, logS, tw, pm, last, s); break;
+        }
+        logS += k;
+    }
+}
+
 // the multiplier tables of the 9-limb butterflies: same values in the 2^261-Montgomery form
 const Fr *NttDomain::table9(const Fr *t) const {
     if (t == nullptr) return nullptr;
@@ -777,7 +906,8 @@ void NttDomain::dif(Fr *data, size_t B, bool inverse, const Fr *postmul, hipStre
         return;
     }
 #endif
-    dif_passes<NttWords>(logn, data, B, tw, postmul, s);
+    if (B <= NTT_SMALL_B) dif_passes_small<NttWords>(logn, data, B, tw, postmul, s);
+    else dif_passes<NttWords>(logn, data, B, tw, postmul, s);
     ZK_HIP(hipGetLastError());
 }
 void NttDomain::dit(Fr *data, size_t B, bool inverse, const Fr *premul, hipStream_t s) const {
@@ -792,7 +922,8 @@ void NttDomain::dit(Fr *data, size_t B, bool inverse, const Fr *premul, hipStrea
         return;
     }
 #endif
-    dit_passes<NttWords>(logn, data, B, tw, premul, s);
+    if (B <= NTT_SMALL_B) dit_passes_small<NttWords>(logn, data, B, tw, premul, s);
+    else dit_passes<NttWords>(logn, data, B, tw, premul, s);
     ZK_HIP(hipGetLastError());
 }
 
