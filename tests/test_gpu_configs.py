@@ -100,8 +100,9 @@ def test_config3_aes256_full_size_batch_every_proof_verifies(zk, oracle):
 
 @pytest.mark.parametrize("alg,B", [(0, 128), (1, 128)])
 def test_pipelined_steps_rotate_working_sets_and_list_copies(zk, oracle, alg, B):
-    """resident_prove_pipelined (csrc/prover.hip) prepares batches two ahead: three working sets, two copies of the quotient MSM's sorted
-    list, solve / transforms / sort of later batches beside the MSMs of earlier ones.  Seven steps take every set and both list copies
+    """resident_prove_pipelined (csrc/prover.hip) prepares batches two ahead: three working sets, two copies of the quotient MSM's ahead-prepared
+    data (comb patterns by default at this batch size -- and, for AES-128, the wire combs after their calibration solve; the sorted bucket list
+    in the ZKPROVE_COMB=0 re-run below), solve / transforms / patterns of later batches beside the MSMs of earlier ones.  Seven steps take every set and both list copies
     through at least two rounds; every step proves the same resident inputs, so the last batch must be byte-identical to ONE
     unpipelined step (which uses none of that machinery) -- and instance 0 to the oracle."""
     _fresh(zk, alg)
@@ -235,6 +236,15 @@ def test_verify_batch_on_the_gpu_agrees_with_verify(zk, oracle, alg, B):
     assert zk.verify_batch_raw(json.dumps(mixed).encode()) == [True, False, False, True, False] + [True] * 18
     assert zk.verify_batch_raw(b"[]") == [] and zk.verify_batch_raw(b"{") == []
     zk.lib.ZkpReset()
+
+def test_bucket_pipeline_of_large_batches_stays_bit_exact():
+    """Batches of 128 and more take the comb path by default (csrc/msm_comb.hip); the sort -> bucket walk -> reduction pipeline with its
+    ahead-sorted, double-buffered entry lists remains the product's path when the tables do not fit (and under ZKPROVE_COMB=0), so the
+    pipelined-steps test above is repeated with the comb switched off (own process: the switch is read once)."""
+    env = dict(os.environ, ZKPROVE_COMB="0")
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k", "pipelined_steps_rotate", "-p", "no:cacheprovider"],
+                         env=env, capture_output=True, text=True, timeout=1200, cwd=H.ROOT)
+    assert res.returncode == 0 and " passed" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
 
 _SHARD_SCRIPT = r"""
 import base64, importlib, json, os, sys, threading

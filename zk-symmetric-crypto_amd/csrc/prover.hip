@@ -457,7 +457,8 @@ __global__ __launch_bounds__(64) void k_bsb22_challenge(const G1Affine *__restri
 }
 
 // ---------------------------------------------------------------------------- comb quotient MSM (msm_comb.hip)
-// Table build is triggered by the first batch of >= comb_min_batch() proofs; once the tables exist every batch that fills whole
+// Table build is triggered by the first batch of >= comb_min_batch() proofs (128: from there on the comb beats the bucket pipeline --
+// 6 465 vs 5 694 proofs/s at B = 128, 8 343 vs 6 734 at 256, 9 819 vs 7 474 at 512, equal at 96; scripts/debug/batch_sweep.sh); once the tables exist every batch that fills whole
 // wavefronts (B > SIDE_G2_MAX_B) takes the comb path.  ZKPROVE_COMB=0 keeps the bucket pipeline (A/B runs), ZKPROVE_COMB_K fixes the
 // clump size (default: the largest k <= 19 whose table fits 30 % of the free device memory), ZKPROVE_COMB_MIN_BATCH the trigger.
 static bool comb_enabled() {
@@ -465,7 +466,7 @@ static bool comb_enabled() {
     return on;
 }
 static size_t comb_min_batch() {
-    static const size_t v = [] { const char *e = getenv("ZKPROVE_COMB_MIN_BATCH"); return e ? (size_t)atol(e) : (size_t)256; }();
+    static const size_t v = [] { const char *e = getenv("ZKPROVE_COMB_MIN_BATCH"); return e ? (size_t)atol(e) : (size_t)128; }();
     return v;
 }
 // Largest clump size whose table fits the budget.  The budget has two sides: a fixed share of the device (0.21 of its memory -- the k = 19
