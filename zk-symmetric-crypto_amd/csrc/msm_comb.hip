@@ -423,6 +423,27 @@ __global__ __launch_bounds__(64, ZK_COMB_BOUNDS(F)) void k_comb_fold2(const type
 // clump ranges per (proof, plane): 8 at a full batch; more when the batch or the plane count is small (so that the walk still has
 // ~1 M threads), but never so many that a thread walks fewer than ~24 clumps -- the fold adds the Q range accumulators of a plane
 // one after the other, and with few clumps (the wire combs: 50 .. 400) a large Q turns the fold into the longer kernel
+// both fold stages in one launch for the narrow width classes of the wire combs (T = 8 / 32 planes: at most 32 doublings per proof):
+// thread b: Horner over ALL planes, each plane the sum of its Q range accumulators, + the constant
+template <class F>
+__global__ __launch_bounds__(64, ZK_COMB_BOUNDS(F)) void k_comb_fold_narrow(const typename Nine<F>::X9 *__restrict__ acc, size_t B, int T, uint32_t Q,
+                                                                           const Affine<F> *__restrict__ corr, XYZZ<F> *__restrict__ out, size_t out_stride) {
+    using F9 = typename Nine<F>::F9;
+    using X9 = typename Nine<F>::X9;
+    const size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    X9 r = X9::inf();
+#pragma unroll 1
+    for (int t = T - 1; t >= 0; t--) {
+        r = X9::dbl_of(r);
+#pragma unroll 1
+        for (uint32_t q = 0; q < Q; q++) r.add(acc[((size_t)q * T + t) * B + b]);
+    }
+    const Affine<F> c = corr[0];
+    if (!c.is_inf()) r.madd(F9::from_words(c.x), F9::from_words(c.y));
+    out[b * out_stride] = r.to_xyzz();
+}
+
 static uint32_t comb_ranges(size_t B, size_t nclumps, int T) {
     static const uint32_t forced = [] { const char *e = getenv("ZKPROVE_COMB_Q"); return e ? (uint32_t)atoi(e) : 0u; }();
     uint32_t Q = forced ? forced : 8;
@@ -489,6 +510,11 @@ static void comb_fold_impl(const CombBasesT<F> &cb, size_t B, CombScratch &sc, X
     const int groups = fold_groups(cb.T);
     const size_t tiles = (B + 63) / 64;
     X9 *acc = reinterpret_cast<X9 *>(sc.acc.p), *r1 = reinterpret_cast<X9 *>(sc.r1.p);
+    if (cb.T <= 32) {
+        hipLaunchKernelGGL(k_comb_fold_narrow<F>, dim3((unsigned)tiles), dim3(64), 0, s, acc, B, cb.T, Q, cb.corr.p, out, out_stride);
+        ZK_HIP(hipGetLastError());
+        return;
+    }
     hipLaunchKernelGGL(k_comb_fold1<F>, dim3((unsigned)(tiles * groups)), dim3(64), 0, s, acc, B, cb.T, Q, r1);
     hipLaunchKernelGGL(k_comb_fold2<F>, dim3((unsigned)tiles), dim3(64), 0, s, r1, B, groups, cb.corr.p, out, out_stride);
     ZK_HIP(hipGetLastError());
