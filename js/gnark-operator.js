@@ -151,6 +151,29 @@ function makeGnarkZkOperator(opts) {
 			})
 			return lib.addon.verify(verifyParams) === true
 		},
+		/**
+		 * N (publicSignals, proof) pairs -> N booleans, one library call: the proofs of a circuit are checked together on the GPU
+		 * (`VerifyBatch`: one pairing-product equation under random coefficients; a batch that fails is re-checked proof by proof),
+		 * element i equals groth16Verify(items[i].publicSignals, items[i].proof)
+		 */
+		async groth16VerifyBatch(items, logger) {
+			const lib = await initGnark(algorithm, fetcher, logger, opts)
+			if(!lib.caps.batchVerifier) {
+				return Promise.all(items.map(it => this.groth16Verify(it.publicSignals, it.proof, logger)))
+			}
+
+			const body = JSON.stringify(items.map(it => ({
+				cipher: algorithm,
+				proof: typeof it.proof === 'string' ? it.proof : b64(it.proof),
+				publicSignals: generateGnarkWitness(algorithm, it.publicSignals)
+			})))
+			const out = JSON.parse((await lib.addon.verifyBatchAsync(Buffer.from(body))).toString())
+			if(!Array.isArray(out) || out.length !== items.length) {
+				throw new Error(`Failed to verify gnark proofs: ${JSON.stringify(out)}`)
+			}
+
+			return out.map(v => v === true)
+		},
 	}
 }
 

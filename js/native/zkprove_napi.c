@@ -30,7 +30,7 @@ typedef const char *(*fn_err_t)(void);
 static struct {
     void *h;
     fn_init_t init;
-    fn_prove_t prove, prove_batch;
+    fn_prove_t prove, prove_batch, verify_batch;
     fn_free_t free_, vfree;
     fn_verify_t verify;
     fn_initvk_t init_vk;
@@ -98,6 +98,7 @@ static napi_value js_open(napi_env env, napi_callback_info info) {
     L.verify = (fn_verify_t)sym("Verify");
     L.vfree = (fn_free_t)sym("VFree");
     L.prove_batch = (fn_prove_t)sym("ProveBatch");
+    L.verify_batch = (fn_prove_t)sym("VerifyBatch");
     L.init_vk = (fn_initvk_t)sym("ZkpInitVerifier");
     L.allow = (fn_allow_t)sym("ZkpAllowUnpinnedKeys");
     L.setup = (fn_setup_t)sym("ZkpSetup");
@@ -109,6 +110,8 @@ static napi_value js_open(napi_env env, napi_callback_info info) {
     CHECK(env, napi_set_named_property(env, out, "extensions", b));
     CHECK(env, napi_get_boolean(env, L.verify != NULL, &b));
     CHECK(env, napi_set_named_property(env, out, "verifier", b));
+    CHECK(env, napi_get_boolean(env, L.verify_batch != NULL, &b));
+    CHECK(env, napi_set_named_property(env, out, "batchVerifier", b));
     return out;
 }
 
@@ -212,6 +215,9 @@ static napi_value call_json_async(napi_env env, napi_callback_info info, fn_prov
 }
 static napi_value js_prove_async(napi_env env, napi_callback_info info) { return call_json_async(env, info, L.prove, "library not opened"); }
 static napi_value js_prove_batch_async(napi_env env, napi_callback_info info) { return call_json_async(env, info, L.prove_batch, "library has no ProveBatch"); }
+/* verifyBatchAsync(jsonArrayOfVerifyRequests) -> Promise<Buffer> holding a JSON array of booleans (the library's result is released with
+ * Free, which is the same free() as VFree) */
+static napi_value js_verify_batch_async(napi_env env, napi_callback_info info) { return call_json_async(env, info, L.verify_batch, "library has no VerifyBatch"); }
 
 /* verify(params) -> bool */
 static napi_value js_verify(napi_env env, napi_callback_info info) {
@@ -292,7 +298,7 @@ static napi_value js_setup(napi_env env, napi_callback_info info) {
 static napi_value module_init(napi_env env, napi_value exports) {
     static const struct { const char *name; napi_callback fn; } fns[] = {
         {"open", js_open}, {"initAlgorithm", js_init}, {"prove", js_prove}, {"proveBatch", js_prove_batch},
-        {"proveAsync", js_prove_async}, {"proveBatchAsync", js_prove_batch_async}, {"verify", js_verify},
+        {"proveAsync", js_prove_async}, {"proveBatchAsync", js_prove_batch_async}, {"verifyBatchAsync", js_verify_batch_async}, {"verify", js_verify},
         {"initVerifier", js_init_vk}, {"allowUnpinnedKeys", js_allow}, {"setup", js_setup},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {

@@ -98,6 +98,9 @@ def test_operator_proves_and_verifies_through_node(zk, oracle, tmp_path):
     r = _run_node([os.path.join("test", "run_operator.js"), "prove", d], env={"UV_THREADPOOL_SIZE": "16"})
     assert "error" not in r, r.get("error")
     assert r["okSingle"] is True and r["okBatch"] == [True] * 16 and r["okTampered"] is False
+    # groth16VerifyBatch (VerifyBatch through the addon): 16 proofs = one GPU batch check; with member 1 under member 0's public signals
+    # the batch check fails and the per-proof fallback answers exactly as groth16Verify would
+    assert r["okVerifyBatch"] == [True] * 16 and r["okVerifyBatchTampered"] == [k != 1 for k in range(16)]
     assert r["okConcurrent"] == [True] * 16          # Promise.all over groth16Prove: coalesced into device batches by the library
     print("node: single %d ms, batch of 16 %d ms, Promise.all of 16 single calls %d ms (libuv pool %s)" % (r["msSingle"], r["msBatch"], r["msConcurrent"], r["poolSize"]))
     assert r["badErr"] == 'Failed to create gnark proof: "key length must be 32: 3"'       # operator.ts:26-30 over provers.go:120-133
