@@ -54,9 +54,9 @@ def test_addon_builds_loads_and_reports_library_errors():
               "unknown:a.prove('{\"cipher\":\"nope\"}').toString(),verify:a.verify('{}')};"
               "process.stdout.write('\\nRESULT '+JSON.stringify(r)+'\\n')")
     r = _run_node(["-e", script, os.path.join(ROOT, "zk-symmetric-crypto_amd", "libzkprove.so")])
-    assert r["keys"] == sorted(["open", "initAlgorithm", "prove", "proveBatch", "proveAsync", "proveBatchAsync", "verify", "initVerifier",
+    assert r["keys"] == sorted(["open", "initAlgorithm", "prove", "proveBatch", "proveAsync", "proveBatchAsync", "verifyBatchAsync", "verify", "initVerifier",
                                 "allowUnpinnedKeys", "setup"])
-    assert r["caps"] == {"extensions": True, "verifier": True}
+    assert r["caps"] == {"extensions": True, "verifier": True, "batchVerifier": True}
     assert r["init"] is False                                   # garbage r1cs: hash pin mismatch, as the reference (library.go:111-118)
     assert json.loads(r["prove"]) == "proving params are not initialized for cipher: chacha20"
     assert json.loads(r["unknown"]) == "could not find prover fornope"
