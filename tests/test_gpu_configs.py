@@ -246,6 +246,50 @@ def test_bucket_pipeline_of_large_batches_stays_bit_exact():
                          env=env, capture_output=True, text=True, timeout=1200, cwd=H.ROOT)
     assert res.returncode == 0 and " passed" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
 
+_VALVE_SCRIPT = r"""
+import importlib, json, os, sys
+import numpy as np
+import torch
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+zk = importlib.import_module("zk-symmetric-crypto_amd")
+import helpers as H
+from oracle import ref
+zk.lib.ZkpAllowUnpinnedKeys(1)
+alg, B = 0, 256
+r1cs = zk.synth.r1cs_bytes(alg)
+pk, vk = zk.setup(r1cs, ref.toxic_from_seed(1), raw=True)
+assert zk.init_algorithm(alg, pk, r1cs)
+rng = H.SplitMix64(0x5EED0000 + 55)
+insts = [H.make_instance(alg, rng) for _ in range(B)]
+wits = np.array([zk.request_witness(H.request_json(alg, i))[1] for i in insts], np.uint32)
+rb = zk.ResidentBatch(alg, wits, [i["r"] for i in insts], [i["s"] for i in insts], [0] * B)      # reserves one working set and builds the comb tables
+info = np.zeros(8, np.int64)
+zk.lib.zkp_quotient_msm_info(alg, info.ctypes.data)
+had_comb, table_mib = int(info[0]), int(info[3])
+rb.step()
+single, errs = rb.fetch()
+assert not errs.any()
+# take (almost) all the memory that is left: the second and third working set of the pipelined entry cannot be allocated any more
+free_b, total_b = torch.cuda.mem_get_info()
+hog = torch.empty(max(0, free_b - (1 << 30)), dtype=torch.uint8, device="cuda")
+rb.steps(4)
+got, errs = rb.fetch()
+zk.lib.zkp_quotient_msm_info(alg, info.ctypes.data)
+print(json.dumps(dict(had_comb=had_comb, table_mib=table_mib, comb_after=int(info[0]), same=bool(np.array_equal(got, single)), ok=bool(not errs.any()), hog_gib=hog.numel() >> 30)))
+"""
+
+
+def test_comb_tables_are_given_back_under_memory_pressure():
+    """The comb tables are an optimisation, the working sets are not: when the pipelined entry cannot allocate its further working sets
+    because the device is full (here: a tensor of the host application takes what is left), the algorithm releases its comb tables
+    (prover.hip, comb_release), continues on the table-free bucket pipeline and produces the same proofs."""
+    res = subprocess.run([sys.executable, "-c", _VALVE_SCRIPT.format(root=H.ROOT)], capture_output=True, text=True, timeout=1200)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["had_comb"] == 1 and out["table_mib"] > 1000, out
+    assert out["comb_after"] == 0 and out["same"] and out["ok"], out
+    assert "comb tables" in res.stderr and "released" in res.stderr
+
 _SHARD_SCRIPT = r"""
 import base64, importlib, json, os, sys, threading
 sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))

@@ -39,8 +39,8 @@ struct DevBuf {
     ~DevBuf() { release(); }
     void alloc(size_t count) {
         release();
+        if (count) ZK_HIP(hipMalloc((void **)&p, count * sizeof(T)));      // throws on failure with the buffer left empty (n = 0)
         n = count;
-        if (count) ZK_HIP(hipMalloc((void **)&p, count * sizeof(T)));
     }
     void ensure(size_t count) { if (count > n) alloc(count); }
     void release() {

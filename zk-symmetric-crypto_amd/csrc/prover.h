@@ -104,7 +104,10 @@ class Algorithm {
     void debug_leftovers(long *out3);                       // {sum, max, instances with any} of the compact bucket-pipeline list left by the last main-stream wire MSM
     size_t resident_batch() const;                          // instances of the current resident batch (0: none)
     bool comb_active() const;                               // the current resident batch takes the comb path for its quotient MSM
-    void comb_prepare(size_t B);                            // lazy table build + scratch (resident_reserve)
+    void comb_prepare(size_t B);
+    bool comb_drop_tables();
+    void resident_reserve_buffers(size_t B);
+    bool comb_release();                                    // out of memory: give the comb tables back, continue on the bucket pipeline                            // lazy table build + scratch (resident_reserve)
     void enqueue_ntt_sort(struct SolveSet &S, hipStream_t sn, int slot, hipEvent_t slot_free = nullptr);
     void enqueue_tail_early(struct SolveSet &S, hipStream_t st);
     void enqueue_finalize(struct SolveSet &S, hipStream_t st);

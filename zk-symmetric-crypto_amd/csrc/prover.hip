@@ -637,6 +637,18 @@ void Algorithm::resident_reserve(size_t B) {
         for (auto &e : res->ev) ZK_HIP(hipEventCreate(&e));
     }
     Resident &R = *res;
+    const size_t cap_before = R.cap;
+    try {
+        resident_reserve_buffers(B);
+    } catch (const ZkError &) {
+        (void)hipGetLastError();
+        R.cap = cap_before;
+        if (!comb_drop_tables()) throw;             // memory-pressure valve, see comb_release
+        resident_reserve_buffers(B);
+    }
+}
+void Algorithm::resident_reserve_buffers(size_t B) {
+    Resident &R = *res;
     R.B = B;
     if (B > R.cap) {
         R.cap = B;
@@ -992,12 +1004,42 @@ void Algorithm::resident_prove(PhaseTimes *times) {
     }
 }
 
+// Memory-pressure valve: the comb tables are an optimisation, the working sets are not.  When a working-set allocation fails while this
+// algorithm holds comb tables (a third circuit with large batches on the same GPU), the tables and their scratch are given back and the
+// quotient / wire MSMs of this algorithm return to the table-free bucket pipeline.
+bool Algorithm::comb_drop_tables() {
+    if (!pk.Zcomb.ok && !wire_comb_on) return false;
+    Resident &R = *res;
+    ZK_HIP(hipDeviceSynchronize());
+    (void)hipGetLastError();
+    const size_t mib = pk.Zcomb.table.bytes() >> 20;
+    pk.Zcomb = CombBases();
+    R.comb = CombScratch();
+    R.comb_cap = 0;
+    for (MsmBasesG1 *mb : {&pk.A, &pk.B1, &pk.K, &pk.ped, &pk.ped_sigma}) { mb->wcomb.clear(); mb->wide_mask.release(); }
+    pk.B2.wcomb.clear(); pk.B2.wide_mask.release();
+    wire_comb_on = false;
+    fprintf(stderr, "zkprove: out of device memory: comb tables (%zu MiB) released, this algorithm continues on the bucket pipeline\n", mib);
+    return true;
+}
+bool Algorithm::comb_release() {
+    if (!comb_drop_tables()) return false;
+    resident_reserve(res->cap);                    // the bucket pipeline's buffers for the reserved batch size
+    return true;
+}
+
 // the second working set (and the separate scratch of its commitment MSMs) exists only once a pipelined entry is used
 void Algorithm::ensure_second_set(int nsets) {
     Resident &R = *res;
     for (int i = 1; i < nsets; i++) {
         if (R.set[i].ready) continue;
-        R.set[i].reserve(prog, R.cap);
+        try {
+            R.set[i].reserve(prog, R.cap);
+        } catch (const ZkError &) {
+            (void)hipGetLastError();
+            if (!comb_release()) throw;
+            R.set[i].reserve(prog, R.cap);
+        }
         R.set[i].sb.B = R.B;
         SolveSet &a = R.set[0], &b = R.set[i];
         ZK_HIP(hipMemcpy(b.sb.inputs.p, a.sb.inputs.p, prog.n_inputs * R.B * sizeof(uint32_t), hipMemcpyDeviceToDevice));
