@@ -396,6 +396,67 @@ __global__ __launch_bounds__(64, sizeof(F) == 64 ? 2 : 4) void k_bench_madd9(typ
     }
     acc[i] = a;
 }
+// a radix-8 DIF butterfly group (3 stages, 12 butterflies) in registers, as the transform kernels run it: kind 11 on the 8 x 32 weak
+// form (ntt.hip, NttWords), kind 12 on 9 signed 29-bit limbs kept across stages (sum: limb-wise + one carry propagation, difference:
+// limb-wise, product: Field9::mul against a pre-limbed twiddle) -- the question is the ratio of their butterfly rates
+__global__ __launch_bounds__(256) void k_bench_bfly_words(Fr *x, const Fr *tw, int iters) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    Fr v[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) v[m] = x[i * 8 + m];
+    for (int k = 0; k < iters; k++) {
+#pragma unroll
+        for (int st = 0; st < 3; st++) {
+            const int half = 4 >> st;
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                if ((m / half) & 1) continue;
+                const Fr s = Fr::add_w(v[m], v[m + half]), d = Fr::sub_w(v[m], v[m + half]);
+                v[m] = s;
+                v[m + half] = Fr::mul_wc(d, tw[(k + st * 4 + (m % half)) & 63]);
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 8; m++) x[i * 8 + m] = v[m];
+}
+__device__ __noinline__ Fr9 bench_mul9_call(Fr9 a, Fr9 b) { return Fr9::mul(a, b); }
+template <bool CALL>
+__global__ __launch_bounds__(256) void k_bench_bfly_9(Fr *x, const Fr9 *tw, int iters) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    Fr9 v[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) v[m] = Fr9::from_words(x[i * 8 + m]);
+    for (int k = 0; k < iters; k++) {
+#pragma unroll
+        for (int st = 0; st < 3; st++) {
+            const int half = 4 >> st;
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                if ((m / half) & 1) continue;
+                const Fr9 s = Fr9::norm(Fr9::add(v[m], v[m + half])), d = Fr9::sub(v[m], v[m + half]);
+                v[m] = s;
+                const Fr9 t = tw[(k + st * 4 + (m % half)) & 63];
+                v[m + half] = CALL ? bench_mul9_call(d, t) : Fr9::mul(d, t);
+            }
+        }
+        // once per "pass" (here: per group) the sums are brought back near [0, M): top limb estimate, q * M subtracted
+        if ((k & 1) == 1) {
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                const int32_t q = v[m].l[8] >> 21;
+                int64_t c = 0;
+#pragma unroll
+                for (int j = 0; j < 9; j++) {
+                    c += (int64_t)v[m].l[j] - (int64_t)q * Fr9Params::M[j];
+                    if (j < 8) { v[m].l[j] = (int32_t)(c & 0x1fffffff); c >>= 29; } else v[m].l[j] = (int32_t)c;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 8; m++) x[i * 8 + m] = Fr9::to_words(Fr9::norm(v[m]));
+}
 __global__ __launch_bounds__(256) void k_bench_mad_i64(uint32_t *x, int iters) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     int32_t a = (int32_t)x[i], b = (int32_t)(x[i] * 2654435761u + 1u);
@@ -490,6 +551,21 @@ extern "C" double zkp_microbench(int kind, long threads, int iters) {
         hipLaunchKernelGGL(k_bench_mul9, dim3(T / 256), dim3(256), 0, 0, x.p, 4);
         ZK_HIP(hipEventRecord(e0, 0));
         hipLaunchKernelGGL(k_bench_mul9, dim3(T / 256), dim3(256), 0, 0, x.p, iters);
+        ZK_HIP(hipEventRecord(e1, 0));
+    } else if (kind == 11 || kind == 12 || kind == 13) {
+        DevBuf<Fr> x(T * 8);
+        std::vector<Fr> h(T * 8);
+        for (size_t i = 0; i < T * 8; i++) for (int k = 0; k < 8; k++) h[i].l[k] = (uint32_t)(i * 2654435761u + k * 40503u) & (k == 7 ? 0x0fffffffu : 0xffffffffu);
+        x.upload(h.data(), T * 8);
+        DevBuf<Fr> tw(64);
+        DevBuf<Fr9> tw9(64);
+        std::vector<Fr9> h9(64);
+        for (int i = 0; i < 64; i++) h9[i] = Fr9::from_words(h[i]);
+        tw.upload(h.data(), 64); tw9.upload(h9.data(), 64);
+        ZK_HIP(hipEventRecord(e0, 0));
+        if (kind == 11) hipLaunchKernelGGL(k_bench_bfly_words, dim3(T / 256), dim3(256), 0, 0, x.p, tw.p, iters);
+        else if (kind == 12) hipLaunchKernelGGL(k_bench_bfly_9<false>, dim3(T / 256), dim3(256), 0, 0, x.p, tw9.p, iters);
+        else hipLaunchKernelGGL(k_bench_bfly_9<true>, dim3(T / 256), dim3(256), 0, 0, x.p, tw9.p, iters);
         ZK_HIP(hipEventRecord(e1, 0));
     } else if (kind == 10) {
         DevBuf<uint32_t> x(T);
