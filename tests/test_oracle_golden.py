@@ -217,7 +217,7 @@ def test_pairing_bilinearity(oracle):
 
 
 # ---------------------------------------------------------------- formats decoded from the reference's artefacts
-@pytest.mark.parametrize("name,nk,nkeys,size", [("chacha20", 2305, 0, 74060), ("aes128", 227, 1, 7696)])
+@pytest.mark.parametrize("name,nk,nkeys,size", [("chacha20", 2305, 0, 74060), ("aes128", 227, 1, 7696), ("aes256", 227, 1, 7696)])
 def test_reference_verifying_keys_decode(name, nk, nkeys, size):
     # gnark/libraries/verifier/impl/generated/vk.* (committed as data fixtures)
     buf = open(os.path.join(H.ROOT, "tests", "golden", "vk." + name), "rb").read()

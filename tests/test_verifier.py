@@ -80,7 +80,7 @@ def test_verify_malformed_requests_return_false(zk):
 
 def test_reference_verifying_keys_load(zk):
     """the reference's own vk files (gnark/libraries/verifier/impl/generated/vk.*) decode: every point decompresses onto its curve"""
-    for alg, name in ((0, "chacha20"), (1, "aes128")):
+    for alg, name in ((0, "chacha20"), (1, "aes128")):          # (aes256: tests/test_oracle_golden.py; its slot stays free for the test below)
         buf = open(os.path.join(H.ROOT, "tests", "golden", "vk." + name), "rb").read()
         assert zk.init_verifier(alg, buf)
         assert not zk.init_verifier(alg, buf[:-3])
