@@ -246,6 +246,36 @@ def test_bucket_pipeline_of_large_batches_stays_bit_exact():
                          env=env, capture_output=True, text=True, timeout=1200, cwd=H.ROOT)
     assert res.returncode == 0 and " passed" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
 
+def test_streamed_prove_batch_answers_bad_members_in_place(zk, oracle):
+    """A streamed ProveBatch call (more than one device chunk) with bad members in different chunks: a request with a short key, one for
+    another cipher, one that is not an object and one with broken JSON answer exactly what Prove answers for them, at their positions;
+    every other request gets its proof (spot-verified) and its ciphertext."""
+    alg, n = 0, 2100
+    _fresh(zk, alg)
+    rng = H.SplitMix64(0x5EED0000 + 321)
+    insts = [H.make_instance(alg, rng) for _ in range(n)]
+    parts = [H.request_json(alg, i).decode() for i in insts]
+    short = json.loads(parts[100]); short["key"] = base64.b64encode(b"k" * 16).decode(); parts[100] = json.dumps(short)
+    other = json.loads(parts[1500]); other["cipher"] = "aes-128-ctr"; parts[1500] = json.dumps(other)
+    parts[1024] = "17"
+    parts[2050] = '{"cipher" "chacha20"}'
+    body = ("[" + ",".join(parts) + "]").encode()
+    res = json.loads(zk.prove_batch_raw(body))
+    assert len(res) == n
+    assert res[100] == json.loads(zk.prove_raw(parts[100].encode())) == "key length must be 32: 16"
+    assert res[1500] == json.loads(zk.prove_raw(parts[1500].encode())) == "proving params are not initialized for cipher: aes-128-ctr"
+    assert res[1024] == {} and res[2050] == {"Offset": body.index(b'{"cipher" "chacha20"}') + 11}
+    bad = {100, 1024, 1500, 2050}
+    for k in range(n):
+        if k in bad:
+            continue
+        assert isinstance(res[k], dict) and "proof" in res[k], (k, res[k])
+    for k in (0, 99, 101, 1023, 1025, 1499, 1501, 2049, 2051, n - 1):
+        out = zk.request_witness(parts[k].encode())[2]
+        assert base64.b64decode(res[k]["ciphertext"]) == out
+        assert zk.verify("chacha20", base64.b64decode(res[k]["proof"]), out, list(zip(insts[k]["nonces"], insts[k]["counters"])), insts[k]["data"])
+    zk.lib.ZkpReset()
+
 _VALVE_SCRIPT = r"""
 import importlib, json, os, sys
 import numpy as np
