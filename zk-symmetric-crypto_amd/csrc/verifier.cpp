@@ -15,6 +15,7 @@
 #include "hostutil.h"
 #include "common.h"
 #include "kernels.h"
+#include "g2_subgroup.cuh"
 
 namespace zk {
 namespace {
@@ -236,10 +237,7 @@ struct Cur {
         if (!g2_on_curve(r)) throw ZkError("G2 point not on curve");
         // the twist has cofactor 2p - r: gnark-crypto's G2Affine.SetBytes (proof.ReadFrom, the embedded vk) also rejects points
         // outside the order-r subgroup, and the Miller loop below is only a pairing on it
-        if (!r.is_inf()) {
-            U256 rr = FR_MODULUS;
-            if (!scalar_mul(r, rr.l, 254).is_inf()) throw ZkError("G2 point not in the order-r subgroup");
-        }
+        if (!g2_in_subgroup(r)) throw ZkError("G2 point not in the order-r subgroup");
         return r;
     }
 };
