@@ -276,6 +276,33 @@ def test_streamed_prove_batch_answers_bad_members_in_place(zk, oracle):
         assert zk.verify("chacha20", base64.b64decode(res[k]["proof"]), out, list(zip(insts[k]["nonces"], insts[k]["counters"])), insts[k]["data"])
     zk.lib.ZkpReset()
 
+@pytest.mark.parametrize("alg", [0, 1])
+def test_comb_paths_under_another_proving_key(zk, oracle, alg):
+    """The comb tables (quotient bases; for AES also the calibrated wire positions of six base sets) are functions of the proving key.
+    Everything above uses the key of toxic seed 1; here a key of seed 2 at the smallest batch that takes the comb paths (130 > 128):
+    instances 0, 64 and 129 bit-identical to the oracle under ITS seed-2 key, the whole batch accepted by VerifyBatch."""
+    B = 130
+    _fresh(zk, alg, seed=2)
+    rng = H.SplitMix64(0x5EED0000 + 400 + alg)
+    insts = [H.make_instance(alg, rng) for _ in range(B)]
+    wits, outs = [], []
+    for inst in insts:
+        _, w, out = zk.request_witness(H.request_json(alg, inst))
+        wits.append(w); outs.append(out)
+    rb = zk.ResidentBatch(alg, np.array(wits, np.uint32), [i["r"] for i in insts], [i["s"] for i in insts], [i["randomize"] for i in insts])
+    rb.steps(3)
+    proofs, errs = rb.fetch()
+    assert not errs.any()
+    info = np.zeros(8, np.int64)
+    assert zk.lib.zkp_quotient_msm_info(alg, info.ctypes.data) == 0 and info[0] == 1 and (alg == 0 or info[5] == 1), info
+    ser = [zk.proof_serialize(proofs[k], alg != 0) for k in range(B)]
+    for k in (0, 64, B - 1):
+        exp, out, *_ = H.oracle_proof_bytes(alg, insts[k], seed=2)
+        assert ser[k] == exp and outs[k] == out, k
+    reqs = [zk.verify_request(H.CIPHER[alg], ser[k], outs[k], list(zip(insts[k]["nonces"], insts[k]["counters"])), insts[k]["data"]) for k in range(B)]
+    assert zk.verify_batch_raw(json.dumps(reqs).encode()) == [True] * B
+    zk.lib.ZkpReset()
+
 _VALVE_SCRIPT = r"""
 import importlib, json, os, sys
 import numpy as np
