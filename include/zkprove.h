@@ -141,8 +141,10 @@ const char *zkp_last_error(void);
 int zkp_device_count(void);
 /* data: [batch][2^logn][32] canonical LE; mode 0 fwd (DIF kernels) 1 inv (DIF) 2 fwd (DIT) 3 inv (DIT) */
 int zkp_ntt(int logn, long batch, uint8_t *data, int mode);
+#ifdef ZK_EXPERIMENTS   /* only in libzkprove_exp.so (make experiments): gnark's unfolded 7-transform computeH, which the product does not run */
 /* computeH: a,b,c [batch][ncons][32] -> h [batch][2^logn][32] (natural coefficient order) */
 int zkp_compute_h(int logn, long batch, long ncons, const uint8_t *a, const uint8_t *b, const uint8_t *c, uint8_t *h_out);
+#endif
 /* points n*64 (G1: x|y) / n*128 (G2: x.a0|x.a1|y.a0|y.a1) canonical LE; scalars [batch][n][32]; c = window bits */
 int zkp_msm_g1(long n, long batch, const uint8_t *points, const uint8_t *scalars, uint8_t *out, int c);
 int zkp_msm_g2(long n, long batch, const uint8_t *points, const uint8_t *scalars, uint8_t *out, int c);

@@ -30,6 +30,11 @@ def test_ntt_matches_oracle(zk, oracle, logn, batch, mode):
 
 @pytest.mark.parametrize("logn,ncons,batch", [(4, 11, 3), (10, 1000, 64), (12, 4096, 2)])
 def test_compute_h_matches_oracle(zk, oracle, logn, ncons, batch):
+    """gnark's unfolded computeH (7 transforms + pointwise quotient).  The product runs the folded form (4 transforms; pinned through
+    f = D*H + C in tests/test_gpu_prove.py), so this entry exists in the experiments build only: the test runs through
+    test_alternative_field_paths_stay_bit_exact (libzkprove_exp.so) and is skipped on the product library."""
+    if getattr(zk.lib, "zkp_compute_h", None) is None:
+        pytest.skip("zkp_compute_h is built with -DZK_EXPERIMENTS only")
     rng = np.random.default_rng(7 + logn)
     n = 1 << logn
     a = np.stack([_rand_fr(rng, ncons) for _ in range(batch)])
@@ -414,8 +419,9 @@ def test_msm_doubling_and_cancellation_inside_a_bucket(zk, oracle, group):
 
 @pytest.mark.parametrize("env,select", [
     ({"ZKPROVE_NTT_F9": "1"}, "test_ntt_matches_oracle or test_compute_h_matches_oracle or test_full_size_ntt"),
+    ({"ZKPROVE_NTT_EIGHT": "1"}, "test_ntt_matches_oracle or test_compute_h_matches_oracle"),
     ({"ZKPROVE_MSM_F9": "0"}, "test_msm_g1_matches_oracle or test_msm_g2_matches_oracle or doubling"),
-], ids=["transforms_9limb", "buckets_8x32"])
+], ids=["transforms_9limb", "transforms_two_pass_and_unfolded_compute_h", "buckets_8x32"])
 def test_alternative_field_paths_stay_bit_exact(env, select):
     """The alternatives that were measured and lost -- the 9-limb butterflies of the transforms (ZKPROVE_NTT_F9=1, csrc/ntt.hip), the
     bucket kernels on the 8 x 32 field (ZKPROVE_MSM_F9=0) and the batch-affine tree (ZKPROVE_MSM_TREE=1) -- are not in the product

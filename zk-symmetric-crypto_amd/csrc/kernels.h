@@ -19,7 +19,9 @@ struct NttDomain {
     // data layout [n][B]; see ntt.hip
     void dif(Fr *data, size_t B, bool inverse, const Fr *postmul, hipStream_t s) const;
     void dit(Fr *data, size_t B, bool inverse, const Fr *premul, hipStream_t s) const;
+#ifdef ZK_EXPERIMENTS
     void compute_h(Fr *a, Fr *b, Fr *c, size_t B, hipStream_t s) const;
+#endif
     // a, b (per-constraint values) -> evaluations of their interpolants on the coset g<w>, natural order
     void to_coset(Fr *a, Fr *b, size_t B, hipStream_t s) const;
     void scale_ninv(Fr *a, size_t B, hipStream_t s) const;

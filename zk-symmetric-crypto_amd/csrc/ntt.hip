@@ -16,7 +16,7 @@
 // Like gnark we never run a bit-reversal pass: inverse transforms are DIF (natural in, bit-reversed
 // out), forward transforms are DIT (bit-reversed in, natural out).  The prover only runs the pair
 // inverse + coset-forward on a and b (to_coset); the rest of computeH lives in the folded key (keyfold.hip).
-// compute_h (all 7 transforms) is kept as the kernel-level entry point zkp_compute_h for parity tests.
+// compute_h (all 7 transforms) is kept as the kernel-level entry point zkp_compute_h of the experiments build (-DZK_EXPERIMENTS) for parity tests.
 #include "kernels.h"
 #include "field9.cuh"
 
@@ -927,6 +927,7 @@ void NttDomain::dit(Fr *data, size_t B, bool inverse, const Fr *premul, hipStrea
     ZK_HIP(hipGetLastError());
 }
 
+#ifdef ZK_EXPERIMENTS   // gnark's unfolded computeH (7 transforms + the pointwise quotient): parity-tested in the experiments build, not part of the product
 // a <- (a*b - c) * den_inv   (all n*B elements)
 __global__ __launch_bounds__(256) void k_quotient_pointwise(Fr *__restrict__ a, const Fr *__restrict__ b, const Fr *__restrict__ c,
                                                             const Fr *__restrict__ consts, size_t total) {
@@ -949,6 +950,8 @@ void NttDomain::compute_h(Fr *a, Fr *b, Fr *c, size_t B, hipStream_t s) const {
     dif(a, B, true, coset_post.p, s);     // postmul = g^-rev(i) / n
     ZK_HIP(hipGetLastError());
 }
+
+#endif  // ZK_EXPERIMENTS
 
 // The prover's quotient stage (see keyfold.hip): only a and b are transformed; the remaining linear maps of computeH
 // live in the folded bases.

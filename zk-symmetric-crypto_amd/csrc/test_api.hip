@@ -76,6 +76,7 @@ extern "C" int zkp_ntt(int logn, long batch, uint8_t *data, int mode) {
     ZKP_CATCH(-1)
 }
 
+#ifdef ZK_EXPERIMENTS
 // a,b,c: [batch][ncons] canonical; h_out: [batch][N] canonical, natural coefficient order
 extern "C" int zkp_compute_h(int logn, long batch, long ncons, const uint8_t *a, const uint8_t *b, const uint8_t *c, uint8_t *h_out) {
     ZKP_TRY
@@ -104,6 +105,7 @@ extern "C" int zkp_compute_h(int logn, long batch, long ncons, const uint8_t *a,
     return 0;
     ZKP_CATCH(-1)
 }
+#endif  // ZK_EXPERIMENTS
 
 template <class F>
 static int msm_test(long n_, long batch, const uint8_t *points, const uint8_t *scalars, uint8_t *out, int c, bool dense = false, const uint8_t *wcomb_cls = nullptr,
