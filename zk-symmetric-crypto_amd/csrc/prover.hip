@@ -471,9 +471,9 @@ static size_t comb_min_batch() {
 }
 // Largest clump size whose table fits the budget.  The budget has two sides: a fixed share of the device (0.21 of its memory -- the k = 19
 // table of a 2^16 domain, the k = 18 table of a 2^17 one -- divided by the replicas the library keeps on this device), and what is left
-// once the buffers this replica will still allocate (working sets, pattern copies) are set aside.  Decisions are serialised process-wide
-// so that each one sees the tables of the replicas before it.
-static std::mutex g_comb_budget_lock;
+// once the buffers this replica will still allocate (working sets, pattern copies) are set aside.  Decisions are serialised per device
+// so that each one sees the tables of the replicas before it on the same GPU.
+static std::mutex g_comb_budget_lock[64];      // per device: replicas on different GPUs decide and build in parallel
 static int comb_pick_k(size_t n, size_t still_needed, int share) {
     static const int forced = [] { const char *e = getenv("ZKPROVE_COMB_K"); return e ? atoi(e) : 0; }();
     if (forced) return forced;
@@ -503,7 +503,7 @@ void Algorithm::comb_prepare(size_t B) {
     Resident &R = *res;
     if (!pk.comb_tried && B >= comb_min_batch()) {
         pk.comb_tried = true;
-        std::lock_guard<std::mutex> budget(g_comb_budget_lock);
+        std::lock_guard<std::mutex> budget(g_comb_budget_lock[device & 63]);
         // still to come for this replica: the second and third working set of the pipelined entries, the two pattern copies (~ the
         // table's clump count x 254 x B words: bounded by the k = 12 figure), range accumulators, and slack for the allocator
         const size_t N = (size_t)1 << prog.log_domain;
