@@ -23,6 +23,7 @@ struct ZkError : public std::runtime_error {
     } while (0)
 
 // RAII device buffer
+void memlog_large_alloc(size_t bytes);      // hostutil.cpp: ZKPROVE_MEMLOG=1 prints allocations >= 256 MiB with their call sites
 template <class T>
 struct DevBuf {
     T *p = nullptr;
@@ -41,6 +42,7 @@ struct DevBuf {
         release();
         if (count) ZK_HIP(hipMalloc((void **)&p, count * sizeof(T)));      // throws on failure with the buffer left empty (n = 0)
         n = count;
+        if (count * sizeof(T) >= ((size_t)256 << 20)) memlog_large_alloc(count * sizeof(T));
     }
     void ensure(size_t count) { if (count > n) alloc(count); }
     void release() {

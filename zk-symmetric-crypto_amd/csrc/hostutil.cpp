@@ -460,3 +460,22 @@ U256 hash_to_fr(const uint8_t *msg, size_t len, const char *dst) {
 }
 
 }  // namespace zk
+
+// ---- ZKPROVE_MEMLOG=1: device allocations >= 256 MiB with the frames that asked for them (sizing the HBM budget)
+#include <execinfo.h>
+namespace zk {
+void memlog_large_alloc(size_t bytes) {
+    static const bool on = getenv("ZKPROVE_MEMLOG") != nullptr;
+    if (!on) return;
+    void *fr[6];
+    const int nf = backtrace(fr, 6);
+    char **sym = backtrace_symbols(fr, nf);
+    fprintf(stderr, "zkprove: alloc %8.1f MiB", bytes / 1048576.0);
+    for (int i = 1; i < nf && sym; i++) {
+        const char *a = strchr(sym[i], '('), *b = a ? strchr(a, '+') : nullptr;
+        if (a && b && b > a + 1) fprintf(stderr, " < %.*s", (int)(b - a - 1 > 60 ? 60 : b - a - 1), a + 1);
+    }
+    fprintf(stderr, "\n");
+    free(sym);
+}
+}  // namespace zk

@@ -480,11 +480,16 @@ static int comb_pick_k(size_t n, size_t still_needed, int share) {
     size_t free_b = 0, total_b = 0;
     ZK_HIP(hipMemGetInfo(&free_b, &total_b));
     const double by_share = 0.21 * (double)total_b / (double)(share < 1 ? 1 : share);
-    const double by_free = free_b > still_needed ? 0.6 * (double)(free_b - still_needed) : 0.0;
+    const double by_free = free_b > still_needed ? 0.75 * (double)(free_b - still_needed) : 0.0;
     const double budget = by_share < by_free ? by_share : by_free;
-    for (int k = 19; k >= 12; k--)
-        if ((double)comb_table_bytes(n, k) <= budget) return k;
-    return 0;
+    int pick = 0;
+    for (int k = 19; k >= 12 && !pick; k--)
+        if ((double)comb_table_bytes(n, k) <= budget) pick = k;
+    static const bool log = getenv("ZKPROVE_MEMLOG") != nullptr;
+    if (log)
+        fprintf(stderr, "zkprove: comb budget: free %.1f GiB of %.1f, still needed %.1f, share 1/%d -> budget %.1f GiB, k = %d (%.1f GiB)\n", free_b / 1073741824.0,
+                total_b / 1073741824.0, still_needed / 1073741824.0, share, budget / 1073741824.0, pick, pick ? comb_table_bytes(n, pick) / 1073741824.0 : 0.0);
+    return pick;
 }
 size_t Algorithm::resident_batch() const { return res ? res->B : 0; }
 void Algorithm::debug_leftovers(long *out3) {
