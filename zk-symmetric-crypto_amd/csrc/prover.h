@@ -109,6 +109,7 @@ class Algorithm {
     void resident_reserve_buffers(size_t B);
     bool comb_release();                                    // out of memory: give the comb tables back, continue on the bucket pipeline                            // lazy table build + scratch (resident_reserve)
     void enqueue_ntt_sort(struct SolveSet &S, hipStream_t sn, int slot, hipEvent_t slot_free = nullptr);
+    hipStream_t side_chain_stream(hipStream_t solve_stream, struct SolveSet &S);
     void enqueue_tail_early(struct SolveSet &S, hipStream_t st);
     void enqueue_finalize(struct SolveSet &S, hipStream_t st);
     void collect_times(struct SolveSet &S, PhaseTimes *times);

@@ -638,7 +638,14 @@ void Algorithm::resident_reserve(size_t B) {
         ZK_HIP(hipStreamCreateWithPriority(&res->stream3, hipStreamNonBlocking, prio_hi));
         // exactly four streams: a fifth one no longer gets a hardware queue of its own (HIP multiplexes streams over 4 queues) and
         // doubled the latency of the 160-460 dependent solver launches.  The copy stream doubles as the side stream of small batches.
-        ZK_HIP(hipStreamCreateWithPriority(&res->copy_stream, hipStreamNonBlocking, prio_hi));
+        // Its priority decides who gets the wave slots the transforms (copy stream) and the next batch's solve stage (stream2) compete
+        // for.  A long solve stage (AES: 430-460 levels, a commitment MSM in the middle) must win, or it is not through when the
+        // quotient walk ends and the transforms of ITS batch start late: AES-256 218.5 ms per step with the copy stream low, 232.2 high.
+        // A short one (ChaCha20: 163 levels) finishes anyway and only delays the transforms, which are the critical chain there:
+        // 88.1 ms high, 88.9 low.  ZKPROVE_COPY_PRIO=hi|lo overrides.
+        static const int copy_prio = [] { const char *e = getenv("ZKPROVE_COPY_PRIO"); return !e ? -1 : !strcmp(e, "hi") ? 1 : 0; }();
+        const bool copy_hi = copy_prio < 0 ? prog.levels.size() <= 256 : copy_prio == 1;
+        ZK_HIP(hipStreamCreateWithPriority(&res->copy_stream, hipStreamNonBlocking, copy_hi ? prio_hi : prio_lo));
         for (auto &e : res->ev) ZK_HIP(hipEventCreate(&e));
     }
     Resident &R = *res;
@@ -795,6 +802,17 @@ bool Algorithm::ahead_eligible() const {
     // the complete predicate of msm_dense_presort: a batch that does not meet it takes the in-line sort of enqueue_main
     return pk.Z.dense && pk.Z.n != 0 && msm_dense_presort_applicable(pk.Z, R.B, R.ms) && R.ms.entries_zb.n >= R.B * max_entries + 1 &&
            R.ms.bucket_start_zb.n >= R.B * (nb + 1);
+}
+// The stream the transforms of an ahead-prepared batch go to: the COPY stream, behind the batch's solve stage (event), so that the
+// solve stage of the batch after it -- a chain of 163-457 short, latency-bound launches -- runs BESIDE these transforms instead of in
+// front of them.  (On one stream the chain solve -> transforms was serial, and since the quotient walk's single-wave workgroups take
+// every wave slot for its whole duration, the solve stage ended up alone on the device between the walk and the transforms:
+// 10.6 ms of 96 per ChaCha20 step, 28 of 239 for AES-256 -- scripts/debug/timeline_step.py.)  ZKPROVE_NTT_STREAM=solve: the old order.
+hipStream_t Algorithm::side_chain_stream(hipStream_t solve_stream, SolveSet &S) {
+    static const bool on_solve = [] { const char *e = getenv("ZKPROVE_NTT_STREAM"); return e && !strcmp(e, "solve"); }();
+    if (on_solve) return solve_stream;
+    ZK_HIP(hipStreamWaitEvent(res->copy_stream, S.solved, 0));
+    return res->copy_stream;
 }
 void Algorithm::enqueue_ntt_sort(SolveSet &S, hipStream_t sn, int slot, hipEvent_t slot_free) {
     Resident &R = *res;
@@ -1084,7 +1102,7 @@ void Algorithm::resident_prove_pipelined(int nsteps, PhaseTimes *times) {
         if (set_free) ZK_HIP(hipStreamWaitEvent(S, set_free, 0));
         enqueue_solve(nx, has_commit ? R.ms2 : R.ms, S);
         ZK_HIP(hipEventRecord(nx.solved, S));
-        if (ahead) enqueue_ntt_sort(nx, S, j & 1, slot_free);
+        if (ahead) enqueue_ntt_sort(nx, side_chain_stream(S, nx), j & 1, slot_free);
     };
     for (int j = 0; j < D && j < nsteps; j++) prepare(j, nullptr, nullptr);
     for (int k = 0; k < nsteps; k++) {
@@ -1274,7 +1292,7 @@ void Algorithm::prove_stream(ChunkFeed &feed, PhaseTimes *times) {
         upload_set(cur, Bk, c.inputs, c.r, c.s, c.rnd, S);
         enqueue_solve(cur, has_commit ? R.ms2 : R.ms, S);
         ZK_HIP(hipEventRecord(cur.solved, S));
-        if (ahead_eligible()) enqueue_ntt_sort(cur, S, (int)(k & 1), k >= 2 ? R.set[(k - 2) % NS].zdone : nullptr);
+        if (ahead_eligible()) enqueue_ntt_sort(cur, side_chain_stream(S, cur), (int)(k & 1), k >= 2 ? R.set[(k - 2) % NS].zdone : nullptr);
         ZK_HIP(hipStreamWaitEvent(M, cur.solved, 0));
         enqueue_main(cur, M, k ? R.ev[11] : nullptr, F);
         ZK_HIP(hipEventRecord(cur.zdone, M));

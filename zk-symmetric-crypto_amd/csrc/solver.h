@@ -17,12 +17,14 @@ enum SolverErr : uint32_t { SERR_NONE = 0, SERR_UNSATISFIED = 1, SERR_LOOKUP_RAN
 
 struct SolverLevel {
     uint32_t first = 0, count = 0;   // range in level_instr
+    uint32_t wide = 0;               // the first `wide` of them need a whole workgroup (k_solve_level); the rest are packed four to one
     bool has_commit = false;         // a BSB22 hint sits in this level: commitment must be ready before launch
     uint32_t div_first = 0, div_count = 0;   // deferred divisions of this level (records in div_list)
 };
 
 struct SolverProgram {
     size_t n_wires = 0, n_inputs = 0, n_constraints = 0, n_public = 0;
+    bool constraints_covered = false;      // every constraint row is written by an R1C instruction (solver_begin clears only the padding then)
     int log_domain = 0;
     std::vector<SolverLevel> levels;
     DevBuf<uint32_t> prog, instr_off, level_instr;

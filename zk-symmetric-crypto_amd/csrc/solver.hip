@@ -18,6 +18,9 @@
 
 namespace zk {
 
+// linear expressions of at least this many terms are evaluated by all slices of a workgroup (eval_terms_coop)
+static constexpr int COOP_MIN_TERMS = 16;
+
 // ------------------------------------------------------------------------------------- build
 namespace {
 void push_linexp(std::vector<uint32_t> &out, const uint32_t *&p) {
@@ -75,7 +78,8 @@ void SolverProgram::build(const R1cs &cs, hipStream_t s) {
     std::vector<Fr> count_tab;
     std::vector<uint32_t> defer;           // deferred divisions: (level-local order) cons, loc, wire, coeff
     std::vector<uint32_t> defer_level(ni, 0);
-    std::vector<uint8_t> is_commit_instr(ni, 0), is_div_instr(ni, 0);
+    std::vector<uint8_t> is_commit_instr(ni, 0), is_div_instr(ni, 0), is_wide_instr(ni, 0);      // wide: see k_solve_level
+    std::vector<uint8_t> covered(n_constraints, 0);      // constraint rows of a / b / c that some R1C instruction writes (solver_begin)
     n_count_rows = 0;
     n_count_slots = 0;
     for (size_t i = 0; i < ni; i++) {
@@ -107,10 +111,12 @@ void SolverProgram::build(const R1cs &cs, hipStream_t s) {
                     kept++;
                 }
                 prg[hdr + 2 + which] = kept;
+                if (kept >= (uint32_t)COOP_MIN_TERMS) is_wide_instr[i] = 1;
             }
             prg[hdr + 5] = loc;
             if (loc == 1 || loc == 2) is_div_instr[i] = 1;
             if (cs.constraint_offset[i] >= n_constraints) throw ZkError("constraint index out of range");
+            covered[cs.constraint_offset[i]] = 1;
         } else if (kind == BP_HINT) {
             const uint32_t hid = cd[1], nin = cd[2];
             const uint32_t out_start = cd[size - 2], out_end = cd[size - 1];
@@ -119,6 +125,7 @@ void SolverProgram::build(const R1cs &cs, hipStream_t s) {
             if (hid == HINT_NBITS) {
                 if (nin != 1) throw ZkError("nBits hint with != 1 input");
                 prg.insert(prg.end(), {OP_NBITS, out_end - out_start, out_start});
+                if (p[0] >= (uint32_t)COOP_MIN_TERMS) is_wide_instr[i] = 1;
                 push_linexp(prg, p);
             } else if (hid == HINT_COUNT) {
                 // inputs: [nTable, nCol, table rows..., query rows...]; first two are constants
@@ -169,6 +176,7 @@ void SolverProgram::build(const R1cs &cs, hipStream_t s) {
                 }
                 const size_t hdr = prg.size();
                 prg.insert(prg.end(), {OP_COUNT, ntab, ncol, nq, out_start, (uint32_t)n_count_slots, table_off, 0u});
+                is_wide_instr[i] = 1;
                 n_count_slots++;
                 // word 7: offset (from the first query) of a table with the start of every query row, so that the slices of a
                 // workgroup can each take every SL-th query although the rows are variable-length linear expressions
@@ -213,6 +221,8 @@ void SolverProgram::build(const R1cs &cs, hipStream_t s) {
     }
     for (size_t w = 0; w < n_wires; w++)
         if (!solved[w]) throw ZkError("circuit leaves wire " + std::to_string(w) + " undefined");
+    constraints_covered = true;
+    for (uint8_t c : covered) constraints_covered = constraints_covered && c;
     // levels
     std::vector<uint32_t> li;
     levels.clear();
@@ -221,7 +231,15 @@ void SolverProgram::build(const R1cs &cs, hipStream_t s) {
         lv.first = (uint32_t)li.size();
         lv.count = (uint32_t)l.size();
         lv.div_first = (uint32_t)(defer.size() / 4);
-        for (uint32_t i : l) {
+        // wide instructions (a linear expression of >= COOP_MIN_TERMS terms, a countHint) first: k_solve_level gives them a workgroup
+        // each and packs the others four to a workgroup
+        std::vector<uint32_t> ordered;
+        for (int pass = 0; pass < 2; pass++)
+            for (uint32_t i : l)
+                if ((int)is_wide_instr[i] == 1 - pass) ordered.push_back(i);
+        lv.wide = 0;
+        for (uint32_t i : l) lv.wide += is_wide_instr[i];
+        for (uint32_t i : ordered) {
             li.push_back(i);
             if (is_commit_instr[i]) lv.has_commit = true;
             if (is_div_instr[i]) {
@@ -340,7 +358,6 @@ __device__ __forceinline__ Fr eval_linexp(const SolveCtx &cx, const uint32_t *&p
 // Must be called by all threads of the workgroup (n and p are workgroup-uniform).  Result valid in slice 0.
 // Workgroup shapes (instances x slices = 256 threads): 64 x 4 for real batches; 16 x 16 and 8 x 32 for the small batches of
 // single Prove() calls, where spare lanes are better spent on the terms of an expression than on instances that do not exist.
-static constexpr int COOP_MIN_TERMS = 16;
 template <int LX, int SL>
 __device__ __forceinline__ Fr eval_terms_coop(const SolveCtx &cx, const uint32_t *&p, uint32_t n, size_t b, Fr *red) {
     const int slice = threadIdx.y, lane = threadIdx.x;
@@ -381,29 +398,26 @@ __device__ __forceinline__ bool small_index(const Fr &v_mont, uint32_t bound, ui
     return hi == 0 && idx < bound;
 }
 
-template <int LX, int SL>
-__global__ __launch_bounds__(256) void k_solve_level(SolveCtx cx, const uint32_t *__restrict__ instr_off, const uint32_t *__restrict__ level_instr,
-                                                     uint32_t count) {
-    // grid = (ceil(B / LX), instructions of the level), block = (LX instances, SL slices): the instruction is uniform per
-    // workgroup, so the program words are scalar loads and all control flow on them is wave-uniform; the slices share
-    // the evaluation of long linear expressions (and the queries of a countHint), slice 0 finishes the instruction
-    static_assert(LX * SL == 256, "workgroup shape");
-    __shared__ Fr red[SL * LX];
+// One instruction.  COOP: the SL slices of the workgroup work on it together (long linear expressions, countHint queries; slice 0
+// finishes it); !COOP: the calling wave owns it (no barriers, no LDS) -- lead = live.
+template <int LX, int SL, bool COOP>
+__device__ __forceinline__ void solve_instruction(const SolveCtx &cx, const uint32_t *__restrict__ instr_off, uint32_t instr, size_t b, bool live, bool lead, Fr *red) {
     const size_t B = cx.B;
-    const size_t b_raw = (size_t)blockIdx.x * LX + threadIdx.x;
-    const bool live = b_raw < B;
-    const size_t b = live ? b_raw : B - 1;            // dead lanes shadow the last instance (no early exit before barriers)
-    const bool lead = threadIdx.y == 0 && live;
-    if (blockIdx.y >= count) return;
-    const uint32_t instr = level_instr[blockIdx.y];
     const uint32_t *p = cx.prog + instr_off[instr];
     const uint32_t op = p[0];
     if (op == OP_R1C) {
         const uint32_t cons = p[1], nL = p[2], nR = p[3], nO = p[4], loc = p[5], sw = p[6], sc = p[7];
         p += 8;
-        Fr vL = eval_terms_coop<LX, SL>(cx, p, nL, b, red);
-        Fr vR = eval_terms_coop<LX, SL>(cx, p, nR, b, red);
-        Fr vO = eval_terms_coop<LX, SL>(cx, p, nO, b, red);
+        Fr vL, vR, vO;
+        if constexpr (COOP) {
+            vL = eval_terms_coop<LX, SL>(cx, p, nL, b, red);
+            vR = eval_terms_coop<LX, SL>(cx, p, nR, b, red);
+            vO = eval_terms_coop<LX, SL>(cx, p, nO, b, red);
+        } else {
+            vL = eval_terms(cx, p, nL, b);
+            vR = eval_terms(cx, p, nR, b);
+            vO = eval_terms(cx, p, nO, b);
+        }
         if (!lead) return;
         if (loc == 0) {
             if (mul_fast(vL, vR) != vO) report(cx, b, SERR_UNSATISFIED, cons);
@@ -431,7 +445,9 @@ __global__ __launch_bounds__(256) void k_solve_level(SolveCtx cx, const uint32_t
     } else if (op == OP_NBITS) {
         const uint32_t nout = p[1], out0 = p[2];
         p += 3;
-        Fr v = eval_linexp_coop<LX, SL>(cx, p, b, red);
+        Fr v;
+        if constexpr (COOP) v = eval_linexp_coop<LX, SL>(cx, p, b, red);
+        else v = eval_linexp(cx, p, b);
         if (!lead) return;
         v = v.from_mont();
         const Fr one = Fr::one(), zero = Fr::zero();
@@ -439,7 +455,7 @@ __global__ __launch_bounds__(256) void k_solve_level(SolveCtx cx, const uint32_t
             const bool bit = k < 256 && ((v.l[k >> 5] >> (k & 31)) & 1);
             cx.wires[(size_t)(out0 + k) * B + b] = bit ? one : zero;
         }
-    } else if (op == OP_COUNT) {
+    } else if (COOP && op == OP_COUNT) {
         // countHint of a log-derivative lookup: multiplicity of every table row among nq (~3 600 for the AES S-box) queries.
         // The slices take every SL-th query (one lane used to walk all of them: the three longest levels of the AES circuits,
         // 3-4 ms each); counters live in global memory, hence atomics.
@@ -484,6 +500,35 @@ __global__ __launch_bounds__(256) void k_solve_level(SolveCtx cx, const uint32_t
         cx.wires[(size_t)p[1] * B + b] = cx.randomize[b];
     } else if (op == OP_BSB22) {
         cx.wires[(size_t)p[1] * B + b] = cx.challenge[b];
+    }
+}
+
+// grid = (ceil(B / LX), workgroups of the level), block = (LX instances, SL slices).  The first `nwide` workgroup rows take one
+// instruction each: the instruction is uniform per workgroup, so the program words are scalar loads and all control flow on them is
+// wave-uniform; the slices share the evaluation of long linear expressions (and the queries of a countHint), slice 0 finishes the
+// instruction.  The rows after them (64 x 4 shape only) take FOUR instructions each, one per wavefront: the instructions whose
+// expressions are all short (< COOP_MIN_TERMS terms: 3/4 of the ChaCha20 program, 9/10 of the AES ones) have nothing for the other
+// three slices to do, and a level's duration is the number of wavefronts it sends through the CUs times their memory round trips
+// (SolverProgram orders every level wide-first and counts them).
+template <int LX, int SL>
+__global__ __launch_bounds__(256) void k_solve_level(SolveCtx cx, const uint32_t *__restrict__ instr_off, const uint32_t *__restrict__ level_instr,
+                                                     uint32_t count, uint32_t nwide) {
+    static_assert(LX * SL == 256, "workgroup shape");
+    __shared__ Fr red[SL * LX];
+    const size_t B = cx.B;
+    const size_t b_raw = (size_t)blockIdx.x * LX + threadIdx.x;
+    const bool live = b_raw < B;
+    const size_t b = live ? b_raw : B - 1;            // dead lanes shadow the last instance (no early exit before barriers)
+    if (blockIdx.y < nwide) {
+        if (blockIdx.y >= count) return;
+        solve_instruction<LX, SL, true>(cx, instr_off, level_instr[blockIdx.y], b, live, threadIdx.y == 0 && live, red);
+        return;
+    }
+    if constexpr (LX == 64) {
+        const uint32_t slice = __builtin_amdgcn_readfirstlane(threadIdx.y);      // a wavefront = one slice: uniform
+        const uint32_t idx = nwide + (blockIdx.y - nwide) * SL + slice;
+        if (idx >= count) return;
+        solve_instruction<LX, SL, false>(cx, instr_off, level_instr[idx], b, live, live, red);
     }
 }
 
@@ -542,9 +587,15 @@ __global__ __launch_bounds__(256) void k_assign_inputs(const uint32_t *__restric
 
 void solver_begin(const SolverProgram &p, SolverBuffers &buf, hipStream_t s) {
     const size_t B = buf.B, N = (size_t)1 << p.log_domain;
-    ZK_HIP(hipMemsetAsync(buf.a.p, 0, N * B * sizeof(Fr), s));
-    ZK_HIP(hipMemsetAsync(buf.b.p, 0, N * B * sizeof(Fr), s));
-    ZK_HIP(hipMemsetAsync(buf.c.p, 0, N * B * sizeof(Fr), s));
+    // a and b: every row an R1C instruction owns is written by it; only the rows nobody writes must be zero again (the transforms
+    // work in place) -- the padding up to the domain size when the program covers all constraints (it does for these circuits), all
+    // rows otherwise.  c is scratch of the deferred divisions (written before read, level by level) and the destination of the
+    // quotient-stage products: never cleared.  (The three full memsets were 6.4 / 12.9 GB of HBM writes per 1024-batch.)
+    const size_t first_clear = p.constraints_covered ? p.n_constraints : 0;
+    if (first_clear < N) {
+        ZK_HIP(hipMemsetAsync(buf.a.p + first_clear * B, 0, (N - first_clear) * B * sizeof(Fr), s));
+        ZK_HIP(hipMemsetAsync(buf.b.p + first_clear * B, 0, (N - first_clear) * B * sizeof(Fr), s));
+    }
     ZK_HIP(hipMemsetAsync(buf.err.p, 0, B * sizeof(uint32_t), s));
     hipLaunchKernelGGL(k_assign_inputs, dim3(ceil_div((p.n_inputs + 1) * B, 256)), dim3(256), 0, s, buf.inputs.p, buf.wires.p, p.n_inputs, B);
     ZK_HIP(hipGetLastError());
@@ -556,14 +607,20 @@ void solver_run_levels(const SolverProgram &p, SolverBuffers &buf, size_t first_
     for (size_t l = first_level; l < last_level && l < p.levels.size(); l++) {
         const SolverLevel &lv = p.levels[l];
         if (!lv.count) continue;
-        for (uint32_t off = 0; off < lv.count; off += 65535) {       // grid.y limit
-            const uint32_t cnt = lv.count - off < 65535 ? lv.count - off : 65535;
-            if (buf.B <= 8)
-                hipLaunchKernelGGL((k_solve_level<8, 32>), dim3(ceil_div(buf.B, 8), cnt), dim3(8, 32), 0, s, cx, p.instr_off.p, p.level_instr.p + lv.first + off, cnt);
-            else if (buf.B <= 16)
-                hipLaunchKernelGGL((k_solve_level<16, 16>), dim3(ceil_div(buf.B, 16), cnt), dim3(16, 16), 0, s, cx, p.instr_off.p, p.level_instr.p + lv.first + off, cnt);
-            else
-                hipLaunchKernelGGL((k_solve_level<64, 4>), dim3(ceil_div(buf.B, 64), cnt), dim3(64, 4), 0, s, cx, p.instr_off.p, p.level_instr.p + lv.first + off, cnt);
+        const uint32_t packed_rows = lv.wide + (lv.count - lv.wide + 3) / 4;
+        static const bool pack = [] { const char *e = getenv("ZKPROVE_SOLVER_PACK"); return !(e && e[0] == '0'); }();
+        if (pack && buf.B > 16 && packed_rows <= 65535) {
+            hipLaunchKernelGGL((k_solve_level<64, 4>), dim3(ceil_div(buf.B, 64), packed_rows), dim3(64, 4), 0, s, cx, p.instr_off.p, p.level_instr.p + lv.first, lv.count, lv.wide);
+        } else {
+            for (uint32_t off = 0; off < lv.count; off += 65535) {       // grid.y limit; every row cooperative (correct for any instruction)
+                const uint32_t cnt = lv.count - off < 65535 ? lv.count - off : 65535;
+                if (buf.B <= 8)
+                    hipLaunchKernelGGL((k_solve_level<8, 32>), dim3(ceil_div(buf.B, 8), cnt), dim3(8, 32), 0, s, cx, p.instr_off.p, p.level_instr.p + lv.first + off, cnt, cnt);
+                else if (buf.B <= 16)
+                    hipLaunchKernelGGL((k_solve_level<16, 16>), dim3(ceil_div(buf.B, 16), cnt), dim3(16, 16), 0, s, cx, p.instr_off.p, p.level_instr.p + lv.first + off, cnt, cnt);
+                else
+                    hipLaunchKernelGGL((k_solve_level<64, 4>), dim3(ceil_div(buf.B, 64), cnt), dim3(64, 4), 0, s, cx, p.instr_off.p, p.level_instr.p + lv.first + off, cnt, cnt);
+            }
         }
         if (lv.div_count)
             hipLaunchKernelGGL(k_solve_divisions, dim3(ceil_div(buf.B, 256), ceil_div(lv.div_count, DIV_GROUP)), dim3(256), 0, s, cx,
