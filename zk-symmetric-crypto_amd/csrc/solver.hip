@@ -510,8 +510,11 @@ __device__ __forceinline__ void solve_instruction(const SolveCtx &cx, const uint
 // expressions are all short (< COOP_MIN_TERMS terms: 3/4 of the ChaCha20 program, 9/10 of the AES ones) have nothing for the other
 // three slices to do, and a level's duration is the number of wavefronts it sends through the CUs times their memory round trips
 // (SolverProgram orders every level wide-first and counts them).
-template <int LX, int SL>
-__global__ __launch_bounds__(256) void k_solve_level(SolveCtx cx, const uint32_t *__restrict__ instr_off, const uint32_t *__restrict__ level_instr,
+// MINB: workgroups per CU the register budget is set for -- 1: 151 registers, 3 resident; 4: 128 registers (96 more bytes of scratch),
+// 4 resident.  Same box, batch 1024: ChaCha20 88.7 ms per step with 4, 90.9 with 1; AES-256 221.1 with 4, 218.8 with 1 (the countHint
+// and division-heavy levels pay for the spills) -- solver_run_levels picks by the program's level count, ZKPROVE_SOLVER_OCC=3|4 overrides.
+template <int LX, int SL, int MINB = 1>
+__global__ __launch_bounds__(256, MINB) void k_solve_level(SolveCtx cx, const uint32_t *__restrict__ instr_off, const uint32_t *__restrict__ level_instr,
                                                      uint32_t count, uint32_t nwide) {
     static_assert(LX * SL == 256, "workgroup shape");
     __shared__ Fr red[SL * LX];
@@ -609,8 +612,11 @@ void solver_run_levels(const SolverProgram &p, SolverBuffers &buf, size_t first_
         if (!lv.count) continue;
         const uint32_t packed_rows = lv.wide + (lv.count - lv.wide + 3) / 4;
         static const bool pack = [] { const char *e = getenv("ZKPROVE_SOLVER_PACK"); return !(e && e[0] == '0'); }();
+        static const int occ_env = [] { const char *e = getenv("ZKPROVE_SOLVER_OCC"); return e ? atoi(e) : 0; }();
+        const bool four = occ_env ? occ_env >= 4 : p.levels.size() <= 256;
         if (pack && buf.B > 16 && packed_rows <= 65535) {
-            hipLaunchKernelGGL((k_solve_level<64, 4>), dim3(ceil_div(buf.B, 64), packed_rows), dim3(64, 4), 0, s, cx, p.instr_off.p, p.level_instr.p + lv.first, lv.count, lv.wide);
+            if (four) hipLaunchKernelGGL((k_solve_level<64, 4, 4>), dim3(ceil_div(buf.B, 64), packed_rows), dim3(64, 4), 0, s, cx, p.instr_off.p, p.level_instr.p + lv.first, lv.count, lv.wide);
+            else hipLaunchKernelGGL((k_solve_level<64, 4, 1>), dim3(ceil_div(buf.B, 64), packed_rows), dim3(64, 4), 0, s, cx, p.instr_off.p, p.level_instr.p + lv.first, lv.count, lv.wide);
         } else {
             for (uint32_t off = 0; off < lv.count; off += 65535) {       // grid.y limit; every row cooperative (correct for any instruction)
                 const uint32_t cnt = lv.count - off < 65535 ? lv.count - off : 65535;
