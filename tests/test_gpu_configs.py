@@ -246,6 +246,22 @@ def test_bucket_pipeline_of_large_batches_stays_bit_exact():
                          env=env, capture_output=True, text=True, timeout=1200, cwd=H.ROOT)
     assert res.returncode == 0 and " passed" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("switches", [
+    {"ZKPROVE_NTT_STREAM": "solve", "ZKPROVE_SOLVER_PACK": "0"},          # round-2 arrangement: transforms behind the solve stage on its stream, a workgroup per instruction
+    {"ZKPROVE_COPY_PRIO": "lo", "ZKPROVE_SOLVER_OCC": "3"},               # what the AES programs get by default, on the ChaCha20 program
+    {"ZKPROVE_COPY_PRIO": "hi", "ZKPROVE_SOLVER_OCC": "4"},
+])
+def test_scheduling_switches_do_not_change_a_byte(switches):
+    """Where the transforms run (copy stream beside the next solve stage / solve stream behind it), the copy stream's priority, the solver
+    kernel's register budget and the packing of short instructions four to a workgroup are scheduling choices: the pipelined-steps test
+    (every working set, both pattern copies, byte-identical to the single step and the oracle) passes under each of them.  Own process:
+    the switches are read once."""
+    env = dict(os.environ, **switches)
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k", "pipelined_steps_rotate", "-p", "no:cacheprovider"],
+                         env=env, capture_output=True, text=True, timeout=1200, cwd=H.ROOT)
+    assert res.returncode == 0 and " passed" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
+
 def test_streamed_prove_batch_answers_bad_members_in_place(zk, oracle):
     """A streamed ProveBatch call (more than one device chunk) with bad members in different chunks: a request with a short key, one for
     another cipher, one that is not an object and one with broken JSON answer exactly what Prove answers for them, at their positions;
