@@ -47,7 +47,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-pipeline", action="store_true", help="one stream, no overlap of consecutive steps")
     ap.add_argument("--cpu-proofs", type=int, default=-1, help="cpu_baseline sample: proofs per worker process (0 = skip, -1 = default 8)")
     ap.add_argument("--abi-requests", type=int, default=-1,
-                    help="ABI leg: JSON requests per ProveBatch call (0 = skip, -1 = default 8192 ChaCha20 / 4096 AES-256)")
+                    help="ABI leg: JSON requests per ProveBatch call (0 = skip, -1 = default 8192: eight device chunks, so that the first chunk (which has nothing to overlap with) weighs 1/8)")
     ap.add_argument("--master-port", type=int, default=0)
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="CPU check of the N-rank launcher + gather plumbing (gloo, no GPU, nothing is proved or timed)")
@@ -401,9 +401,9 @@ def run_rank(args):
         if args.abi_requests != 0 and world == 1:
             # after every timed region: the ABI-inclusive rates (not `value`: the contract times resident inputs)
             try:
-                out["abi"] = abi_leg(args.alg, args.abi_requests if args.abi_requests > 0 else (8192 if args.alg == 0 else 4096), head.vk)
+                out["abi"] = abi_leg(args.alg, args.abi_requests if args.abi_requests > 0 else 8192, head.vk)
                 if 2 in lines and args.alg != 2:
-                    out["aes256_ctr"]["abi"] = abi_leg(2, args.abi_requests if args.abi_requests > 0 else 4096, algs[1][1].vk)
+                    out["aes256_ctr"]["abi"] = abi_leg(2, args.abi_requests if args.abi_requests > 0 else 8192, algs[1][1].vk)
             except Exception as e:
                 out["abi"] = {"error": repr(e)}
         if args.cpu_proofs != 0 and world == 1:
