@@ -1304,9 +1304,10 @@ void Algorithm::prove_stream(ChunkFeed &feed, PhaseTimes *times) {
         if (ahead_eligible()) enqueue_ntt_sort(nx, side_chain_stream(S, nx), (int)(j & 1), j >= 2 ? R.set[(j - 2) % NS].zdone : nullptr);
         return true;
     };
+    size_t k = 0;
+    try {
     for (size_t j = 0; j < D; j++)
         if (!prepare()) break;
-    size_t k = 0;
     for (; k < fetched; k++) {
         SolveSet &cur = R.set[k % NS];
         set_batch(held[k % NS].count);
@@ -1320,6 +1321,11 @@ void Algorithm::prove_stream(ChunkFeed &feed, PhaseTimes *times) {
         ZK_HIP(hipEventRecord(cur.consumed, F));
         if (k >= 1) download(k - 1);            // frees set (k - 1) % NS == (k + D) % NS; at most NS chunks are away from the feed
         prepare();                              // chunk k + D
+    }
+    } catch (...) {
+        // nothing may still read the caller's pinned chunk buffers or write this replica's sets when the error reaches the caller
+        (void)hipStreamSynchronize(S); (void)hipStreamSynchronize(C); (void)hipStreamSynchronize(M); (void)hipStreamSynchronize(F);
+        throw;
     }
     // k chunks were enqueued; all but the last are already back
     if (k) download(k - 1);
