@@ -789,9 +789,10 @@ void Algorithm::enqueue_solve(SolveSet &S, MsmScratch &commit_scratch, hipStream
 }
 
 // Ahead mode (pipelined entries, large batches): the transforms and the quotient MSM's bucket sort of a batch need nothing but its solved
-// wires, so they are enqueued right behind its solve stage -- on the solve stream / copy stream, i.e. while the main stream still walks
-// the PREVIOUS batch's quotient MSM.  The sort (LDS / memory bound, 10 ms alone, 15 beside other kernels) then hides under that walk
-// instead of standing on the critical path between the wire MSMs and the walk; the sorted list is double-buffered (slot = batch
+// wires, so they are enqueued right behind its solve stage -- on the copy stream (side_chain_stream), i.e. while the main stream is still
+// busy with an EARLIER batch.  (Nothing runs under the quotient walk itself: its single-wave workgroups hold every wave slot; the ahead
+// work fills the window between two walks, beside the wire MSMs -- DESIGN.md section 6.)  The sort / pattern extraction then no longer
+// stands on the critical path between the wire MSMs and the walk; the sorted list is double-buffered (slot = batch
 // parity).  ZKPROVE_SORT_AHEAD=0 keeps everything in enqueue_main.
 bool Algorithm::ahead_eligible() const {
     static const bool on = [] { const char *e = getenv("ZKPROVE_SORT_AHEAD"); return !(e && e[0] == '0'); }();
@@ -1005,7 +1006,7 @@ void Algorithm::collect_times(SolveSet &S, PhaseTimes *times) {
     t45 += t6e;
     if (R.last_g2_side) ZK_HIP(hipEventElapsedTime(&t45, R.ev[4], R.ev[13]));      // the G2 MSM ran beside the G1 chain: msm_g1 = the main stream from its first MSM to the end of the walk
     ZK_HIP(hipEventElapsedTime(&times->z_segments, R.ev[8], R.ev[9]));
-    if (R.last_ahead) ZK_HIP(hipEventElapsedTime(&t34, R.ev[19], R.ev[20]));      // the transforms ran on the solve stream, beside the previous batch's MSMs
+    if (R.last_ahead) ZK_HIP(hipEventElapsedTime(&t34, R.ev[19], R.ev[20]));      // the transforms ran on the copy stream (side_chain_stream): start to end, INCLUDING the time they wait for wave slots under a quotient walk
     times->solve = t01 + t23; times->commit = t12; times->ntt = t34; times->msm_g1 = t45; times->msm_g2 = t56; times->finalize = t67;
 }
 
@@ -1097,7 +1098,7 @@ void Algorithm::resident_prove_pipelined(int nsteps, PhaseTimes *times) {
     ZK_HIP(hipEventRecord(R.ev[0], M));
     ZK_HIP(hipStreamWaitEvent(S, R.ev[0], 0));
     ZK_HIP(hipStreamWaitEvent(F, R.ev[0], 0));
-    auto prepare = [&](int j, hipEvent_t set_free, hipEvent_t slot_free) {      // solve stage of batch j (+ ahead work) on the solve stream
+    auto prepare = [&](int j, hipEvent_t set_free, hipEvent_t slot_free) {      // solve stage of batch j on the solve stream, its ahead work (transforms, patterns / sort) on the copy stream
         SolveSet &nx = R.set[j % NS];
         if (set_free) ZK_HIP(hipStreamWaitEvent(S, set_free, 0));
         enqueue_solve(nx, has_commit ? R.ms2 : R.ms, S);
