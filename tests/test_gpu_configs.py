@@ -363,6 +363,55 @@ def test_comb_tables_are_given_back_under_memory_pressure():
     assert out["comb_after"] == 0 and out["same"] and out["ok"], out
     assert "comb tables" in res.stderr and "released" in res.stderr
 
+_THREE_SCRIPT = r"""
+import base64, importlib, json, os, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+zk = importlib.import_module("zk-symmetric-crypto_amd")
+import helpers as H
+from oracle import ref
+zk.lib.ZkpAllowUnpinnedKeys(1)
+def comb(alg):
+    info = np.zeros(8, np.int64)
+    zk.lib.zkp_quotient_msm_info(alg, info.ctypes.data)
+    return int(info[0])
+order = (0, 2, 1)                       # ChaCha20, AES-256, then AES-128 arrives on a full device
+for alg in order:
+    r1cs = zk.synth.r1cs_bytes(alg)
+    pk, vk = zk.setup(r1cs, ref.toxic_from_seed(1), raw=True)
+    assert zk.init_algorithm(alg, pk, r1cs) and zk.init_verifier(alg, vk)
+out = {{"ok": {{}}, "comb_before": {{}}, "comb_after": {{}}}}
+for rnd in range(2):
+    for alg in order:
+        rng = H.SplitMix64(4242 + alg)
+        insts = [H.make_instance(alg, rng) for _ in range(2048)]
+        res = json.loads(zk.prove_batch_raw(("[" + ",".join(H.request_json(alg, i).decode() for i in insts) + "]").encode()))
+        good = 0
+        for k in range(len(insts)):
+            g = isinstance(res[k], dict) and "proof" in res[k]
+            if g and (k % 256 == 0 or k == len(insts) - 1):
+                o = zk.request_witness(H.request_json(alg, insts[k]))[2]
+                g = base64.b64decode(res[k]["ciphertext"]) == o and zk.verify(H.CIPHER[alg], base64.b64decode(res[k]["proof"]), o, list(zip(insts[k]["nonces"], insts[k]["counters"])), insts[k]["data"])
+            good += bool(g)
+        out["ok"]["%d.%d" % (rnd, alg)] = good
+        if rnd == 0 and alg == 2: out["comb_before"] = {{str(a): comb(a) for a in (0, 2)}}
+out["comb_after"] = {{str(a): comb(a) for a in order}}
+print(json.dumps(out))
+"""
+
+def test_a_third_circuit_takes_the_idle_neighbours_tables():
+    """Three circuits with 1024-chunks on one GPU: the tables and working sets of ChaCha20 and AES-256 fill the device, AES-128's working
+    sets do not fit and it has no tables of its own to give back.  Its request must not fail for the sake of another circuit's
+    optimisation: the least recently used idle neighbour (ChaCha20) gives its comb tables back (cabi.cpp release_neighbours,
+    prover.hip relieve_pressure) and continues on the bucket pipeline; every request of every circuit is answered in both rounds."""
+    res = subprocess.run([sys.executable, "-c", _THREE_SCRIPT.format(root=H.ROOT)], capture_output=True, text=True, timeout=1500)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert all(v == 2048 for v in out["ok"].values()) and len(out["ok"]) == 6, (out, res.stderr[-3000:])
+    assert out["comb_before"] == {"0": 1, "2": 1}, out
+    assert out["comb_after"]["0"] == 0, out                     # ChaCha20 was used least recently
+    assert "comb tables" in res.stderr and "released" in res.stderr
+
 _SHARD_SCRIPT = r"""
 import base64, importlib, json, os, sys, threading
 sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))

@@ -1,6 +1,7 @@
 // C ABI of libzkprove.so (include/zkprove.h): the reference's cgo surface
 // (gnark/libraries/prover/libprove.go:18-86) plus the registry / request handling of
 // gnark/libraries/prover/impl/library.go:17-160 and impl/provers.go:48-280, re-implemented in C++.
+#include <algorithm>
 #include <string.h>
 #include <memory>
 #include <mutex>
@@ -258,6 +259,26 @@ std::vector<Algorithm *> get_replicas(int id) {
     for (auto &r : g_slots[id].replicas) out.push_back(r.get());
     return out;
 }
+
+// Algorithm::neighbours_release: idle algorithms on the requester's device give their comb tables back (prover.hip, relieve_pressure).
+// Slots that are being initialised or reset right now (lock held) are skipped.
+// ONE algorithm per call, the least recently used first (the caller retries its allocation and comes back if that was not enough).
+bool release_neighbours(Algorithm *self) {
+    std::vector<std::unique_lock<std::mutex>> held;
+    std::vector<Algorithm *> cand;
+    for (auto &slot : g_slots) {
+        std::unique_lock<std::mutex> lk(slot.lock, std::try_to_lock);
+        if (!lk) continue;
+        for (auto &r : slot.replicas)
+            if (r.get() != self && r->device == self->device && r->comb_table_bytes() != 0) cand.push_back(r.get());
+        held.push_back(std::move(lk));
+    }
+    std::sort(cand.begin(), cand.end(), [](const Algorithm *a, const Algorithm *b) { return a->last_use.load() < b->last_use.load(); });
+    for (Algorithm *a : cand)
+        if (a->release_comb_if_idle()) return true;
+    return false;
+}
+const bool g_hook_set = [] { Algorithm::neighbours_release = release_neighbours; return true; }();
 
 std::string response_json(const std::vector<uint8_t> &proof, const std::vector<uint8_t> &ct) {
     return "{\"proof\":\"" + base64_encode(proof.data(), proof.size()) + "\",\"ciphertext\":\"" + base64_encode(ct.data(), ct.size()) + "\"}";

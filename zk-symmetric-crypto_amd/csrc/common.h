@@ -23,6 +23,10 @@ struct ZkError : public std::runtime_error {
     } while (0)
 
 // RAII device buffer
+// A large allocation must leave DEVICE_HEADROOM free: a device run down to its last megabyte cannot give the next kernel its scratch
+// memory, and the HIP runtime aborts the process for that (HSA_STATUS_ERROR_OUT_OF_RESOURCES) instead of returning an error.  Throws
+// ZkError like a failed hipMalloc, so the memory-pressure valves (prover.hip, relieve_pressure) see both the same way.
+void require_headroom(size_t bytes);
 void memlog_large_alloc(size_t bytes);      // hostutil.cpp: ZKPROVE_MEMLOG=1 prints allocations >= 256 MiB with their call sites
 template <class T>
 struct DevBuf {
@@ -40,6 +44,7 @@ struct DevBuf {
     ~DevBuf() { release(); }
     void alloc(size_t count) {
         release();
+        if (count * sizeof(T) >= ((size_t)256 << 20)) require_headroom(count * sizeof(T));
         if (count) ZK_HIP(hipMalloc((void **)&p, count * sizeof(T)));      // throws on failure with the buffer left empty (n = 0)
         n = count;
         if (count * sizeof(T) >= ((size_t)256 << 20)) memlog_large_alloc(count * sizeof(T));

@@ -464,6 +464,13 @@ U256 hash_to_fr(const uint8_t *msg, size_t len, const char *dst) {
 // ---- ZKPROVE_MEMLOG=1: device allocations >= 256 MiB with the frames that asked for them (sizing the HBM budget)
 #include <execinfo.h>
 namespace zk {
+void require_headroom(size_t bytes) {
+    constexpr size_t DEVICE_HEADROOM = (size_t)4 << 30;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (free_b < bytes + DEVICE_HEADROOM)
+        throw ZkError("out of device memory: " + std::to_string(bytes >> 20) + " MiB asked, " + std::to_string(free_b >> 20) + " MiB free (4096 MiB are kept for the runtime)");
+}
 void memlog_large_alloc(size_t bytes) {
     static const bool on = getenv("ZKPROVE_MEMLOG") != nullptr;
     if (!on) return;

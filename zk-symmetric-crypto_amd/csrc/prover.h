@@ -4,6 +4,7 @@
 // Replaces groth16.Prove(r1cs, pk, witness) of gnark v0.14 (call sites
 // gnark/libraries/prover/impl/provers.go:179,269) and ProvingKey.ReadFrom (impl/library.go:104-109).
 #pragma once
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include "hostutil.h"
@@ -90,6 +91,7 @@ class Algorithm {
     struct Resident;
     void upload_set(struct SolveSet &S, size_t B, const uint32_t *inputs, const U256 *r, const U256 *s, const U256 *randomize, hipStream_t st);
     void ensure_second_set(int nsets = 2);
+    void ensure_second_set_once(int nsets);
     void enqueue_solve(struct SolveSet &S, MsmScratch &commit_scratch, hipStream_t st);
     void enqueue_main(struct SolveSet &S, hipStream_t st, hipEvent_t before_msm, hipStream_t tail);
     bool ahead_eligible() const;
@@ -108,6 +110,13 @@ class Algorithm {
     bool comb_drop_tables();
     void resident_reserve_buffers(size_t B);
     bool comb_release();                                    // out of memory: give the comb tables back, continue on the bucket pipeline                            // lazy table build + scratch (resident_reserve)
+    // Memory pressure across algorithms: the hook (set by cabi.cpp, which owns the registry) asks every OTHER algorithm on this device
+    // that is idle right now to give its comb tables back (release_comb_if_idle); true when something was freed
+    static bool (*neighbours_release)(Algorithm *self);
+    bool release_comb_if_idle();
+    size_t comb_table_bytes() const;                        // quotient + wire comb tables held right now
+    std::atomic<uint64_t> last_use{0};                      // stamp of the last proving call (prove_batch / prove_stream)
+    bool relieve_pressure(bool rereserve);                  // own tables first (rereserve: + the bucket pipeline's buffers, comb_release), one idle neighbour's next
     void enqueue_ntt_sort(struct SolveSet &S, hipStream_t sn, int slot, hipEvent_t slot_free = nullptr);
     hipStream_t side_chain_stream(hipStream_t solve_stream, struct SolveSet &S);
     void enqueue_tail_early(struct SolveSet &S, hipStream_t st);

@@ -624,6 +624,7 @@ void Algorithm::wire_comb_reserve(MsmScratch &sc, bool main_set, size_t B) {
 }
 
 // ------------------------------------------------------------------------------- pipeline
+static std::atomic<uint64_t> g_use_clock{0};      // Algorithm::last_use stamps (least recently used algorithm gives its tables back first)
 void Algorithm::resident_reserve(size_t B) {
     DeviceScope on_device(device);
     if (!res) {
@@ -650,13 +651,15 @@ void Algorithm::resident_reserve(size_t B) {
     }
     Resident &R = *res;
     const size_t cap_before = R.cap;
-    try {
-        resident_reserve_buffers(B);
-    } catch (const ZkError &) {
-        (void)hipGetLastError();
-        R.cap = cap_before;
-        if (!comb_drop_tables()) throw;             // memory-pressure valve, see comb_release
-        resident_reserve_buffers(B);
+    for (int attempt = 0;; attempt++) {
+        try {
+            resident_reserve_buffers(B);
+            break;
+        } catch (const ZkError &) {
+            (void)hipGetLastError();
+            R.cap = cap_before;
+            if (attempt >= 5 || !relieve_pressure(false)) throw;      // memory-pressure valve, see comb_release
+        }
     }
 }
 void Algorithm::resident_reserve_buffers(size_t B) {
@@ -719,12 +722,12 @@ void Algorithm::resident_reserve_buffers(size_t B) {
     const size_t nbz = (size_t)1 << (pk.Z.c - 1), ez = pk.Z.n * (size_t)pk.Z.W;
     const size_t Bd = pk.Zcomb.ok ? std::min(B, SIDE_G2_MAX_B) : B;
     if (R.dense_cap < Bd) {
-        R.dense_cap = Bd;
         R.ms.reserve(Bd, ez, nbz, msm_part_stride(pk.Z.n, pk.Z.c));
         R.ms.reserve_dense(Bd, ez, nbz);
         if (Bd > SIDE_G2_MAX_B) R.ms.reserve_dense_second(Bd, ez, nbz);      // ahead mode, enqueue_ntt_sort
         R.ms.reserve_tree(Bd, ez, nbz);
         R.ms.reserve_sums(Bd, nbz, 1);
+        R.dense_cap = Bd;               // only now: an allocation above may throw, and the retry (resident_reserve) must come back here
     }
     for (auto &st : R.set) st.sb.B = B;
     R.ms.B = B; R.ms2.B = B;
@@ -1051,19 +1054,52 @@ bool Algorithm::comb_release() {
     resident_reserve(res->cap);                    // the bucket pipeline's buffers for the reserved batch size
     return true;
 }
+// A third circuit with large batches on a GPU whose memory two circuits' tables and working sets already fill: its working sets do not
+// fit and it has no tables of its own to give back.  The tables of the algorithms that are idle at that moment go instead (they continue
+// on the bucket pipeline; the log line says so) -- a request must not fail for the sake of another circuit's optimisation.
+bool (*Algorithm::neighbours_release)(Algorithm *self) = nullptr;
+bool Algorithm::release_comb_if_idle() {
+    std::unique_lock<std::mutex> lk(mu, std::try_to_lock);
+    if (!lk || !res) return false;
+    DeviceScope on_device(device);
+    try {
+        return comb_release();
+    } catch (...) {
+        (void)hipGetLastError();
+        return false;
+    }
+}
+size_t Algorithm::comb_table_bytes() const {
+    size_t b = pk.Zcomb.table.bytes();
+    for (const MsmBasesG1 *mb : {&pk.A, &pk.B1, &pk.K, &pk.ped, &pk.ped_sigma})
+        for (const auto &c : mb->wcomb) b += c->table.bytes();
+    for (const auto &c : pk.B2.wcomb) b += c->table.bytes();
+    return b;
+}
+bool Algorithm::relieve_pressure(bool rereserve) {
+    if (rereserve ? comb_release() : comb_drop_tables()) return true;
+    return neighbours_release && neighbours_release(this);
+}
 
 // the second working set (and the separate scratch of its commitment MSMs) exists only once a pipelined entry is used
 void Algorithm::ensure_second_set(int nsets) {
+    // every allocation below is "grow if smaller": after a failure the memory-pressure valve (own comb tables, then one idle
+    // neighbour's per round) makes room and the whole reservation is simply repeated
+    for (int attempt = 0;; attempt++) {
+        try {
+            ensure_second_set_once(nsets);
+            return;
+        } catch (const ZkError &) {
+            (void)hipGetLastError();
+            if (attempt >= 5 || !relieve_pressure(true)) throw;
+        }
+    }
+}
+void Algorithm::ensure_second_set_once(int nsets) {
     Resident &R = *res;
     for (int i = 1; i < nsets; i++) {
         if (R.set[i].ready) continue;
-        try {
-            R.set[i].reserve(prog, R.cap);
-        } catch (const ZkError &) {
-            (void)hipGetLastError();
-            if (!comb_release()) throw;
-            R.set[i].reserve(prog, R.cap);
-        }
+        R.set[i].reserve(prog, R.cap);
         R.set[i].sb.B = R.B;
         SolveSet &a = R.set[0], &b = R.set[i];
         ZK_HIP(hipMemcpy(b.sb.inputs.p, a.sb.inputs.p, prog.n_inputs * R.B * sizeof(uint32_t), hipMemcpyDeviceToDevice));
@@ -1221,6 +1257,7 @@ void Algorithm::resident_download(ProofPoints *out, uint32_t *errs) {
 void Algorithm::prove_batch(size_t batch, const uint32_t *inputs, const U256 *r, const U256 *s, const U256 *randomize, ProofPoints *out,
                             uint32_t *errs, PhaseTimes *times) {
     std::unique_lock<std::mutex> lk(mu);
+    last_use = ++g_use_clock;
     DeviceScope on_device(device);
     const size_t ni = prog.n_inputs;
     const size_t nchunks = (batch + max_chunk - 1) / max_chunk;
@@ -1257,6 +1294,7 @@ void Algorithm::prove_batch(size_t batch, const uint32_t *inputs, const U256 *r,
 // and downloads on the copy stream.  The feed is asked for chunk k only after chunk k-NS has been handed back.
 void Algorithm::prove_stream(ChunkFeed &feed, PhaseTimes *times) {
     std::lock_guard<std::mutex> lk(mu);
+    last_use = ++g_use_clock;
     DeviceScope on_device(device);
     resident_reserve(max_chunk);
     Resident &R = *res;
