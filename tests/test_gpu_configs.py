@@ -412,6 +412,17 @@ def test_a_third_circuit_takes_the_idle_neighbours_tables():
     assert out["comb_after"]["0"] == 0, out                     # ChaCha20 was used least recently
     assert "comb tables" in res.stderr and "released" in res.stderr
 
+def test_two_ciphers_streamed_at_the_same_time():
+    """Two host threads, one streamed ProveBatch call each (ChaCha20 and AES-256, 3 000 requests = three device chunks), at the same time,
+    twice: the algorithms share the device, the pinned chunk pool and (HIP multiplexes streams) hardware queues -- every request of both
+    calls is answered, the sampled proofs verify (scripts/debug/two_ciphers_concurrent.py)."""
+    res = subprocess.run([sys.executable, os.path.join(H.ROOT, "scripts", "debug", "two_ciphers_concurrent.py")], capture_output=True, text=True, timeout=1200)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [json.loads(l) for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 2, res.stdout[-2000:]
+    for ln in lines:
+        assert ln["alg0"] == dict(ln["alg0"], ok=3000, of=3000) and ln["alg2"] == dict(ln["alg2"], ok=3000, of=3000), ln
+
 _SHARD_SCRIPT = r"""
 import base64, importlib, json, os, sys, threading
 sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
