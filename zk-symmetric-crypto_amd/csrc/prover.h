@@ -101,6 +101,9 @@ class Algorithm {
     std::vector<uint32_t> calib_inputs;                     // [n][n_inputs]
     std::vector<U256> calib_rnd;                            // [n] Randomize hint values
     bool wire_comb_tried = false, wire_comb_on = false;
+    bool comb_dropped = false;          // the tables went under memory pressure: the next proving call looks at the budget again (comb_second_chance)
+    int comb_rebuilds = 0;              // ... at most twice in an algorithm's life (a build costs seconds: no ping-pong between circuits)
+    void comb_second_chance();
     void wire_comb_prepare(size_t B);
     void wire_comb_reserve(MsmScratch &sc, bool main_set, size_t B);
     void debug_leftovers(long *out3);                       // {sum, max, instances with any} of the compact bucket-pipeline list left by the last main-stream wire MSM

@@ -513,7 +513,8 @@ void Algorithm::comb_prepare(size_t B) {
         // table's clump count x 254 x B words: bounded by the k = 12 figure), range accumulators, and slack for the allocator
         const size_t N = (size_t)1 << prog.log_domain;
         const size_t per_set = B * (prog.n_wires + 3 * N) * sizeof(Fr);
-        const size_t still_needed = 2 * per_set + 2 * ((pk.ze.n / 16 + 1) * 254 * B * sizeof(uint32_t)) + ((size_t)6 << 30);
+        const size_t sets_to_come = (R.set[1].ready ? 0 : 1) + (R.set[2].ready ? 0 : 1);      // (a second chance after a release finds them in place)
+        const size_t still_needed = sets_to_come * per_set + 2 * ((pk.ze.n / 16 + 1) * 254 * B * sizeof(uint32_t)) + ((size_t)6 << 30);
         const int k = comb_pick_k(pk.ze.n, still_needed, comb_share);
         bool ok = false;
         std::string why = "not enough free device memory";
@@ -1046,8 +1047,19 @@ bool Algorithm::comb_drop_tables() {
     for (MsmBasesG1 *mb : {&pk.A, &pk.B1, &pk.K, &pk.ped, &pk.ped_sigma}) { mb->wcomb.clear(); mb->wide_mask.release(); }
     pk.B2.wcomb.clear(); pk.B2.wide_mask.release();
     wire_comb_on = false;
+    comb_dropped = true;
     fprintf(stderr, "zkprove: out of device memory: comb tables (%zu MiB) released, this algorithm continues on the bucket pipeline\n", mib);
     return true;
+}
+// Tables that went under pressure are not gone for good: when this algorithm is next asked to prove -- the pressure has passed, every
+// circuit's working sets exist -- the budget (comb_pick_k: what is free beyond this algorithm's own needs) is consulted once more and
+// builds what fits, possibly a smaller clump size.  Twice per algorithm at most.
+void Algorithm::comb_second_chance() {
+    if (!comb_dropped || comb_rebuilds >= 2) return;
+    comb_dropped = false;
+    comb_rebuilds++;
+    pk.comb_tried = false;
+    wire_comb_tried = false;
 }
 bool Algorithm::comb_release() {
     if (!comb_drop_tables()) return false;
@@ -1258,6 +1270,7 @@ void Algorithm::prove_batch(size_t batch, const uint32_t *inputs, const U256 *r,
                             uint32_t *errs, PhaseTimes *times) {
     std::unique_lock<std::mutex> lk(mu);
     last_use = ++g_use_clock;
+    comb_second_chance();
     DeviceScope on_device(device);
     const size_t ni = prog.n_inputs;
     const size_t nchunks = (batch + max_chunk - 1) / max_chunk;
@@ -1295,6 +1308,7 @@ void Algorithm::prove_batch(size_t batch, const uint32_t *inputs, const U256 *r,
 void Algorithm::prove_stream(ChunkFeed &feed, PhaseTimes *times) {
     std::lock_guard<std::mutex> lk(mu);
     last_use = ++g_use_clock;
+    comb_second_chance();
     DeviceScope on_device(device);
     resident_reserve(max_chunk);
     Resident &R = *res;
