@@ -279,6 +279,15 @@ bool release_neighbours(Algorithm *self) {
     return false;
 }
 const bool g_hook_set = [] { Algorithm::neighbours_release = release_neighbours; return true; }();
+// HIP multiplexes all streams of the process over GPU_MAX_HW_QUEUES hardware queues (default 4).  One algorithm uses four streams; with
+// two or three circuits loaded their streams share queues, which costs nothing in throughput (the chunk loops submit in an order that
+// tolerates it) but serialises the parallel chains of a one-proof call: AES-256 Prove() 18.6 ms at 4 queues, 17.3 at 8, 16.9 at 16 with
+// ChaCha20 loaded beside it.  Set at load time, before this library's first HIP call, unless the host chose a value itself (or
+// initialised HIP earlier: then it has no effect).  ZKPROVE_KEEP_HW_QUEUES=1 leaves the environment alone.
+const bool g_hw_queues_set = [] {
+    if (!getenv("ZKPROVE_KEEP_HW_QUEUES")) setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    return true;
+}();
 
 std::string response_json(const std::vector<uint8_t> &proof, const std::vector<uint8_t> &ct) {
     return "{\"proof\":\"" + base64_encode(proof.data(), proof.size()) + "\",\"ciphertext\":\"" + base64_encode(ct.data(), ct.size()) + "\"}";

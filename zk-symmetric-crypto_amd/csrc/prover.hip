@@ -906,6 +906,19 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm,
     const bool side = B <= SIDE_G2_MAX_B;
     hipStream_t sk = R.stream2;
     if (side) {
+        // the G2 chain first: MSM, blinding s*delta2, Fp2 inversion -- the longest of the tail's chains (5 ms for one AES proof), and on
+        // a one-proof batch the HOST needs a millisecond to submit the launches of the other chains
+        {
+            hipStream_t g2s = R.copy_stream;      // idle in single-chunk calls
+            ZK_HIP(hipStreamWaitEvent(g2s, R.ev[3], 0));
+            if (before_msm) ZK_HIP(hipStreamWaitEvent(g2s, before_msm, 0));
+            ZK_HIP(hipEventRecord(R.ev[5], g2s));
+            msm_batch(pk.B2, S.sb.wires.p, B, R.ms_g2, R.m_bs2.p, g2s);
+            if (split_world == 1)
+                hipLaunchKernelGGL(k_finalize_g2, dim3(ceil_div(B, 64)), dim3(64), 0, g2s, R.m_bs2.p, pk.g2_misc.p, pk.delta2_tab.p, S.s.p, S.out.p, B);
+            ZK_HIP(hipEventRecord(R.ev[6], g2s));               // (the tail stream joins it below, behind its own chain)
+            R.last_g2_side = true;                // phase times: msm_g1 = the main stream from its first MSM to the end (collect_times)
+        }
         ZK_HIP(hipStreamWaitEvent(sk, R.ev[3], 0));
         dom.dif(S.sb.b.p, B, true, nullptr, sk);
         dom.dit(S.sb.b.p, B, false, dom.coset_pre.p, sk);
@@ -949,23 +962,19 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm,
         ZK_HIP(hipStreamWaitEvent(tail, R.ev[12], 0));
         if (split_world == 1) enqueue_tail_early(S, tail);
     }
-    ZK_HIP(hipEventRecord(R.ev[5], st));
-    // the G2 sum next, so that its blinding and affine conversion also run under the two largest MSMs.  A small batch is a chain of
-    // latency-bound kernels: there the G2 chain gets its own stream and scratch and runs beside the K / Z chains
-    hipStream_t g2 = side ? R.copy_stream : st;      // the copy stream is idle in single-chunk calls
-    if (side) {          // wires only: may start with the transforms
-        ZK_HIP(hipStreamWaitEvent(g2, R.ev[3], 0));
-        if (before_msm) ZK_HIP(hipStreamWaitEvent(g2, before_msm, 0));
+    // the G2 sum next, so that its blinding and affine conversion also run under the two largest MSMs.  (A small batch is a set of
+    // latency-bound chains: its G2 chain -- MSM and tail, which used to queue behind the G1 tail's two variable-base multiplications:
+    // one Prove() call 7.4 -> 6.5 ms -- went to the copy stream at the top.)
+    if (!side) {
+        ZK_HIP(hipEventRecord(R.ev[5], st));
+        msm_batch(pk.B2, S.sb.wires.p, B, R.ms, R.m_bs2.p, st);
+        ZK_HIP(hipEventRecord(R.ev[6], st));
+        ZK_HIP(hipStreamWaitEvent(tail, R.ev[6], 0));
+        if (split_world == 1)
+            hipLaunchKernelGGL(k_finalize_g2, dim3(ceil_div(B, 64)), dim3(64), 0, tail, R.m_bs2.p, pk.g2_misc.p, pk.delta2_tab.p, S.s.p, S.out.p, B);
+    } else {
+        ZK_HIP(hipStreamWaitEvent(tail, R.ev[6], 0));
     }
-    msm_batch(pk.B2, S.sb.wires.p, B, side ? R.ms_g2 : R.ms, R.m_bs2.p, g2);
-    // small batch: the G2 tail (fixed-base s*delta2, Fp2 inversion: 1 ms of latency for a single proof) stays on the side stream, beside
-    // the two variable-base multiplications of the G1 tail (2.6 ms) instead of behind them -- one Prove() call 7.4 -> 6.4 ms
-    if (side && split_world == 1)
-        hipLaunchKernelGGL(k_finalize_g2, dim3(ceil_div(B, 64)), dim3(64), 0, g2, R.m_bs2.p, pk.g2_misc.p, pk.delta2_tab.p, S.s.p, S.out.p, B);
-    ZK_HIP(hipEventRecord(R.ev[6], g2));
-    ZK_HIP(hipStreamWaitEvent(tail, R.ev[6], 0));
-    if (!side && split_world == 1)
-        hipLaunchKernelGGL(k_finalize_g2, dim3(ceil_div(B, 64)), dim3(64), 0, tail, R.m_bs2.p, pk.g2_misc.p, pk.delta2_tab.p, S.s.p, S.out.p, B);
     if (!side) msm_batch(pk.K, S.sb.wires.p, B, R.ms, R.m_k.p, st);
     // sum_k h_k Z_k = sum_i (a_i b_i) Ze_i + (a part linear in the wires that sits in K); c only serves as the buffer of the
     // instance-major products
