@@ -116,6 +116,27 @@ def profile_manifest():
     return m
 
 
+def same_box_microbench(zk):
+    """The ceilings `roofline` divides by, measured on THIS box right after the timed regions (boxes of the pool differ by ~5 %):
+    back-to-back G1 mixed additions on the walk's field (every lane busy, no memory) and the v_mad_i64_i32 issue rate -- about a second
+    of device time.  Through the test library (libzkprove_test.so: same objects as the product + csrc/test_api.hip)."""
+    out = {}
+    try:
+        t = zk.testlib
+        for kind, name, per_iter, iters in ((8, "g1_mixed_add_per_s", 1, 400), (7, "fp_mul_per_s", 2, 2000), (10, "v_mad_i64_i32_per_s", 64, 2000)):
+            best = 0.0
+            for threads in (256 * 256 * 4, 256 * 256 * 8):
+                ms = t.zkp_microbench(kind, threads, iters)
+                if ms > 0:
+                    best = max(best, threads * iters * per_iter / ms * 1e3)
+            out[name] = best
+        out["g1_mixed_add_isa_ceiling_per_s"] = out["v_mad_i64_i32_per_s"] / 1467.0
+        out["file"] = "measured by this run (zkp_microbench kinds 8, 7, 10 after the timed regions)"
+    except Exception as e:
+        return {"error": repr(e)}
+    return out
+
+
 def roofline_objects(alg, B, mean, value_per_gpu, manifest, zinfo, ntt_alone_ms=None):
     """zinfo = zkp_quotient_msm_info of the resident batch: [comb?, k | c, clumps | windows, table MiB, mixed additions per proof]"""
     zdur_ms = mean.get("z_segments", 0.0) or mean["msm_g1"]
@@ -133,7 +154,7 @@ def roofline_objects(alg, B, mean, value_per_gpu, manifest, zinfo, ntt_alone_ms=
             traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command line; collected at commit %s -- not measured by this run)" % (pm["file"], manifest.get("commit", "?"))
         except Exception:
             traffic = None
-    mb = manifest.get("microbench", {})
+    mb = manifest.get("microbench_same_box") or manifest.get("microbench", {})
     if comb:
         kernel = "k_comb_walk (quotient MSM over G1.Z as a fixed-base bit-plane comb, csrc/msm_comb.hip: clumps of k = %d bases, %d clumps, %d MiB of signed subset-sum tables)" % (zinfo[1], zinfo[2], zinfo[3])
         how = ("every proof costs clumps x 254 = %d mixed additions (one per clump and bit plane; no sort, no buckets, no reduction)" % zinfo[4])
@@ -203,6 +224,9 @@ def run_rank(args):
         return selftest_rank(args, rank, world)
 
     sys.path.insert(0, ROOT)
+    # eight hardware queues for the process (two circuits x four streams): the HOST application's choice, made before anything
+    # initialises HIP -- the library itself never touches the environment (include/zkprove.h, ZkpSetHardwareQueues)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     # stdout must carry exactly ONE JSON line: everything else that writes to fd 1 (the library mirrors the reference's
     # "Initialized <alg>" println, RCCL banners, ...) is sent to stderr; the JSON goes to the saved descriptor at the end
     import ctypes
@@ -364,6 +388,10 @@ def run_rank(args):
 
     if rank == 0:
         lines = {}
+        if world == 1:
+            mb_here = same_box_microbench(zk)
+            if "error" not in mb_here:
+                manifest = dict(manifest, microbench_same_box=mb_here)
         for alg, leg, r in algs:
             value = B * world * K / r["dt"]
             zinfo = np.zeros(8, np.int64)

@@ -5,7 +5,8 @@
  * Section 1 is byte-compatible with the header cgo generates for libprove.go; the JS operator
  * (js/src/gnark/operator.ts:14-47) can load this library unmodified.
  * Section 2 are additive extensions (batching, deterministic blinding, device-resident benchmark).
- * Section 3 are kernel-level entry points used by the parity tests.
+ * Nothing else is exported (linker version script generated from this header).  The kernel-level entry points of the parity tests
+ * and the micro-benchmarks live in a library of their own, libzkprove_test.so (include/zkprove_test.h), built from the same objects.
  */
 #ifndef ZKPROVE_H
 #define ZKPROVE_H
@@ -75,12 +76,29 @@ void ZkpAllowUnpinnedKeys(int allow);
  * ZkpDeviceReplicas(id) = number of device replicas of an initialised algorithm (0 = not initialised). */
 int ZkpSetDevice(int device);
 int ZkpDeviceReplicas(int algorithmID);
+/* HIP multiplexes the streams of a process over GPU_MAX_HW_QUEUES hardware queues (default 4); one algorithm uses four streams, so with
+ * two or three circuits loaded the parallel chains of a single Prove() share queues (AES-256: 18.6 ms at 4 queues, 17.3 at 8).  The library
+ * does not touch the environment by itself; this call sets GPU_MAX_HW_QUEUES=n for the process and only has an effect BEFORE the
+ * first HIP call of the process (exporting the variable before start-up is equivalent).  Returns 0, -1 for n outside 1..64. */
+int ZkpSetHardwareQueues(int n);
 /* Drop all initialised algorithms (frees HBM). */
 void ZkpReset(void);
 /* params = JSON array of Prove requests (all for the same cipher); returns a JSON array of Prove
  * responses.  One GPU batch per call: this is how callers reach GPU throughput, since the reference
  * FFI is synchronous (utils.ts:200-212; benchmark.ts:30-34 is effectively serial). */
 ProveReturn ProveBatch(GoSlice params);
+/* Inner boundary: the single third-party call of the reference's provers, groth16.Prove(cp.r1cs, cp.pk, wtns)
+ * (gnark/libraries/prover/impl/provers.go:179 ChaCha20, :269 AES; SURVEY.md section 8b "inner boundary"), for a Go host that keeps its
+ * own request handling and witness construction (frontend.NewWitness, provers.go:175,265).
+ *   witness = wtns.MarshalBinary(): u32 nbPublic | u32 nbSecret | u32 n | n x 32-byte big-endian canonical field elements (public
+ *             part first, without the constant-one wire), all big-endian -- gnark v0.14 backend/witness.
+ *   returns   r1 >= 0: r0 = gProof.WriteTo bytes (164 B ChaCha20 / 196 B AES: what gProof.ReadFrom takes), r1 = their length;
+ *             r1 <  0: r0 = UTF-8 error text of length -r1 (what groth16.Prove would have returned as `error`: witness of the wrong
+ *                      shape, "constraint #n is not satisfied", algorithm not initialised).  Release r0 with Free either way.
+ * Blinding r, s and the value of the AES circuits' hints.Randomize wire come from /dev/urandom as in gnark (crypto/rand);
+ * ZkpProveWitnessDeterministic fixes them (canonical little-endian 32-byte scalars, NULL = zero) for parity tests. */
+ProveReturn ZkpProveWitness(unsigned char algorithmID, GoSlice witness);
+ProveReturn ZkpProveWitnessDeterministic(unsigned char algorithmID, GoSlice witness, const uint8_t *r32, const uint8_t *s32, const uint8_t *randomize32);
 /* Prove with caller-supplied blinding (canonical little-endian 32-byte scalars r, s and the value of the
  * AES circuits' hints.Randomize wire; may be NULL = zero).  gnark samples these from crypto/rand, which is
  * the only source of non-determinism in a proof; fixing them makes proofs reproducible for parity tests. */
@@ -136,45 +154,11 @@ long zkp_proof_serialize(const uint8_t *proof384, int has_commitment, uint8_t *o
  * instructions, calldata words, levels, coefficients */
 int zkp_r1cs_stats(GoSlice r1cs, uint64_t *stats8);
 
-/* ---------------------------------------------------------------- 3. kernel-level entry points */
+/* last error text of this thread (InitAlgorithm / bench / witness-level entries); zkp_last_panic: the reference-style panic value of
+ * the last failed zkp_request_witness on this thread */
 const char *zkp_last_error(void);
+const char *zkp_last_panic(void);
 int zkp_device_count(void);
-/* data: [batch][2^logn][32] canonical LE; mode 0 fwd (DIF kernels) 1 inv (DIF) 2 fwd (DIT) 3 inv (DIT) */
-int zkp_ntt(int logn, long batch, uint8_t *data, int mode);
-#ifdef ZK_EXPERIMENTS   /* only in libzkprove_exp.so (make experiments): gnark's unfolded 7-transform computeH, which the product does not run */
-/* computeH: a,b,c [batch][ncons][32] -> h [batch][2^logn][32] (natural coefficient order) */
-int zkp_compute_h(int logn, long batch, long ncons, const uint8_t *a, const uint8_t *b, const uint8_t *c, uint8_t *h_out);
-#endif
-/* points n*64 (G1: x|y) / n*128 (G2: x.a0|x.a1|y.a0|y.a1) canonical LE; scalars [batch][n][32]; c = window bits */
-int zkp_msm_g1(long n, long batch, const uint8_t *points, const uint8_t *scalars, uint8_t *out, int c);
-int zkp_msm_g2(long n, long batch, const uint8_t *points, const uint8_t *scalars, uint8_t *out, int c);
-/* same as zkp_msm_g1 through the dense (quotient-MSM) sort path: no 0/+-1 fast path, two-level sort when c >= 9 */
-int zkp_msm_g1_dense(long n, long batch, const uint8_t *points, const uint8_t *scalars, uint8_t *out, int c);
-/* wire MSM (0 / +-1 fast path + bucket pipeline) with a wire comb attached: cls[n] = width class of each base's scalars (0: 0 / +-1,
- * 1: < 2^8, 2: < 2^32, 3: any); group 1 = G1, 2 = G2; values wider than their class must still give the right sum (bucket hand-over) */
-int zkp_msm_wire_comb(int group, long n, long batch, const uint8_t *points, const uint8_t *scalars, uint8_t *out, int c, int k, const uint8_t *cls);
-/* same sum through the fixed-base bit-plane comb of the quotient MSM of large batches (csrc/msm_comb.hip): clumps of k bases, table
- * of their signed subset sums; mode 1 passes the scalars as products of two matrices (the prover's call shape).
- * returns 0, or 1 when the bases are degenerate for the comb (point at infinity, coinciding subset sum) and nothing was computed */
-int zkp_msm_comb(long n, long batch, const uint8_t *points, const uint8_t *scalars, uint8_t *out, int k, int mode);
-/* timing of the comb path at production shape (2^logn synthetic bases, pseudo-random scalars): out_ms[5] = table build, patterns,
- * walk, fold, table GiB */
-int zkp_bench_comb(int logn, long batch, int k, int iters, double *out_ms);
-/* Key folding done at InitAlgorithm (csrc/keyfold.hip): pk.G1.Z (2^logn - 1 points, 64 B canonical LE x|y each) ->
- * ze[i] = 1/(N D) sum_k w^-ik g^-k Z_k (2^logn points) and zc[j] = -1/(N D) sum_k w^-jk Z_k (ncons points), D = g^N - 1;
- * replaces the last four transforms of gnark's computeH (backend/groth16/bn254/prove.go) per proof. */
-int zkp_fold_quotient_bases(int logn, long ncons, const uint8_t *z, uint8_t *ze, uint8_t *zc);
-/* second half of the folding: K'_w = K_w + sum_{terms of wire w} coeffs[coeff] * zc[cons] (the R1CS output matrix applied to zc).
- * k: the points of the wires rows_k (ascending); terms: (wire, cons, coeff index) u32 triples.  Returns the number of folded rows
- * written to out_rows / out_points (union of rows_k and the term wires, ascending), -1 on error. */
-long zkp_fold_output_matrix(long nzc, const uint8_t *zc, long nk, const uint8_t *k, const uint32_t *rows_k, long nterms, const uint32_t *terms,
-                            long ncoeff, const uint8_t *coeffs, uint32_t *out_rows, uint8_t *out_points);
-/* device time (ms) of the prover's transform stage -- inverse + coset-forward NTT of two [2^logn][batch] matrices -- mean of iters runs */
-double zkp_bench_to_coset(int logn, long batch, int iters);
-/* field 0 = Fp, 1 = Fr; in / out: n canonical LE 32-byte elements; out[i] = in[i]^-1 (0 -> 0) by the device's binary-GCD inversion */
-int zkp_field_inv(int field, long n, const uint8_t *in, uint8_t *out);
-/* kind 0: Fp mul (2/iter) 1: G1 mixed add 2: G2 mixed add 3: Fp Fermat inversion 4: Fp binary-GCD inversion; returns milliseconds */
-double zkp_microbench(int kind, long threads, int iters);
 
 #ifdef __cplusplus
 }

@@ -157,24 +157,39 @@ static void sha256(const uint8_t *msg, size_t len, uint8_t out[32]) {
 }
 void oracle_sha256(const uint8_t *msg, long len, uint8_t *out) { sha256(msg, (size_t)len, out); }
 
-/* RFC 9380 expand_message_xmd(SHA-256) + gnark-crypto fr.Hash(msg, dst, 1): 48 bytes -> BE int mod r.
+/* RFC 9380 section 5.3.1 expand_message_xmd, H = SHA-256 (b_in_bytes 32, s_in_bytes 64): out_len uniform bytes.
+ * Pinned against the RFC's published vectors (appendix K.1) by tests/test_pins.py.  Returns 0, -1 when out of the RFC's limits. */
+static int expand_message_xmd(const uint8_t *msg, size_t mlen, const uint8_t *dst, size_t dlen, uint8_t *out, size_t out_len) {
+    size_t ell = (out_len + 31) / 32;
+    if (ell > 255 || out_len > 65535 || dlen > 255) return -1;
+    size_t blen = 64 + mlen + 2 + 1 + dlen + 1;
+    uint8_t *b = (uint8_t *)calloc(blen, 1);                      /* Z_pad || msg || l_i_b_str || 0 || DST_prime */
+    memcpy(b + 64, msg, mlen);
+    b[64 + mlen] = (uint8_t)(out_len >> 8); b[64 + mlen + 1] = (uint8_t)out_len; b[64 + mlen + 2] = 0;
+    memcpy(b + 64 + mlen + 3, dst, dlen); b[64 + mlen + 3 + dlen] = (uint8_t)dlen;
+    uint8_t b0[32], bi[32];
+    sha256(b, blen, b0); free(b);
+    uint8_t t[32 + 1 + 255 + 1];
+    memcpy(t + 33, dst, dlen); t[33 + dlen] = (uint8_t)dlen;
+    memset(bi, 0, 32);
+    for (size_t i = 1; i <= ell; i++) {                           /* b_i = H((b_0 xor b_(i-1)) || i || DST_prime), b_0 xor 0 for i = 1 */
+        for (int k = 0; k < 32; k++) t[k] = b0[k] ^ bi[k];
+        t[32] = (uint8_t)i;
+        sha256(t, 34 + dlen, bi);
+        size_t off = 32 * (i - 1), take = out_len - off < 32 ? out_len - off : 32;
+        memcpy(out + off, bi, take);
+    }
+    return 0;
+}
+int oracle_expand_message_xmd(const uint8_t *msg, long mlen, const uint8_t *dst, long dlen, uint8_t *out, long out_len) {
+    return expand_message_xmd(msg, (size_t)mlen, dst, (size_t)dlen, out, (size_t)out_len);
+}
+/* gnark-crypto fr.Hash(msg, dst, 1): 48 uniform bytes -> BE int mod r.  [gnark-mem]
  * Output: Fr element in Montgomery form. */
 static void hash_to_fr(const uint8_t *msg, size_t mlen, const char *dst, fe_t *out) {
-    size_t dlen = strlen(dst);
     const size_t L = 48;
-    size_t blen = 64 + mlen + 2 + 1 + dlen + 1;
-    uint8_t *b = (uint8_t *)calloc(blen, 1);
-    memcpy(b + 64, msg, mlen);
-    b[64 + mlen] = (uint8_t)(L >> 8); b[64 + mlen + 1] = (uint8_t)L; b[64 + mlen + 2] = 0;
-    memcpy(b + 64 + mlen + 3, dst, dlen); b[64 + mlen + 3 + dlen] = (uint8_t)dlen;
-    uint8_t b0[32], bi[32], prev[32], uni[64];
-    sha256(b, blen, b0); free(b);
-    uint8_t t[32 + 1 + 256 + 1];
-    memcpy(t, b0, 32); t[32] = 1; memcpy(t + 33, dst, dlen); t[33 + dlen] = (uint8_t)dlen;
-    sha256(t, 34 + dlen, bi); memcpy(uni, bi, 32); memcpy(prev, bi, 32);
-    for (int k = 0; k < 32; k++) t[k] = b0[k] ^ prev[k];
-    t[32] = 2;
-    sha256(t, 34 + dlen, bi); memcpy(uni + 32, bi, 32);
+    uint8_t uni[48];
+    expand_message_xmd(msg, mlen, (const uint8_t *)dst, strlen(dst), uni, L);
     /* 48 BE bytes mod r: process via Horner on bytes in Montgomery arithmetic */
     fe_t acc; memset(&acc, 0, sizeof(acc));
     fe_t c256; f_set_u64(&FR, &c256, 256);

@@ -139,15 +139,23 @@ def g1_mul(a, k):
     return r
 
 
-def hash_to_fr_py(msg: bytes, dst: bytes) -> int:
-    """RFC 9380 expand_message_xmd(SHA-256), 48 bytes, big-endian mod r (gnark-crypto fr.Hash count=1)."""
+def expand_message_xmd_py(msg: bytes, dst: bytes, n: int) -> bytes:
+    """RFC 9380 section 5.3.1 expand_message_xmd with SHA-256 (pinned to the RFC's appendix K.1 vectors by tests/test_pins.py)."""
     import hashlib
-    L = 48
+    ell = (n + 31) // 32
+    assert ell <= 255 and n <= 65535 and len(dst) <= 255
     dst_prime = dst + bytes([len(dst)])
-    b0 = hashlib.sha256(bytes(64) + msg + L.to_bytes(2, "big") + b"\x00" + dst_prime).digest()
-    b1 = hashlib.sha256(b0 + b"\x01" + dst_prime).digest()
-    b2 = hashlib.sha256(bytes(x ^ y for x, y in zip(b0, b1)) + b"\x02" + dst_prime).digest()
-    return int.from_bytes((b1 + b2)[:L], "big") % R
+    b0 = hashlib.sha256(bytes(64) + msg + n.to_bytes(2, "big") + b"\x00" + dst_prime).digest()
+    out, bi = b"", bytes(32)
+    for i in range(1, ell + 1):
+        bi = hashlib.sha256(bytes(x ^ y for x, y in zip(b0, bi)) + bytes([i]) + dst_prime).digest()
+        out += bi
+    return out[:n]
+
+
+def hash_to_fr_py(msg: bytes, dst: bytes) -> int:
+    """gnark-crypto fr.Hash(msg, dst, 1)[0]: 48 uniform bytes, big-endian, mod r.  [gnark-mem]"""
+    return int.from_bytes(expand_message_xmd_py(msg, dst, 48), "big") % R
 
 
 def groth16_verify(vk: dict, proof: dict, public_inputs) -> bool:

@@ -13,7 +13,7 @@ ks = [int(x) for x in sys.argv[3].split(",")]
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 for k in ks:
     out = (C.c_double * 5)()
-    rc = zk.lib.zkp_bench_comb(logn, batch, k, iters, out)
+    rc = zk.testlib.zkp_bench_comb(logn, batch, k, iters, out)
     n = 1 << logn
     adds = ((n + k - 1) // k) * 254 * batch
     print(json.dumps({"logn": logn, "batch": batch, "k": k, "rc": rc, "build_ms": round(out[0], 1), "patterns_ms": round(out[1], 2), "walk_ms": round(out[2], 2),

@@ -19,5 +19,5 @@ if special & 4:
     sc[1, 9] = np.frombuffer(((R - int.from_bytes(sc[1, 8].tobytes(), "little")) % R).to_bytes(32, "little"), np.uint8)
 exp = np.stack([oracle.msm_g1(pts, sc[b]) for b in range(batch)])
 got = np.zeros((batch, 64), np.uint8)
-rc = zk.lib.zkp_msm_g1_dense(n, batch, pts.ctypes.data, sc.ctypes.data, got.ctypes.data, c)
+rc = zk.testlib.zkp_msm_g1_dense(n, batch, pts.ctypes.data, sc.ctypes.data, got.ctypes.data, c)
 print(sys.argv[1:], "tree=%s piece=%s" % (os.environ.get("ZKPROVE_MSM_TREE"), os.environ.get("ZKPROVE_MSM_PIECE")), "rc", rc, "match per instance:", [bool(np.array_equal(got[b], exp[b])) for b in range(batch)], flush=True)

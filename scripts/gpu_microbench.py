@@ -8,7 +8,7 @@ for kind, name, per_iter, iters in ((0, "fp_mul", 2, 2000), (1, "g1_mixed_add", 
                                     (5, "v_mad_u64_u32", 64, 2000), (6, "mad_addc_pair", 64, 2000), (7, "fp9_mul", 2, 2000), (8, "g1_mixed_add_9limb", 1, 400),
                                     (9, "g2_mixed_add_9limb", 1, 150), (10, "v_mad_i64_i32", 64, 2000)):
     for threads in (256 * 256 * 4, 256 * 256 * 8, 256 * 256 * 16):
-        ms = zk.lib.zkp_microbench(kind, threads, iters)
+        ms = zk.testlib.zkp_microbench(kind, threads, iters)
         ops = threads * iters * per_iter
         rate = ops / ms * 1e3
         best[name] = max(best.get(name, 0.0), rate)

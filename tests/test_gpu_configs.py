@@ -363,6 +363,58 @@ def test_comb_tables_are_given_back_under_memory_pressure():
     assert out["comb_after"] == 0 and out["same"] and out["ok"], out
     assert "comb tables" in res.stderr and "released" in res.stderr
 
+_OOM_SCRIPT = r"""
+import importlib, json, os, sys
+import numpy as np
+import torch
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+zk = importlib.import_module("zk-symmetric-crypto_amd")
+import helpers as H
+from oracle import ref
+zk.lib.ZkpAllowUnpinnedKeys(1)
+alg = 0
+r1cs = zk.synth.r1cs_bytes(alg)
+pk, vk = zk.setup(r1cs, ref.toxic_from_seed(1), raw=True)
+assert zk.init_algorithm(alg, pk, r1cs)
+rng = H.SplitMix64(0x5EED0000 + 77)
+insts = [H.make_instance(alg, rng) for _ in range(1024)]
+wits = np.array([zk.request_witness(H.request_json(alg, i))[1] for i in insts], np.uint32)
+def small():
+    rb = zk.ResidentBatch(alg, wits[:8], [i["r"] for i in insts[:8]], [i["s"] for i in insts[:8]], [0] * 8)
+    rb.step()
+    return rb.fetch()
+first, errs = small()
+assert not errs.any()
+free_b, total_b = torch.cuda.mem_get_info()
+hog = torch.empty(max(0, free_b - (5 << 29)), dtype=torch.uint8, device="cuda")      # 2.5 GiB stay free: enough for 8 proofs, not for 1 024
+failed = False
+try:
+    zk.ResidentBatch(alg, wits, [i["r"] for i in insts], [i["s"] for i in insts], [0] * 1024)
+except RuntimeError:
+    failed = True
+again, errs2 = small()                                  # with the device still full
+one = json.loads(zk.prove_raw(H.request_json(alg, insts[0])))
+del hog
+torch.cuda.empty_cache()
+rb = zk.ResidentBatch(alg, wits[:256], [i["r"] for i in insts[:256]], [i["s"] for i in insts[:256]], [0] * 256)      # and grows again once there is room
+rb.step()
+big, errs3 = rb.fetch()
+print(json.dumps(dict(failed=failed, same=bool(np.array_equal(first, again)), ok=bool(not errs2.any() and not errs3.any()), prove="proof" in one,
+                      grown_same=bool(np.array_equal(big[:8], first)))))
+"""
+
+
+def test_a_failed_large_reservation_leaves_the_library_usable():
+    """DevBuf::alloc releases before it allocates, so a reservation that fails half way leaves EMPTY buffers behind; the capacities the
+    prover remembers are reset with them (prover.hip, resident_reserve).  Small batch -> a 1024-batch that cannot be reserved (the
+    device is filled from the host application's side) answers with an error -> the same small batch and a Prove() still work, with the
+    same proofs, instead of launching kernels on null pointers -> a larger batch is reserved again once memory is back."""
+    res = subprocess.run([sys.executable, "-c", _OOM_SCRIPT.format(root=H.ROOT)], capture_output=True, text=True, timeout=1200)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert out == dict(failed=True, same=True, ok=True, prove=True, grown_same=True), (out, res.stderr[-2000:])
+
+
 _THREE_SCRIPT = r"""
 import base64, importlib, json, os, sys
 import numpy as np

@@ -24,7 +24,7 @@ def test_ntt_matches_oracle(zk, oracle, logn, batch, mode):
     data = np.stack([_rand_fr(rng, n) for _ in range(batch)])
     exp = np.stack([oracle.ntt(data[b], inverse=bool(mode & 1)) for b in range(batch)])
     got = data.copy()
-    assert zk.lib.zkp_ntt(logn, batch, got.ctypes.data, mode) == 0, zk.last_error()
+    assert zk.testlib.zkp_ntt(logn, batch, got.ctypes.data, mode) == 0, zk.last_error()
     assert np.array_equal(got, exp)
 
 
@@ -33,8 +33,8 @@ def test_compute_h_matches_oracle(zk, oracle, logn, ncons, batch):
     """gnark's unfolded computeH (7 transforms + pointwise quotient).  The product runs the folded form (4 transforms; pinned through
     f = D*H + C in tests/test_gpu_prove.py), so this entry exists in the experiments build only: the test runs through
     test_alternative_field_paths_stay_bit_exact (libzkprove_exp.so); run on the product library it loads that build for this one entry."""
-    lib = zk.lib
-    if getattr(lib, "zkp_compute_h", None) is None:          # product library: take the entry from the experiments build of the same sources
+    lib = zk.testlib
+    if getattr(lib, "zkp_compute_h", None) is None:          # product build: take the entry from the experiments build of the same sources
         import ctypes as C
         import os
         import helpers as H
@@ -93,7 +93,7 @@ def test_msm_g1_matches_oracle(zk, oracle, n, batch, c):
         sc[0, 5] = np.frombuffer((R - 1).to_bytes(32, "little"), np.uint8)
     exp = np.stack([oracle.msm_g1(pts, sc[b]) for b in range(batch)])
     got = np.zeros((batch, 64), np.uint8)
-    rc = zk.lib.zkp_msm_g1(n, batch, pts.ctypes.data, sc.ctypes.data, got.ctypes.data, c)
+    rc = zk.testlib.zkp_msm_g1(n, batch, pts.ctypes.data, sc.ctypes.data, got.ctypes.data, c)
     assert rc == 0, zk.last_error()
     assert np.array_equal(got, exp)
 
@@ -105,7 +105,7 @@ def test_msm_g2_matches_oracle(zk, oracle, n, batch, c):
     sc = _scalars_mix(rng, n, batch)
     exp = np.stack([oracle.msm_g2(pts, sc[b]) for b in range(batch)])
     got = np.zeros((batch, 128), np.uint8)
-    rc = zk.lib.zkp_msm_g2(n, batch, pts.ctypes.data, sc.ctypes.data, got.ctypes.data, c)
+    rc = zk.testlib.zkp_msm_g2(n, batch, pts.ctypes.data, sc.ctypes.data, got.ctypes.data, c)
     assert rc == 0, zk.last_error()
     assert np.array_equal(got, exp)
 
@@ -120,7 +120,7 @@ def test_msm_all_zero_and_all_one(zk, oracle):
     sc[3] = _rand_fr(rng, n)
     exp = np.stack([oracle.msm_g1(pts, sc[b]) for b in range(batch)])
     got = np.zeros((batch, 64), np.uint8)
-    assert zk.lib.zkp_msm_g1(n, batch, pts.ctypes.data, sc.ctypes.data, got.ctypes.data, 9) == 0
+    assert zk.testlib.zkp_msm_g1(n, batch, pts.ctypes.data, sc.ctypes.data, got.ctypes.data, 9) == 0
     assert np.array_equal(got, exp)
     assert not got[0].any()      # empty sum = infinity = (0,0)
 
@@ -138,7 +138,7 @@ def test_msm_g1_dense_path_matches_oracle(zk, oracle, n, batch, c):
         sc[0, 6:40] = sc[0, 41]                              # many equal scalars -> one hot bucket per window
     exp = np.stack([oracle.msm_g1(pts, sc[b]) for b in range(batch)])
     got = np.zeros((batch, 64), np.uint8)
-    rc = zk.lib.zkp_msm_g1_dense(n, batch, pts.ctypes.data, sc.ctypes.data, got.ctypes.data, c)
+    rc = zk.testlib.zkp_msm_g1_dense(n, batch, pts.ctypes.data, sc.ctypes.data, got.ctypes.data, c)
     assert rc == 0, zk.last_error()
     assert np.array_equal(got, exp)
 
@@ -162,7 +162,7 @@ def test_msm_comb_matches_oracle(zk, oracle, n, batch, k, mode):
             sc[2] = np.frombuffer((R - 1).to_bytes(32, "little"), np.uint8)
     exp = np.stack([oracle.msm_g1(pts, sc[b]) for b in range(batch)])
     got = np.zeros((batch, 64), np.uint8)
-    rc = zk.lib.zkp_msm_comb(n, batch, pts.ctypes.data, sc.ctypes.data, got.ctypes.data, k, mode)
+    rc = zk.testlib.zkp_msm_comb(n, batch, pts.ctypes.data, sc.ctypes.data, got.ctypes.data, k, mode)
     assert rc == 0, zk.last_error()
     assert np.array_equal(got, exp)
     if batch > 1:
@@ -188,7 +188,7 @@ def test_msm_comb_tabulates_degenerate_bases_by_the_complete_rules(zk, oracle):
     v = pts.copy(); v[8:16] = v[8]; variants["a clump of eight equal bases"] = v
     for name, p in variants.items():
         p = np.ascontiguousarray(p)
-        assert zk.lib.zkp_msm_comb(n, batch, p.ctypes.data, sc.ctypes.data, got.ctypes.data, 8, 0) == 0, name
+        assert zk.testlib.zkp_msm_comb(n, batch, p.ctypes.data, sc.ctypes.data, got.ctypes.data, 8, 0) == 0, name
         assert np.array_equal(got, np.stack([oracle.msm_g1(p, sc[b]) for b in range(batch)])), name
 
 
@@ -226,7 +226,7 @@ def test_msm_wire_comb_matches_oracle(zk, oracle, group, n, batch, k):
     msm = oracle.msm_g1 if group == 1 else oracle.msm_g2
     exp = np.stack([msm(pts, sc[b]) for b in range(batch)])
     got = np.zeros((batch, 64 * group), np.uint8)
-    rc = zk.lib.zkp_msm_wire_comb(group, n, batch, pts.ctypes.data, sc.ctypes.data, got.ctypes.data, 9, k, cls.ctypes.data)
+    rc = zk.testlib.zkp_msm_wire_comb(group, n, batch, pts.ctypes.data, sc.ctypes.data, got.ctypes.data, 9, k, cls.ctypes.data)
     assert rc == 0, zk.last_error()
     assert np.array_equal(got, exp)
 
@@ -242,7 +242,7 @@ def test_msm_dense_all_equal_scalars_overflows_lds_bins(zk, oracle):
     sc[1, n // 2:] = _rand_fr(rng, n - n // 2)
     exp = np.stack([oracle.msm_g1(pts, sc[b]) for b in range(batch)])
     got = np.zeros((batch, 64), np.uint8)
-    assert zk.lib.zkp_msm_g1_dense(n, batch, pts.ctypes.data, sc.ctypes.data, got.ctypes.data, 16) == 0
+    assert zk.testlib.zkp_msm_g1_dense(n, batch, pts.ctypes.data, sc.ctypes.data, got.ctypes.data, 16) == 0
     assert np.array_equal(got, exp)
 
 
@@ -263,7 +263,7 @@ def test_fold_quotient_bases_matches_definition(zk, oracle, logn, ncons):
     ze_s = [nd_inv * sum(pow(winv, i * k, R) * pow(ginv, k, R) * z[k] for k in range(N - 1)) % R for i in range(N)]
     zc_s = [-nd_inv * sum(pow(winv, j * k, R) * z[k] for k in range(N - 1)) % R for j in range(ncons)]
     ze, zc = np.zeros((N, 64), np.uint8), np.zeros((ncons, 64), np.uint8)
-    assert zk.lib.zkp_fold_quotient_bases(logn, ncons, pts.ctypes.data, ze.ctypes.data, zc.ctypes.data) == 0, zk.last_error()
+    assert zk.testlib.zkp_fold_quotient_bases(logn, ncons, pts.ctypes.data, ze.ctypes.data, zc.ctypes.data) == 0, zk.last_error()
     assert np.array_equal(ze, oracle.g1_fixed_base(oracle.ints_to_le32(ze_s)))
     assert np.array_equal(zc, oracle.g1_fixed_base(oracle.ints_to_le32(zc_s)))
 
@@ -290,7 +290,7 @@ def test_fold_output_matrix_matches_definition(zk, oracle):
     co = oracle.ints_to_le32(coeffs)
     cap = len(rows_k) + len(terms)
     out_rows, out_pts = np.zeros(cap, np.uint32), np.zeros((cap, 64), np.uint8)
-    n = zk.lib.zkp_fold_output_matrix(nzc, zc.ctypes.data, len(rows_k), k.ctypes.data, rows_k.ctypes.data, len(terms), t.ctypes.data, len(coeffs),
+    n = zk.testlib.zkp_fold_output_matrix(nzc, zc.ctypes.data, len(rows_k), k.ctypes.data, rows_k.ctypes.data, len(terms), t.ctypes.data, len(coeffs),
                                       co.ctypes.data, out_rows.ctypes.data, out_pts.ctypes.data)
     assert n > 0, zk.last_error()
     exp = {int(w): ks for w, ks in zip(rows_k, k_s)}
@@ -310,9 +310,9 @@ def test_full_size_ntt_round_trip_and_linearity(zk):
     x = rng.integers(0, 256, size=(batch, n, 32), dtype=np.uint8)
     x[:, :, 31] &= 0x1F                                  # < 2^253 < r
     y = x.copy()
-    assert zk.lib.zkp_ntt(logn, batch, y.ctypes.data, 0) == 0        # forward, DIF kernels
+    assert zk.testlib.zkp_ntt(logn, batch, y.ctypes.data, 0) == 0        # forward, DIF kernels
     z = y.copy()
-    assert zk.lib.zkp_ntt(logn, batch, z.ctypes.data, 3) == 0        # inverse, DIT kernels
+    assert zk.testlib.zkp_ntt(logn, batch, z.ctypes.data, 3) == 0        # inverse, DIT kernels
     assert np.array_equal(z, x)
     # linearity on two instances: NTT(a) + NTT(b) == NTT(a + b)  (mod r)
     a = [int.from_bytes(x[0, i].tobytes(), "little") for i in range(0, n, 997)]
@@ -321,7 +321,7 @@ def test_full_size_ntt_round_trip_and_linearity(zk):
     for i in range(n):
         v = (int.from_bytes(x[0, i].tobytes(), "little") + int.from_bytes(x[1, i].tobytes(), "little")) % R
         tot[0, i] = np.frombuffer(v.to_bytes(32, "little"), np.uint8)
-    assert zk.lib.zkp_ntt(logn, 1, tot.ctypes.data, 0) == 0
+    assert zk.testlib.zkp_ntt(logn, 1, tot.ctypes.data, 0) == 0
     for i in range(0, n, 1231):
         lhs = (int.from_bytes(y[0, i].tobytes(), "little") + int.from_bytes(y[1, i].tobytes(), "little")) % R
         assert lhs == int.from_bytes(tot[0, i].tobytes(), "little")
@@ -338,7 +338,7 @@ def test_field_inversion_binary_gcd_matches_modular_inverse(zk, field):
     vals += [int.from_bytes(rng.bytes(32), "little") % m for _ in range(4000)]
     buf = np.frombuffer(b"".join(v.to_bytes(32, "little") for v in vals), np.uint8).copy()
     out = np.zeros_like(buf)
-    assert zk.lib.zkp_field_inv(field, len(vals), buf.ctypes.data, out.ctypes.data) == 0
+    assert zk.testlib.zkp_field_inv(field, len(vals), buf.ctypes.data, out.ctypes.data) == 0
     got = [int.from_bytes(out[32 * i:32 * i + 32].tobytes(), "little") for i in range(len(vals))]
     exp = [pow(v, -1, m) if v else 0 for v in vals]
     assert got == exp
@@ -365,7 +365,7 @@ for (n, batch, c) in {cases}:
     sc[1, 9] = np.frombuffer(((R - int.from_bytes(sc[1, 8].tobytes(), "little")) % R).to_bytes(32, "little"), np.uint8)   # and P - P in instance 1
     exp = np.stack([oracle.msm_g1(pts, sc[b]) for b in range(batch)])
     got = np.zeros((batch, 64), np.uint8)
-    rc = zk.lib.zkp_msm_g1_dense(n, batch, pts.ctypes.data, sc.ctypes.data, got.ctypes.data, c)
+    rc = zk.testlib.zkp_msm_g1_dense(n, batch, pts.ctypes.data, sc.ctypes.data, got.ctypes.data, c)
     res["%d,%d,%d" % (n, batch, c)] = bool(rc == 0 and np.array_equal(got, exp))
 print(json.dumps(res))
 """
@@ -411,17 +411,17 @@ def test_msm_doubling_and_cancellation_inside_a_bucket(zk, oracle, group):
     if group == "g1_dense":
         exp = np.stack([oracle.msm_g1(pts, sc[b]) for b in range(batch)])
         got = np.zeros((batch, 64), np.uint8)
-        assert zk.lib.zkp_msm_g1_dense(n, batch, pts.ctypes.data, sc.ctypes.data, got.ctypes.data, c) == 0
+        assert zk.testlib.zkp_msm_g1_dense(n, batch, pts.ctypes.data, sc.ctypes.data, got.ctypes.data, c) == 0
     elif group == "g1_sparse":
         sc[:, 100:400] = 0; sc[:, 400:500, :] = 0; sc[:, 400:500, 0] = 1                    # mixed classes: zeros, ones, wide
         exp = np.stack([oracle.msm_g1(pts, sc[b]) for b in range(batch)])
         got = np.zeros((batch, 64), np.uint8)
-        assert zk.lib.zkp_msm_g1(n, batch, pts.ctypes.data, sc.ctypes.data, got.ctypes.data, c) == 0
+        assert zk.testlib.zkp_msm_g1(n, batch, pts.ctypes.data, sc.ctypes.data, got.ctypes.data, c) == 0
     else:
         sc[:, 100:400] = 0
         exp = np.stack([oracle.msm_g2(pts, sc[b]) for b in range(batch)])
         got = np.zeros((batch, 128), np.uint8)
-        assert zk.lib.zkp_msm_g2(n, batch, pts.ctypes.data, sc.ctypes.data, got.ctypes.data, c) == 0
+        assert zk.testlib.zkp_msm_g2(n, batch, pts.ctypes.data, sc.ctypes.data, got.ctypes.data, c) == 0
     assert np.array_equal(got, exp)
 
 

@@ -15,14 +15,32 @@ from oracle import r1cs_format as rf
 import helpers as H
 
 
-def test_library_exports_every_declared_symbol(zk):
-    hdr = open(os.path.join(H.ROOT, "include", "zkprove.h")).read()
-    hdr = re.sub(r"#ifdef ZK_EXPERIMENTS.*?#endif", "", hdr, flags=re.S)          # entries of the experiments build (libzkprove_exp.so) only
+def _declared(header, experiments=False):
+    hdr = open(os.path.join(H.ROOT, "include", header)).read()
+    if not experiments:
+        hdr = re.sub(r"#ifdef ZK_EXPERIMENTS.*?#endif", "", hdr, flags=re.S)      # entries of the experiments build (libzkprove_exp.so) only
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", hdr)
-    assert {"InitAlgorithm", "Prove", "Free", "enforce_binding", "GenerateOPRFRequestData", "TOPRFFinalize", "ProveBatch"} <= set(names)
+    return re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{()]*\)\s*;", hdr)
+
+
+def _exported(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return {l.split()[-1] for l in out.splitlines() if l.strip()}
+
+
+def test_library_exports_every_declared_symbol(zk):
+    """The drop-in exports include/zkprove.h -- every declared function, and NOTHING else (no C++ symbols, no test entry points);
+    the test library exports zkprove.h + zkprove_test.h and nothing else."""
+    names = _declared("zkprove.h")
+    assert {"InitAlgorithm", "Prove", "Free", "enforce_binding", "GenerateOPRFRequestData", "TOPRFFinalize", "ProveBatch", "ZkpProveWitness"} <= set(names)
     for n in names:
         assert hasattr(zk.lib, n), "libzkprove.so does not export %s" % n
+    assert _exported(zk.LIB_PATH) == set(names), sorted(_exported(zk.LIB_PATH) ^ set(names))
+    test_names = set(names) | set(_declared("zkprove_test.h"))
+    assert _exported(zk.TESTLIB_PATH) == test_names, sorted(_exported(zk.TESTLIB_PATH) ^ test_names)
+    for n in test_names:
+        assert hasattr(zk.testlib, n)
     zk.lib.enforce_binding()
     # every symbol the two unchanged reference loaders bind: koffi (js/src/gnark/utils.ts:81-92) and cgo
     # (libprove.go:18-86, libverify.go:18-64) -- the library stands in for libprove.so AND libverify.so

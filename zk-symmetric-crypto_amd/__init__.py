@@ -12,8 +12,12 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# ZKPROVE_LIB: another build of the same library (tests load libzkprove_exp.so, the -DZK_EXPERIMENTS build, through it)
+# ZKPROVE_LIB: another build of the same library (tests load libzkprove_exp.so, the -DZK_EXPERIMENTS build, through it; that build
+# exports the kernel-level test entries too, so it then also stands in for the test library)
 LIB_PATH = os.environ.get("ZKPROVE_LIB") or os.path.join(_HERE, "libzkprove.so")
+# kernel-level entry points of the parity tests and micro-benchmarks (include/zkprove_test.h): a library of their own, linked from the
+# same objects as the product + csrc/test_api.hip.  The drop-in exports include/zkprove.h and nothing else.
+TESTLIB_PATH = os.environ.get("ZKPROVE_LIB") or os.environ.get("ZKPROVE_TESTLIB") or os.path.join(_HERE, "libzkprove_test.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -31,8 +35,8 @@ class ProveReturn(C.Structure):  # js/src/gnark/utils.ts:53-56
     _fields_ = [("r0", C.c_void_p), ("r1", C.c_longlong)]
 
 
-def _sig(name, restype, argtypes):
-    fn = getattr(lib, name, None)
+def _sig(name, restype, argtypes, of=None):
+    fn = getattr(of if of is not None else lib, name, None)
     if fn is not None:
         fn.restype = restype
         fn.argtypes = argtypes
@@ -42,24 +46,54 @@ def _sig(name, restype, argtypes):
 _vp, _i64, _i32 = C.c_void_p, C.c_long, C.c_int
 _sig("zkp_last_error", C.c_char_p, [])
 _sig("zkp_device_count", _i32, [])
-_sig("zkp_ntt", _i32, [_i32, _i64, _vp, _i32])
-_sig("zkp_compute_h", _i32, [_i32, _i64, _i64, _vp, _vp, _vp, _vp])
-_sig("zkp_msm_g1", _i32, [_i64, _i64, _vp, _vp, _vp, _i32])
-_sig("zkp_msm_g2", _i32, [_i64, _i64, _vp, _vp, _vp, _i32])
-_sig("zkp_msm_g1_dense", _i32, [_i64, _i64, _vp, _vp, _vp, _i32])
-_sig("zkp_msm_comb", _i32, [_i64, _i64, _vp, _vp, _vp, _i32, _i32])
-_sig("zkp_msm_wire_comb", _i32, [_i32, _i64, _i64, _vp, _vp, _vp, _i32, _i32, _vp])
-_sig("zkp_bench_comb", _i32, [_i32, _i64, _i32, _i32, _vp])
-_sig("zkp_fold_quotient_bases", _i32, [_i32, _i64, _vp, _vp, _vp])
-_sig("zkp_fold_output_matrix", _i64, [_i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp])
-_sig("zkp_microbench", C.c_double, [_i32, _i64, _i32])
-_sig("zkp_field_inv", _i32, [_i32, _i64, _vp, _vp])
-_sig("zkp_bench_to_coset", C.c_double, [_i32, _i64, _i32])
-_sig("zkp_debug_tree", _i32, [_i32, _i32, _i32, _i32])
+
+_testlib = None
+
+
+def _load_testlib():
+    global _testlib
+    if _testlib is None:
+        if not os.path.exists(TESTLIB_PATH):
+            raise ImportError("libzkprove_test.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'`" % TESTLIB_PATH)
+        t = lib if os.path.abspath(TESTLIB_PATH) == os.path.abspath(LIB_PATH) else C.CDLL(TESTLIB_PATH)
+        for name, res, args in (
+                ("zkp_last_error", C.c_char_p, []),
+                ("zkp_ntt", _i32, [_i32, _i64, _vp, _i32]),
+                ("zkp_compute_h", _i32, [_i32, _i64, _i64, _vp, _vp, _vp, _vp]),
+                ("zkp_msm_g1", _i32, [_i64, _i64, _vp, _vp, _vp, _i32]),
+                ("zkp_msm_g2", _i32, [_i64, _i64, _vp, _vp, _vp, _i32]),
+                ("zkp_msm_g1_dense", _i32, [_i64, _i64, _vp, _vp, _vp, _i32]),
+                ("zkp_msm_comb", _i32, [_i64, _i64, _vp, _vp, _vp, _i32, _i32]),
+                ("zkp_msm_wire_comb", _i32, [_i32, _i64, _i64, _vp, _vp, _vp, _i32, _i32, _vp]),
+                ("zkp_bench_comb", _i32, [_i32, _i64, _i32, _i32, _vp]),
+                ("zkp_fold_quotient_bases", _i32, [_i32, _i64, _vp, _vp, _vp]),
+                ("zkp_fold_output_matrix", _i64, [_i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
+                ("zkp_microbench", C.c_double, [_i32, _i64, _i32]),
+                ("zkp_field_inv", _i32, [_i32, _i64, _vp, _vp]),
+                ("zkp_bench_to_coset", C.c_double, [_i32, _i64, _i32]),
+                ("zkp_debug_tree", _i32, [_i32, _i32, _i32, _i32]),
+                ("zkp_pairing_product_check", _i32, [_vp, _vp, _i64, _i32]),
+                ("zkp_vk_pairing_identities", _i32, [_vp, _i64, _i32]),
+                ("zkp_expand_message_xmd", _i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i32]),
+                ("zkp_bsb22_challenge", _i32, [_vp, _i64, _vp]),
+                ("zkp_bsb22_challenge_host", _i32, [_vp, _i64, _vp])):
+            _sig(name, res, args, of=t)
+        _testlib = t
+    return _testlib
+
+
+def __getattr__(name):          # zk.testlib: loaded on first use (the product path never needs it)
+    if name == "testlib":
+        return _load_testlib()
+    raise AttributeError(name)
 
 
 def last_error() -> str:
-    return lib.zkp_last_error().decode()
+    """last error text of this thread, from whichever of the two libraries reported one"""
+    msg = lib.zkp_last_error().decode()
+    if not msg and _testlib is not None and _testlib is not lib:
+        msg = _testlib.zkp_last_error().decode()
+    return msg
 
 
 def device_count() -> int:
@@ -88,6 +122,9 @@ _sig("VerifyBatch", ProveReturn, [GoSlice])
 _sig("zkp_verify_batch_timed", ProveReturn, [GoSlice, C.POINTER(C.c_double)])
 _sig("VFree", None, [C.c_void_p])
 _sig("ZkpProveDeterministic", ProveReturn, [GoSlice, _u8p, _u8p, _u8p])
+_sig("ZkpProveWitness", ProveReturn, [C.c_ubyte, GoSlice])
+_sig("ZkpProveWitnessDeterministic", ProveReturn, [C.c_ubyte, GoSlice, _u8p, _u8p, _u8p])
+_sig("ZkpSetHardwareQueues", _i32, [_i32])
 _sig("zkp_n_inputs", _i64, [_i32])
 _sig("zkp_bench_upload", _i32, [_i32, _i64, _vp, _vp, _vp, _vp])
 _sig("zkp_bench_step", _i32, [_i32, _vp])
@@ -141,6 +178,31 @@ def prove_deterministic_raw(request_json: bytes, r: int, s: int, randomize: int 
     sl, keep = _slice(request_json)
     bufs = [C.create_string_buffer(int(v).to_bytes(32, "little"), 32) for v in (r, s, randomize)]
     return _take(lib.ZkpProveDeterministic(sl, *[C.cast(b, C.c_void_p) for b in bufs]))
+
+
+def witness_binary(n_public: int, values) -> bytes:
+    """gnark witness.MarshalBinary layout: u32 nbPublic | u32 nbSecret | u32 n | n x 32-byte big-endian elements (public first, no
+    constant-one wire) -- what the Go shim passes for groth16.Prove(r1cs, pk, wtns) (impl/provers.go:175-179)"""
+    vals = [int(v) for v in values]
+    n = len(vals)
+    return (n_public.to_bytes(4, "big") + (n - n_public).to_bytes(4, "big") + n.to_bytes(4, "big") + b"".join(v.to_bytes(32, "big") for v in vals))
+
+
+def prove_witness(algorithm_id: int, witness: bytes, r=None, s=None, randomize=None) -> bytes:
+    """ZkpProveWitness (the inner boundary groth16.Prove(r1cs, pk, wtns)): gnark binary witness -> Proof.WriteTo bytes; raises
+    RuntimeError(error text) where groth16.Prove returns an error.  r / s / randomize given: the deterministic variant."""
+    sl, keep = _slice(witness)
+    if r is None and s is None and randomize is None:
+        ret = lib.ZkpProveWitness(algorithm_id, sl)
+    else:
+        bufs = [C.create_string_buffer(int(v or 0).to_bytes(32, "little"), 32) for v in (r, s, randomize)]
+        ret = lib.ZkpProveWitnessDeterministic(algorithm_id, sl, *[C.cast(b, C.c_void_p) for b in bufs])
+    n = ret.r1
+    out = C.string_at(ret.r0, abs(n))
+    lib.Free(ret.r0)
+    if n < 0:
+        raise RuntimeError(out.decode())
+    return out
 
 
 def prove_batch_raw(requests_json: bytes) -> bytes:

@@ -105,6 +105,7 @@ void set_default_device(int dev) {
     g_device_explicit = true;
     g_device_list.clear();
 }
+void set_last_error(const std::string &msg) { g_err = msg; }
 void bind_device(int dev) {
     // unconditionally: the calling thread's current device is state this library does not own (the host application -- torch,
     // another HIP user -- may have changed it since our last call on this thread), and the call is a thread-local store
@@ -279,16 +280,6 @@ bool release_neighbours(Algorithm *self) {
     return false;
 }
 const bool g_hook_set = [] { Algorithm::neighbours_release = release_neighbours; return true; }();
-// HIP multiplexes all streams of the process over GPU_MAX_HW_QUEUES hardware queues (default 4).  One algorithm uses four streams; with
-// two or three circuits loaded their streams share queues, which costs nothing in throughput (the chunk loops submit in an order that
-// tolerates it) but serialises the parallel chains of a one-proof call: AES-256 Prove() 18.6 ms at 4 queues, 17.3 at 8, 16.9 at 16 with
-// ChaCha20 loaded beside it.  Set at load time, before this library's first HIP call, unless the host chose a value itself (or
-// initialised HIP earlier: then it has no effect).  ZKPROVE_KEEP_HW_QUEUES=1 leaves the environment alone.
-const bool g_hw_queues_set = [] {
-    if (!getenv("ZKPROVE_KEEP_HW_QUEUES")) setenv("GPU_MAX_HW_QUEUES", "8", 0);
-    return true;
-}();
-
 std::string response_json(const std::vector<uint8_t> &proof, const std::vector<uint8_t> &ct) {
     return "{\"proof\":\"" + base64_encode(proof.data(), proof.size()) + "\",\"ciphertext\":\"" + base64_encode(ct.data(), ct.size()) + "\"}";
 }
@@ -769,6 +760,71 @@ ProveReturn prove_one(GoSlice params, const U256 *r, const U256 *s, const U256 *
     return make_return(result);
 }
 
+// ------------------------------------------------------------------------------------------- inner boundary
+// groth16.Prove(cp.r1cs, cp.pk, wtns) of impl/provers.go:179,269 as one call: gnark's binary witness in, Proof.WriteTo bytes out.
+// witness.MarshalBinary (gnark v0.14 backend/witness): u32 nbPublic | u32 nbSecret | fr.Vector = u32 n | n x 32-byte big-endian canonical
+// elements, public part first, WITHOUT the constant-one wire.  [gnark-mem: DESIGN.md section 5]
+struct WitnessError { std::string msg; };
+std::vector<uint8_t> prove_witness(int id, const uint8_t *w, size_t len, const U256 *r_fix, const U256 *s_fix, const U256 *rnd_fix) {
+    if (id < 0 || id >= 3) throw WitnessError{"unknown algorithm id " + std::to_string(id)};
+    Algorithm *alg = get_alg(id);
+    if (!alg) throw WitnessError{std::string("proving params are not initialized for cipher: ") + ALGS[id].name};
+    auto be32 = [&](size_t off) { return ((uint32_t)w[off] << 24) | ((uint32_t)w[off + 1] << 16) | ((uint32_t)w[off + 2] << 8) | w[off + 3]; };
+    if (len < 12) throw WitnessError{"witness: short header (" + std::to_string(len) + " bytes)"};
+    const uint64_t n_pub = be32(0), n_sec = be32(4), n = be32(8);
+    if (n != n_pub + n_sec) throw WitnessError{"witness: vector length " + std::to_string(n) + " differs from nbPublic + nbSecret = " + std::to_string(n_pub + n_sec)};
+    if (len != 12 + 32 * n) throw WitnessError{"witness: " + std::to_string(len) + " bytes for " + std::to_string(n) + " elements (expected " + std::to_string(12 + 32 * n) + ")"};
+    const size_t ni = alg->n_inputs(), want_pub = alg->cs.nb_public - 1, want_sec = alg->cs.nb_secret;      // the R1CS counts the constant one among its public wires
+    if (n_pub != want_pub || n_sec != want_sec || n != ni)
+        throw WitnessError{"invalid witness size, got " + std::to_string(n_pub) + " public + " + std::to_string(n_sec) + " secret, expected " + std::to_string(want_pub) + " + " +
+                           std::to_string(want_sec)};
+    std::vector<uint32_t> inputs(ni);
+    std::vector<WideInput> wide;
+    for (size_t i = 0; i < ni; i++) {
+        const uint8_t *e = w + 12 + 32 * i;
+        U256 v;
+        for (int k = 0; k < 8; k++) v.l[7 - k] = ((uint32_t)e[4 * k] << 24) | ((uint32_t)e[4 * k + 1] << 16) | ((uint32_t)e[4 * k + 2] << 8) | e[4 * k + 3];
+        if (u256_cmp(v, FR_MODULUS) >= 0) throw WitnessError{"witness: element " + std::to_string(i) + " is not a canonical field element"};      // fr.Vector.ReadFrom -> SetBytesCanonical
+        bool small = true;
+        for (int k = 1; k < 8; k++) small = small && v.l[k] == 0;
+        inputs[i] = small ? v.l[0] : 0u;
+        if (!small) wide.push_back(WideInput{0u, (uint32_t)i, v});
+    }
+    U256 r, s, rnd;
+    if (r_fix) r = *r_fix; else r = fr_random();
+    if (s_fix) s = *s_fix; else s = fr_random();
+    if (rnd_fix) rnd = *rnd_fix; else rnd = fr_random();
+    ProofPoints pp;
+    uint32_t err = 0;
+    alg->prove_batch(1, inputs.data(), &r, &s, &rnd, &pp, &err, nullptr, wide.data(), wide.size());
+    if (err) {
+        // groth16.Prove returns the solver's error (constraint/solver.go UnsatisfiedConstraintError: "constraint #%d is not satisfied")
+        const uint32_t code = err & 0xff, cons = err >> 8;
+        throw WitnessError{code == SERR_UNSATISFIED ? "constraint #" + std::to_string(cons) + " is not satisfied"
+                                                    : "witness does not solve (solver error " + std::to_string(code) + " at constraint " + std::to_string(cons) + ")"};
+    }
+    return proof_serialize(pp, alg->has_commit);
+}
+ProveReturn prove_witness_abi(int id, GoSlice witness, const U256 *r, const U256 *s, const U256 *rnd) {
+    std::string fail;
+    try {
+        const std::vector<uint8_t> p = prove_witness(id, (const uint8_t *)witness.data, (size_t)(witness.len < 0 ? 0 : witness.len), r, s, rnd);
+        ProveReturn ret;
+        ret.r0 = malloc(p.size());
+        memcpy(ret.r0, p.data(), p.size());
+        ret.r1 = (long long)p.size();
+        return ret;
+    } catch (const WitnessError &e) {
+        fail = e.msg;
+    } catch (const std::exception &e) {
+        fail = e.what();
+    }
+    g_err = fail;
+    ProveReturn ret = make_return(fail);
+    ret.r1 = -ret.r1;
+    return ret;
+}
+
 U256 u256_from_le(const uint8_t *p) {
     U256 v;
     if (p) memcpy(v.l, p, 32); else memset(v.l, 0, 32);
@@ -807,6 +863,7 @@ void ZkpReset(void) {
         s.replicas.clear();
     }
     g_chunk_pool.clear();
+    verifier_reset();
     std::lock_guard<std::mutex> lk(g_dev_lock);
     g_device_list.clear();                  // ZKPROVE_DEVICES / ZkpSetDevice are read again by the next InitAlgorithm
 }
@@ -880,6 +937,12 @@ ProveReturn ZkpProveDeterministic(GoSlice params, const uint8_t *r32, const uint
     return prove_one(params, &r, &s, &rnd);
 }
 
+ProveReturn ZkpProveWitness(unsigned char algorithmID, GoSlice witness) { return prove_witness_abi(algorithmID, witness, nullptr, nullptr, nullptr); }
+ProveReturn ZkpProveWitnessDeterministic(unsigned char algorithmID, GoSlice witness, const uint8_t *r32, const uint8_t *s32, const uint8_t *randomize32) {
+    U256 r = u256_from_le(r32), s = u256_from_le(s32), rnd = u256_from_le(randomize32);
+    return prove_witness_abi(algorithmID, witness, &r, &s, &rnd);
+}
+
 ProveReturn ProveBatch(GoSlice params) { return make_return(prove_batch_json((const char *)params.data, (size_t)params.len)); }
 
 ProveReturn GenerateOPRFRequestData(GoSlice) { return make_return(json_quote("toprf is not supported by libzkprove")); }
@@ -894,13 +957,12 @@ long zkp_n_inputs(int id) {
     Algorithm *a = get_alg(id);
     return a ? (long)a->n_inputs() : -1;
 }
-extern const char *zkp_last_error(void);
-static thread_local std::string g_cabi_err;
 #define CABI_TRY try {
 #define CABI_CATCH                                      \
     }                                                   \
     catch (const std::exception &e) {                   \
         fprintf(stderr, "zkprove: %s\n", e.what());     \
+        g_err = e.what();                               \
         return -1;                                      \
     }
 
@@ -1019,6 +1081,18 @@ int zkp_request_witness(GoSlice params, uint32_t *inputs, long inputs_cap, uint8
     }
 }
 const char *zkp_last_panic(void) { return g_err.c_str(); }
+const char *zkp_last_error(void) { return g_err.c_str(); }
+int zkp_device_count(void) { return visible_devices(); }
+// GPU_MAX_HW_QUEUES: HIP multiplexes all streams of the process over that many hardware queues (default 4).  One algorithm uses four
+// streams; with two or three circuits loaded their streams share queues, which costs nothing in throughput (the chunk loops submit in an
+// order that tolerates it) but serialises the parallel chains of a one-proof call: AES-256 Prove() 18.6 ms at 4 queues, 17.3 at 8 with
+// ChaCha20 loaded beside it.  The library never touches the process environment on its own (a constructor that calls setenv races with
+// the host application's threads); a host that wants the setting either exports GPU_MAX_HW_QUEUES=8 itself or calls this BEFORE the
+// first HIP call of the process (its own, torch's, or this library's InitAlgorithm).  Returns 0, -1 when n is out of range.
+int ZkpSetHardwareQueues(int n) {
+    if (n < 1 || n > 64) return -1;
+    return setenv("GPU_MAX_HW_QUEUES", std::to_string(n).c_str(), 1) == 0 ? 0 : -1;
+}
 long zkp_proof_serialize(const uint8_t *proof384, int has_commitment, uint8_t *out, long cap) {
     ProofPoints p;
     memcpy(&p, proof384, sizeof(p));

@@ -89,6 +89,9 @@ struct DeviceScope {
     DeviceScope &operator=(const DeviceScope &) = delete;
 };
 
+void verifier_reset();                           // verifier.cpp: drop the device images of the verifying keys (ZkpReset)
+void set_last_error(const std::string &msg);     // cabi.cpp: what zkp_last_error() returns on this thread
+
 // hipFuncSetAttribute is per device: run fn the first time each device passes through
 struct PerDeviceOnce {
     std::atomic<uint64_t> done{0};

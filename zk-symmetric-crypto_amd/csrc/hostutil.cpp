@@ -439,24 +439,35 @@ U256 fr_random() {
     fr_random_fill(&v, 1);
     return v;
 }
-U256 hash_to_fr(const uint8_t *msg, size_t len, const char *dst) {
-    const size_t dlen = strlen(dst), L = 48;
-    std::vector<uint8_t> b(64 + len + 3 + dlen + 1, 0);
+// RFC 9380 section 5.3.1 expand_message_xmd with H = SHA-256 (b_in_bytes 32, s_in_bytes 64): out_len uniform bytes from msg under dst.
+// Checked against the published vectors of RFC 9380 appendix K.1 (tests/test_pins.py).
+bool expand_message_xmd(const uint8_t *msg, size_t len, const uint8_t *dst, size_t dlen, uint8_t *out, size_t out_len) {
+    const size_t ell = (out_len + 31) / 32;
+    if (ell > 255 || out_len > 65535 || dlen > 255) return false;
+    std::vector<uint8_t> b(64 + len + 3 + dlen + 1, 0);                     // Z_pad || msg || l_i_b_str || 0 || DST_prime
     memcpy(b.data() + 64, msg, len);
-    b[64 + len] = (uint8_t)(L >> 8); b[64 + len + 1] = (uint8_t)L; b[64 + len + 2] = 0;
+    b[64 + len] = (uint8_t)(out_len >> 8); b[64 + len + 1] = (uint8_t)out_len; b[64 + len + 2] = 0;
     memcpy(b.data() + 64 + len + 3, dst, dlen);
     b[64 + len + 3 + dlen] = (uint8_t)dlen;
-    uint8_t b0[32], b1[32], b2[32];
+    uint8_t b0[32], bi[32];
     sha256(b.data(), b.size(), b0);
-    std::vector<uint8_t> t(32 + 1 + dlen + 1);
-    memcpy(t.data(), b0, 32); t[32] = 1; memcpy(t.data() + 33, dst, dlen); t[33 + dlen] = (uint8_t)dlen;
-    sha256(t.data(), t.size(), b1);
-    for (int k = 0; k < 32; k++) t[k] = b0[k] ^ b1[k];
-    t[32] = 2;
-    sha256(t.data(), t.size(), b2);
-    uint8_t uni[64];
-    memcpy(uni, b1, 32); memcpy(uni + 32, b2, 32);
-    return u256_from_be_mod(uni, L, FR_MODULUS);
+    std::vector<uint8_t> t(32 + 1 + dlen + 1);                              // (b_0 xor b_(i-1)) || i || DST_prime
+    memcpy(t.data() + 33, dst, dlen); t[33 + dlen] = (uint8_t)dlen;
+    memset(bi, 0, 32);
+    for (size_t i = 1; i <= ell; i++) {
+        for (int k = 0; k < 32; k++) t[k] = b0[k] ^ bi[k];
+        t[32] = (uint8_t)i;
+        sha256(t.data(), t.size(), bi);
+        const size_t off = 32 * (i - 1), take = out_len - off < 32 ? out_len - off : 32;
+        memcpy(out + off, bi, take);
+    }
+    return true;
+}
+// gnark-crypto fr.Hash(msg, dst, 1)[0]: L = 48 uniform bytes per element, big-endian, reduced mod r  [gnark-mem: DESIGN.md section 5]
+U256 hash_to_fr(const uint8_t *msg, size_t len, const char *dst) {
+    uint8_t uni[48];
+    if (!expand_message_xmd(msg, len, (const uint8_t *)dst, strlen(dst), uni, sizeof(uni))) throw ZkError("hash_to_fr: domain separation tag too long");
+    return u256_from_be_mod(uni, sizeof(uni), FR_MODULUS);
 }
 
 }  // namespace zk

@@ -89,7 +89,9 @@ void u256_to_be(const U256 &v, uint8_t out[32]);
 // uniformly random element of [0, r) from the OS entropy source (fr.Element.SetRandom)
 U256 fr_random();
 void fr_random_fill(U256 *out, size_t n);
-// RFC 9380 expand_message_xmd(SHA-256) -> one Fr element (gnark-crypto fr.Hash(msg, dst, 1)), canonical
+// RFC 9380 expand_message_xmd(SHA-256): out_len <= 255 * 32 uniform bytes; false when dst / out_len exceed the RFC's limits
+bool expand_message_xmd(const uint8_t *msg, size_t len, const uint8_t *dst, size_t dlen, uint8_t *out, size_t out_len);
+// ... -> one Fr element (gnark-crypto fr.Hash(msg, dst, 1)), canonical
 U256 hash_to_fr(const uint8_t *msg, size_t len, const char *dst);
 
 }  // namespace zk

@@ -34,6 +34,10 @@ struct ProofPoints {
     U256 ar[2], bs[4] /* x.a0 x.a1 y.a0 y.a1 */, krs[2], commitment[2], pok[2];
 };
 
+// A witness element that does not fit the u32 assignment the request layer packs (ZkpProveWitness accepts any gnark witness vector:
+// 32-byte field elements): written over the solver's input row after the u32 assignment.  value: canonical.
+struct WideInput { uint32_t instance, index; U256 value; };
+
 struct PhaseTimes {   // milliseconds, device time measured with HIP events on the prover's stream
     float solve = 0, commit = 0, ntt = 0, msm_g1 = 0, msm_g2 = 0, finalize = 0, total = 0;
     float z_segments = 0;   // the dominant kernel alone: k_msm_accumulate<Fp, true> of the quotient MSM
@@ -81,8 +85,9 @@ class Algorithm {
     // constant one, then secret).  r, s, randomize: [batch] canonical Fr (randomize may be null when
     // the circuit has no Randomize hint).  Results in out[batch]; errs[batch] = solver error words
     // (0 = ok).  Work is processed in chunks of at most `chunk` instances.
+    // wide (optional, single-chunk batches only): elements of the assignment that are wider than 32 bits
     void prove_batch(size_t batch, const uint32_t *inputs, const U256 *r, const U256 *s, const U256 *randomize, ProofPoints *out,
-                     uint32_t *errs, PhaseTimes *times = nullptr);
+                     uint32_t *errs, PhaseTimes *times = nullptr, const WideInput *wide = nullptr, size_t n_wide = 0);
 
     // the same over chunks pulled from a feed (several replicas may pull from one feed: dynamic sharing of a batch between devices)
     void prove_stream(ChunkFeed &feed, PhaseTimes *times = nullptr);
@@ -127,7 +132,7 @@ class Algorithm {
     void collect_times(struct SolveSet &S, PhaseTimes *times);
     std::unique_ptr<Resident> res;
     void resident_reserve(size_t B);
-    void resident_upload(size_t B, const uint32_t *inputs_rowmajor_instance, const U256 *r, const U256 *s, const U256 *randomize);
+    void resident_upload(size_t B, const uint32_t *inputs_rowmajor_instance, const U256 *r, const U256 *s, const U256 *randomize, const WideInput *wide = nullptr, size_t n_wide = 0);
     void resident_prove(PhaseTimes *times);                  // one batch, one stream
     void resident_prove_pipelined(int nsteps, PhaseTimes *times);   // timed region of bench.py: solve(k+1) under NTT+MSM(k)
     void resident_download(ProofPoints *out, uint32_t *errs);

@@ -1,6 +1,7 @@
 // Groth16 batch pipeline on one MI355X (see prover.h).
 #include "prover.h"
 #include "fixedbase.cuh"
+#include "xmd.cuh"
 #include <string.h>
 #include <algorithm>
 
@@ -108,6 +109,8 @@ struct SolveSet {
     DevBuf<U256> chal;
     DevBuf<U256> r, s, rnd;            // blinding scalars and the Randomize hint value of this batch (canonical)
     DevBuf<ProofPoints> out;           // proofs of this batch
+    DevBuf<WideInput> wide;            // assignment elements wider than 32 bits (ZkpProveWitness; none for the request path)
+    size_t n_wide = 0;
     std::vector<G1Affine> h_com;
     std::vector<U256> h_chal;
     hipEvent_t solved = nullptr, consumed = nullptr, uploaded = nullptr, t0 = nullptr, t1 = nullptr, t2 = nullptr, t3 = nullptr;
@@ -287,6 +290,15 @@ __global__ __launch_bounds__(64) void k_u256_to_mont(const U256 *in, Fr *out, si
     for (int k = 0; k < 8; k++) v.l[k] = in[i].l[k];
     out[i] = v.to_mont();
 }
+// wires row (index + 1) of instance `instance` <- value (the u32 assignment of solver_begin wrote a placeholder there)
+__global__ __launch_bounds__(64) void k_wide_inputs(const WideInput *__restrict__ wide, size_t n, Fr *__restrict__ wires, size_t B) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr v;
+#pragma unroll
+    for (int k = 0; k < 8; k++) v.l[k] = wide[i].value.l[k];
+    wires[((size_t)wide[i].index + 1) * B + wide[i].instance] = v.to_mont();
+}
 __device__ __forceinline__ void store_fp(U256 &dst, const Fp &v) {
 #pragma unroll
     for (int k = 0; k < 8; k++) dst.l[k] = v.l[k];
@@ -378,80 +390,26 @@ __global__ void k_store_commit(const G1Affine *com, const G1Affine *pok, ProofPo
 // challenge = fr.Hash(commitment.Marshal(), "bsb22-commitment", 1)[0]  (gnark backend/groth16/bn254/prove.go; gnark-crypto
 // field/hash: RFC 9380 expand_message_xmd with SHA-256, 48 bytes, big-endian, reduced mod r).  One thread per proof: five
 // SHA-256 compressions and one 384-bit reduction; keeps the solve stage stream-ordered (no device-host round trip in the
-// middle of the witness solve).  Same bytes as hostutil.cpp::hash_to_fr, which the parity tests pin against the oracle.
-__device__ __forceinline__ uint32_t sha_rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
-__device__ void sha256_block(uint32_t st[8], const uint32_t w_in[16]) {
-    static const uint32_t K[64] = {
-        0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3,
-        0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
-        0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13,
-        0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
-        0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
-        0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
-    uint32_t w[64];
-    for (int i = 0; i < 16; i++) w[i] = w_in[i];
-    for (int i = 16; i < 64; i++) {
-        const uint32_t s0 = sha_rotr(w[i - 15], 7) ^ sha_rotr(w[i - 15], 18) ^ (w[i - 15] >> 3);
-        const uint32_t s1 = sha_rotr(w[i - 2], 17) ^ sha_rotr(w[i - 2], 19) ^ (w[i - 2] >> 10);
-        w[i] = w[i - 16] + s0 + w[i - 7] + s1;
-    }
-    uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
-    for (int i = 0; i < 64; i++) {
-        const uint32_t S1 = sha_rotr(e, 6) ^ sha_rotr(e, 11) ^ sha_rotr(e, 25);
-        const uint32_t ch = (e & f) ^ (~e & g);
-        const uint32_t t1 = h + S1 + ch + K[i] + w[i];
-        const uint32_t S0 = sha_rotr(a, 2) ^ sha_rotr(a, 13) ^ sha_rotr(a, 22);
-        const uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
-        const uint32_t t2 = S0 + mj;
-        h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
-    }
-    st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
-}
-__device__ __forceinline__ void sha256_iv(uint32_t st[8]) {
-    st[0] = 0x6a09e667; st[1] = 0xbb67ae85; st[2] = 0x3c6ef372; st[3] = 0xa54ff53a; st[4] = 0x510e527f; st[5] = 0x9b05688c; st[6] = 0x1f83d9ab; st[7] = 0x5be0cd19;
-}
+// middle of the witness solve).  The expander is the general device function of xmd.cuh, which the parity tests run against the
+// RFC's published vectors; the bytes equal hostutil.cpp::hash_to_fr's (tests: proofs with commitments == oracle).
 // com: canonical affine commitments (little-endian limbs; infinity = zeros, serialised as zero bytes like the host code);
 // challenge: Montgomery form, as the solver reads it
 __global__ __launch_bounds__(64) void k_bsb22_challenge(const G1Affine *__restrict__ com, Fr *__restrict__ challenge, size_t B) {
     const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    const uint32_t DST[4] = {0x62736232u, 0x322d636fu, 0x6d6d6974u, 0x6d656e74u};      // "bsb22-commitment", big-endian words
-    // msg = X || Y, 32-byte big-endian each = limbs 7..0 as big-endian words
-    uint32_t m[16];
-    for (int i = 0; i < 8; i++) { m[i] = com[b].x.l[7 - i]; m[8 + i] = com[b].y.l[7 - i]; }
-    uint32_t b0[8], b1[8], b2[8], w[16];
-    // b0 = H(Z_pad(64) || msg(64) || 0x0030 || 0x00 || DST || 0x10): 148 bytes -> 3 blocks
-    sha256_iv(b0);
-    for (int i = 0; i < 16; i++) w[i] = 0;
-    sha256_block(b0, w);
-    sha256_block(b0, m);
-    w[0] = 0x00300000u | (DST[0] >> 24);                                            // 00 30 00 'b'
-    w[1] = (DST[0] << 8) | (DST[1] >> 24); w[2] = (DST[1] << 8) | (DST[2] >> 24); w[3] = (DST[2] << 8) | (DST[3] >> 24);
-    w[4] = (DST[3] << 8) | 0x10u;                                                   // ... 't' 0x10
-    w[5] = 0x80000000u;
-    for (int i = 6; i < 15; i++) w[i] = 0;
-    w[15] = 148 * 8;
-    sha256_block(b0, w);
-    // b_i = H((b0 ^ b_{i-1}) || i || DST || 0x10): 50 bytes -> 1 block
-    auto tail_block = [&](const uint32_t in[8], uint32_t idx, uint32_t out[8]) {
-        uint32_t t[16];
-        for (int i = 0; i < 8; i++) t[i] = in[i];
-        t[8] = (idx << 24) | (DST[0] >> 8);
-        t[9] = (DST[0] << 24) | (DST[1] >> 8); t[10] = (DST[1] << 24) | (DST[2] >> 8); t[11] = (DST[2] << 24) | (DST[3] >> 8);
-        t[12] = (DST[3] << 24) | (0x10u << 16) | 0x8000u;
-        t[13] = 0; t[14] = 0; t[15] = 50 * 8;
-        sha256_iv(out);
-        sha256_block(out, t);
-    };
-    tail_block(b0, 1, b1);
-    uint32_t x[8];
-    for (int i = 0; i < 8; i++) x[i] = b0[i] ^ b1[i];
-    tail_block(x, 2, b2);
-    // uniform = b1 || b2[0..15] as a 384-bit big-endian integer = hi * 2^256 + lo, hi = first 16 bytes
+    const uint8_t DST[16] = {'b', 's', 'b', '2', '2', '-', 'c', 'o', 'm', 'm', 'i', 't', 'm', 'e', 'n', 't'};
+    // msg = G1Affine.Marshal() = X || Y, 32 bytes big-endian each  [gnark-mem: uncompressed form, no public committed values]
+    uint8_t m[64], uni[48];
+    for (int i = 0; i < 8; i++) {
+        const uint32_t x = com[b].x.l[7 - i], y = com[b].y.l[7 - i];
+        m[4 * i] = (uint8_t)(x >> 24); m[4 * i + 1] = (uint8_t)(x >> 16); m[4 * i + 2] = (uint8_t)(x >> 8); m[4 * i + 3] = (uint8_t)x;
+        m[32 + 4 * i] = (uint8_t)(y >> 24); m[32 + 4 * i + 1] = (uint8_t)(y >> 16); m[32 + 4 * i + 2] = (uint8_t)(y >> 8); m[32 + 4 * i + 3] = (uint8_t)y;
+    }
+    expand_message_xmd_dev(m, 64, DST, 16, uni, 48);
+    // uniform bytes as a 384-bit big-endian integer = hi * 2^256 + lo, hi = first 16 bytes
     Fr hi = Fr::zero(), lo;
-    for (int i = 0; i < 4; i++) hi.l[3 - i] = b1[i];
-    for (int i = 0; i < 4; i++) lo.l[7 - i] = b1[4 + i];
-    for (int i = 0; i < 4; i++) lo.l[3 - i] = b2[i];
+    for (int i = 0; i < 4; i++) hi.l[3 - i] = ((uint32_t)uni[4 * i] << 24) | ((uint32_t)uni[4 * i + 1] << 16) | ((uint32_t)uni[4 * i + 2] << 8) | uni[4 * i + 3];
+    for (int i = 0; i < 8; i++) lo.l[7 - i] = ((uint32_t)uni[16 + 4 * i] << 24) | ((uint32_t)uni[16 + 4 * i + 1] << 16) | ((uint32_t)uni[16 + 4 * i + 2] << 8) | uni[16 + 4 * i + 3];
     // Montgomery form of (hi R + lo) mod r  (R = 2^256; to_mont accepts any 256-bit operand)
     challenge[b] = hi.to_mont().to_mont() + lo.to_mont();
 }
@@ -569,8 +527,13 @@ void Algorithm::wire_comb_prepare(size_t B) {
     const size_t ni = prog.n_inputs, Bc = std::min(calib_inputs.size() / ni, R.cap), nw = prog.n_wires;
     if (!Bc) return;
     SolveSet &S = R.set[0];
-    const size_t B_saved = R.B;
-    // 1. calibration solve (set 0 is free: nothing has been uploaded for the batch being reserved yet)
+    // 1. calibration solve (set 0 is free: nothing has been uploaded for the batch being reserved yet).  The batch size of the set is
+    // borrowed for it and put back on every way out (an allocation or HIP error below reaches resident_reserve's retry loop).
+    struct RestoreB {
+        Resident &R; SolveSet &S; size_t B, sbB, msB; bool armed = true;
+        void now() { if (armed) { R.B = B; S.sb.B = sbB; R.ms.B = msB; armed = false; } }
+        ~RestoreB() { now(); }
+    } restore{R, S, R.B, S.sb.B, R.ms.B};
     R.B = Bc; S.sb.B = Bc; R.ms.B = Bc;
     std::vector<U256> ones(Bc);
     for (auto &v : ones) { memset(v.l, 0, 32); v.l[0] = 1; }
@@ -584,7 +547,7 @@ void Algorithm::wire_comb_prepare(size_t B) {
     ZK_HIP(hipMemcpyAsync(cls.data(), dcls.p, nw, hipMemcpyDeviceToHost, R.stream));
     ZK_HIP(hipStreamSynchronize(R.stream));
     ZK_HIP(hipStreamSynchronize(R.copy_stream));
-    R.B = B_saved; S.sb.B = B_saved; R.ms.B = B_saved;
+    restore.now();
     for (uint32_t e : errs)
         if (e) { fprintf(stderr, "zkprove: wire-comb calibration: the synthetic witnesses did not solve (error word %u): wire MSMs keep the bucket pipeline\n", e); return; }
     size_t nwide = 0;
@@ -599,11 +562,20 @@ void Algorithm::wire_comb_prepare(size_t B) {
         for (size_t j = 0; j < mb.n; j++) c[j] = cls[rows[j]];
         return msm_attach_wire_comb(mb, c.data(), wire_comb_k(), R.stream);
     };
-    bool ok = attach(pk.A) && attach(pk.B1) && attach(pk.K) && attach(pk.B2);
-    if (ok && has_commit) ok = attach(pk.ped) && attach(pk.ped_sigma);
-    if (!ok) {
+    auto detach_all = [&] {
         for (MsmBasesG1 *mb : {&pk.A, &pk.B1, &pk.K, &pk.ped, &pk.ped_sigma}) { mb->wcomb.clear(); mb->wide_mask.release(); }
         pk.B2.wcomb.clear(); pk.B2.wide_mask.release();
+    };
+    bool ok = false;
+    try {
+        ok = attach(pk.A) && attach(pk.B1) && attach(pk.K) && attach(pk.B2);
+        if (ok && has_commit) ok = attach(pk.ped) && attach(pk.ped_sigma);
+    } catch (...) {
+        detach_all();          // a table allocation failed half way (memory pressure): nothing half-attached stays behind, unused and unfreed
+        throw;
+    }
+    if (!ok) {
+        detach_all();
         fprintf(stderr, "zkprove: wire-comb tables not built (degenerate bases): wire MSMs keep the bucket pipeline\n");
         return;
     }
@@ -651,14 +623,17 @@ void Algorithm::resident_reserve(size_t B) {
         for (auto &e : res->ev) ZK_HIP(hipEventCreate(&e));
     }
     Resident &R = *res;
-    const size_t cap_before = R.cap;
     for (int attempt = 0;; attempt++) {
         try {
             resident_reserve_buffers(B);
             break;
         } catch (const ZkError &) {
             (void)hipGetLastError();
-            R.cap = cap_before;
+            // DevBuf::alloc releases before it allocates: the buffer whose growth failed is EMPTY now, so no capacity recorded before
+            // the failure may survive it -- neither for the retry nor, when the retries run out, for the next (smaller) call, which
+            // would otherwise skip its ensure() calls and launch kernels on a null pointer.  Every reservation is "grow if smaller",
+            // so starting from zero costs nothing for the buffers that are still in place.
+            R.cap = 0; R.dense_cap = 0; R.comb_cap = 0; R.B = 0;
             if (attempt >= 5 || !relieve_pressure(false)) throw;      // memory-pressure valve, see comb_release
         }
     }
@@ -736,6 +711,7 @@ void Algorithm::resident_reserve_buffers(size_t B) {
 
 // inputs [B][n_inputs] (instance-major, as the host builds them), r / s / randomize [B] canonical -> set S, on stream st
 void Algorithm::upload_set(SolveSet &S, size_t B, const uint32_t *inputs, const U256 *r, const U256 *s, const U256 *randomize, hipStream_t st) {
+    S.n_wide = 0;
     ZK_HIP(hipMemcpyAsync(S.sb.inputs.p, inputs, prog.n_inputs * B * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     ZK_HIP(hipMemcpyAsync(S.r.p, r, B * sizeof(U256), hipMemcpyHostToDevice, st));
     ZK_HIP(hipMemcpyAsync(S.s.p, s, B * sizeof(U256), hipMemcpyHostToDevice, st));
@@ -743,11 +719,20 @@ void Algorithm::upload_set(SolveSet &S, size_t B, const uint32_t *inputs, const 
     else ZK_HIP(hipMemsetAsync(S.rnd.p, 0, B * sizeof(U256), st));
 }
 
-void Algorithm::resident_upload(size_t B, const uint32_t *inputs, const U256 *r, const U256 *s, const U256 *randomize) {
+void Algorithm::resident_upload(size_t B, const uint32_t *inputs, const U256 *r, const U256 *s, const U256 *randomize, const WideInput *wide, size_t n_wide) {
     resident_reserve(B);
     Resident &R = *res;
     for (auto &S : R.set)
-        if (S.ready) upload_set(S, B, inputs, r, s, randomize, R.stream);
+        if (S.ready) {
+            upload_set(S, B, inputs, r, s, randomize, R.stream);
+            if (n_wide) {
+                for (size_t i = 0; i < n_wide; i++)
+                    if (wide[i].instance >= B || wide[i].index >= prog.n_inputs) throw ZkError("wide witness element out of range");
+                S.wide.ensure(n_wide);
+                ZK_HIP(hipMemcpyAsync(S.wide.p, wide, n_wide * sizeof(WideInput), hipMemcpyHostToDevice, R.stream));
+                S.n_wide = n_wide;
+            }
+        }
     ZK_HIP(hipStreamSynchronize(R.stream));
 }
 
@@ -759,6 +744,7 @@ void Algorithm::enqueue_solve(SolveSet &S, MsmScratch &commit_scratch, hipStream
     ZK_HIP(hipEventRecord(S.t0, st));
     hipLaunchKernelGGL(k_u256_to_mont, dim3(ceil_div(B, 64)), dim3(64), 0, st, S.rnd.p, S.sb.randomize.p, B);
     solver_begin(prog, S.sb, st);
+    if (S.n_wide) hipLaunchKernelGGL(k_wide_inputs, dim3(ceil_div(S.n_wide, 64)), dim3(64), 0, st, S.wide.p, S.n_wide, S.sb.wires.p, B);
     if (has_commit) {
         solver_run_levels(prog, S.sb, 0, commit_level, st);
         ZK_HIP(hipEventRecord(S.t1, st));
@@ -1049,7 +1035,7 @@ void Algorithm::resident_prove(PhaseTimes *times) {
 // algorithm holds comb tables (a third circuit with large batches on the same GPU), the tables and their scratch are given back and the
 // quotient / wire MSMs of this algorithm return to the table-free bucket pipeline.
 bool Algorithm::comb_drop_tables() {
-    if (!pk.Zcomb.ok && !wire_comb_on) return false;
+    if (comb_table_bytes() == 0) return false;
     Resident &R = *res;
     ZK_HIP(hipDeviceSynchronize());
     (void)hipGetLastError();
@@ -1280,15 +1266,16 @@ void Algorithm::resident_download(ProofPoints *out, uint32_t *errs) {
 // resident_prove_pipelined does with repeated passes (solve of chunk k+1 and tail of chunk k-1 under the NTT + MSM stage of chunk k),
 // with the uploads / downloads on a copy stream, so callers of ProveBatch see the pipelined rate.
 void Algorithm::prove_batch(size_t batch, const uint32_t *inputs, const U256 *r, const U256 *s, const U256 *randomize, ProofPoints *out,
-                            uint32_t *errs, PhaseTimes *times) {
+                            uint32_t *errs, PhaseTimes *times, const WideInput *wide, size_t n_wide) {
     std::unique_lock<std::mutex> lk(mu);
     last_use = ++g_use_clock;
     comb_second_chance();
     DeviceScope on_device(device);
     const size_t ni = prog.n_inputs;
     const size_t nchunks = (batch + max_chunk - 1) / max_chunk;
+    if (n_wide && nchunks > 1) throw ZkError("prove_batch: wide witness elements are supported for single-chunk batches only");
     if (nchunks <= 1) {
-        resident_upload(batch, inputs, r, s, randomize);
+        resident_upload(batch, inputs, r, s, randomize, wide, n_wide);
         PhaseTimes t;
         resident_prove(&t);
         resident_download(out, errs);

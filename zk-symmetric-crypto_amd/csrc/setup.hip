@@ -111,15 +111,12 @@ __global__ void k_generators(G1Affine *g1, G2Affine *g2) {
     if (threadIdx.x || blockIdx.x) return;
     g1->x = Fp::from_u32(1); g1->y = Fp::from_u32(2);
     // standard BN254 G2 generator (gnark-crypto bn254.go), canonical limbs -> Montgomery
-    const uint32_t X0[8] = {0xd992f6edu, 0x46debd5cu, 0xf75edaddu, 0x674322d4u, 0x5e5c4479u, 0x426a0066u, 0x121f1e76u, 0x1800deefu};
-    const uint32_t X1[8] = {0xaef312c2u, 0x97e485b7u, 0x35a9e712u, 0xf1aa4933u, 0x31fb5d25u, 0x7260bfb7u, 0x920d483au, 0x198e9393u};
-    const uint32_t Y0[8] = {0x66fa7daau, 0x4ce6cc01u, 0x0c43d37bu, 0xe3d1e769u, 0x8dcb408fu, 0x4aab7180u, 0xdb8c6debu, 0x12c85ea5u};
-    const uint32_t Y1[8] = {0xd122975bu, 0x55acdadcu, 0x70b38ef3u, 0xbc4b3133u, 0x690c3395u, 0xec9e99adu, 0x585ff075u, 0x090689d0u};
+#include "g2_generator.inc"
     Fp t;
-    for (int k = 0; k < 8; k++) t.l[k] = X0[k]; g2->x.a0 = t.to_mont();
-    for (int k = 0; k < 8; k++) t.l[k] = X1[k]; g2->x.a1 = t.to_mont();
-    for (int k = 0; k < 8; k++) t.l[k] = Y0[k]; g2->y.a0 = t.to_mont();
-    for (int k = 0; k < 8; k++) t.l[k] = Y1[k]; g2->y.a1 = t.to_mont();
+    for (int k = 0; k < 8; k++) t.l[k] = G2_GEN_X0[k]; g2->x.a0 = t.to_mont();
+    for (int k = 0; k < 8; k++) t.l[k] = G2_GEN_X1[k]; g2->x.a1 = t.to_mont();
+    for (int k = 0; k < 8; k++) t.l[k] = G2_GEN_Y0[k]; g2->y.a0 = t.to_mont();
+    for (int k = 0; k < 8; k++) t.l[k] = G2_GEN_Y1[k]; g2->y.a1 = t.to_mont();
 }
 
 // ---- byte writers (gnark-crypto marshal.go conventions; see oracle/gnark_format.py for the decoded layout)

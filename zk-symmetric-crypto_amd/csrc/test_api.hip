@@ -12,14 +12,12 @@ using namespace zk;
 void fp_to_mont_dev(void *p, size_t count, hipStream_t s);
 void fp_from_mont_dev(void *p, size_t count, hipStream_t s);
 
-static thread_local std::string g_last_error;
-extern "C" const char *zkp_last_error(void) { return g_last_error.c_str(); }
 
 #define ZKP_TRY try { zk::bind_default_device();
 #define ZKP_CATCH(rv)                         \
     }                                         \
     catch (const std::exception &e) {         \
-        g_last_error = e.what();              \
+        zk::set_last_error(e.what());         \
         fprintf(stderr, "zkprove: %s\n", e.what()); \
         return rv;                            \
     }
@@ -39,11 +37,6 @@ static uint32_t brev(uint32_t v, int bits) {
     return r;
 }
 
-extern "C" int zkp_device_count(void) {
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
-    return n;
-}
 
 // mode 0: forward via DIF, 1: inverse via DIF, 2: forward via DIT, 3: inverse via DIT.  natural order in/out.
 extern "C" int zkp_ntt(int logn, long batch, uint8_t *data, int mode) {
@@ -732,3 +725,63 @@ extern "C" int zkp_debug_tree(int n, int c, int piece, int dbg) {
     ZKP_CATCH(-1)
 }
 #endif  // ZK_EXPERIMENTS
+
+// ------------------------------------------------------------------------------------ pins (tests/test_pins.py, tests/test_gpu_pins.py)
+#include "hostutil.h"
+#include "xmd.cuh"
+namespace zk {
+int pairing_product_check(const uint8_t *g1_raw, const uint8_t *g2_raw, size_t n, bool on_device);      // verifier.cpp
+int vk_pairing_identities(const uint8_t *vk_bytes, size_t len, bool on_device);
+}
+// prod e(P_i, Q_i) == 1 through the verifier's host pairing (device = 0) or with the Miller loops in the batch verifier's kernel
+// (device = 1); points in gnark-crypto's uncompressed encoding.  1 / 0, -1: undecodable / error
+extern "C" int zkp_pairing_product_check(const uint8_t *g1_raw, const uint8_t *g2_raw, long n, int device) {
+    try {
+        return zk::pairing_product_check(g1_raw, g2_raw, (size_t)n, device != 0);
+    } catch (const std::exception &e) { zk::set_last_error(e.what()); return -1; }
+}
+// bit 0: e(beta1, G2) == e(G1, beta2), bit 1: e(delta1, G2) == e(G1, delta2), for a key in gnark's VerifyingKey.WriteTo layout; -1: does not parse
+extern "C" int zkp_vk_pairing_identities(const uint8_t *vk, long len, int device) {
+    try {
+        return zk::vk_pairing_identities(vk, (size_t)len, device != 0);
+    } catch (const std::exception &e) { zk::set_last_error(e.what()); return -1; }
+}
+__global__ void k_xmd_test(const uint8_t *msg, uint32_t mlen, const uint8_t *dst, uint32_t dlen, uint8_t *out, uint32_t out_len) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) expand_message_xmd_dev(msg, mlen, dst, dlen, out, out_len);
+}
+// RFC 9380 expand_message_xmd(SHA-256): device = 0 the host function behind hostutil.cpp::hash_to_fr (verifier), device = 1 the device
+// function behind k_bsb22_challenge (prover)
+extern "C" int zkp_expand_message_xmd(const uint8_t *msg, long mlen, const uint8_t *dst, long dlen, uint8_t *out, long out_len, int device) {
+    if (mlen < 0 || dlen < 0 || dlen > 255 || out_len < 0 || out_len > 255 * 32) return -1;
+    if (!device) return zk::expand_message_xmd(msg, (size_t)mlen, dst, (size_t)dlen, out, (size_t)out_len) ? 0 : -1;
+    ZKP_TRY
+    DevBuf<uint8_t> dm((size_t)mlen + 1), dd((size_t)dlen + 1), dout((size_t)out_len + 1);
+    if (mlen) ZK_HIP(hipMemcpy(dm.p, msg, (size_t)mlen, hipMemcpyHostToDevice));
+    if (dlen) ZK_HIP(hipMemcpy(dd.p, dst, (size_t)dlen, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_xmd_test, dim3(1), dim3(64), 0, 0, dm.p, (uint32_t)mlen, dd.p, (uint32_t)dlen, dout.p, (uint32_t)out_len);
+    ZK_HIP(hipGetLastError());
+    if (out_len) ZK_HIP(hipMemcpy(out, dout.p, (size_t)out_len, hipMemcpyDeviceToHost));
+    return 0;
+    ZKP_CATCH(-1)
+}
+// the prover's challenge kernel on n commitments: com = n x (x | y) canonical little-endian 32-byte coordinates -> n canonical LE Fr
+extern "C" int zkp_bsb22_challenge(const uint8_t *com, long n, uint8_t *out) {
+    ZKP_TRY
+    const size_t N = (size_t)n;
+    DevBuf<G1Affine> dc(N);
+    DevBuf<Fr> dr(N);
+    ZK_HIP(hipMemcpy(dc.p, com, N * 64, hipMemcpyHostToDevice));
+    bsb22_challenge_device(dc.p, dr.p, N, 0);
+    fr_from_mont(dr.p, N, 0);
+    ZK_HIP(hipMemcpy(out, dr.p, N * 32, hipMemcpyDeviceToHost));
+    return 0;
+    ZKP_CATCH(-1)
+}
+// host-side counterpart (verifier.cpp's path): hash_to_fr(X || Y big-endian, "bsb22-commitment")
+extern "C" int zkp_bsb22_challenge_host(const uint8_t *com_be64, long n, uint8_t *out) {
+    for (long i = 0; i < n; i++) {
+        const zk::U256 v = zk::hash_to_fr(com_be64 + 64 * i, 64, "bsb22-commitment");
+        memcpy(out + 32 * i, v.l, 32);
+    }
+    return 0;
+}

@@ -270,7 +270,16 @@ static void vk_parse(const uint8_t *p, size_t len, VerifyingKey &vk) {
     if (c.pos != len) throw ZkError("trailing bytes in verifying key");
 }
 
-std::unique_ptr<VerifyingKey> g_vk[3];
+// The key of an algorithm is immutable once published; ZkpInitVerifier swaps in a new object under the lock and bumps the version.
+// Readers take a reference (shared ownership) TOGETHER with the version it carries, both under the lock: a concurrent re-init can
+// neither free the key a call is still using nor make a device image built from the old key pass for the new one.
+struct VkRef {
+    std::shared_ptr<const VerifyingKey> vk;
+    uint64_t version = 0;
+    explicit operator bool() const { return (bool)vk; }
+};
+std::shared_ptr<const VerifyingKey> g_vk[3];
+uint64_t g_vk_version[3] = {0, 0, 0};      // bumped whenever g_vk[alg] is replaced
 std::mutex g_vk_lock;
 const char *NAMES[3] = {"chacha20", "aes-128-ctr", "aes-256-ctr"};
 
@@ -349,8 +358,8 @@ static bool parse_request(const uint8_t *data, size_t len, ParsedReq &rq) {
     rq.alg = alg;
     return true;
 }
-// the verifying key of an algorithm (ZkpInitVerifier, else vk.<ext> from $ZKPROVE_VK_DIR or from beside the library); nullptr: none
-static const VerifyingKey *load_vk(int alg);
+// the verifying key of an algorithm (ZkpInitVerifier, else vk.<ext> from $ZKPROVE_VK_DIR or from beside the library); empty: none
+static VkRef load_vk(int alg);
 static bool verify_parsed(const ParsedReq &rq, const VerifyingKey &vk) {
     const std::vector<uint8_t> &proof = rq.proof;
     const std::vector<uint32_t> &pub = rq.pub;
@@ -406,7 +415,7 @@ static bool verify_parsed(const ParsedReq &rq, const VerifyingKey &vk) {
     return ok;
 }
 
-static const VerifyingKey *load_vk(int alg) {
+static VkRef load_vk(int alg) {
     std::unique_lock<std::mutex> lk(g_vk_lock);
     if (!g_vk[alg]) {
         // the reference embeds generated/vk.* at build time (verifier/impl/library.go:92-160), so its `Verify` works with no set-up call.
@@ -431,22 +440,22 @@ static const VerifyingKey *load_vk(int alg) {
                 size_t n;
                 while ((n = fread(tmp, 1, sizeof(tmp), f)) > 0) buf.insert(buf.end(), tmp, tmp + n);
                 fclose(f);
-                std::unique_ptr<VerifyingKey> k(new VerifyingKey());
+                std::shared_ptr<VerifyingKey> k(new VerifyingKey());
                 vk_parse(buf.data(), buf.size(), *k);
                 g_vk[alg] = std::move(k);
+                g_vk_version[alg]++;
                 break;
             }
         }
     }
-    return g_vk[alg].get();
+    return VkRef{g_vk[alg], g_vk_version[alg]};
 }
 static bool verify_impl(const uint8_t *data, size_t len) {
     ParsedReq rq;
     if (!parse_request(data, len, rq)) return false;
-    const VerifyingKey *vk = load_vk(rq.alg);
-    if (!vk) { printf("verifying key for %s is not initialised\n", NAMES[rq.alg]); return false; }
-    const VerifyingKey copy = *vk;          // ZkpInitVerifier may replace the key while this call runs
-    return verify_parsed(rq, copy);
+    const VkRef ref = load_vk(rq.alg);      // shared ownership: ZkpInitVerifier may replace the key while this call runs
+    if (!ref) { printf("verifying key for %s is not initialised\n", NAMES[rq.alg]); return false; }
+    return verify_parsed(rq, *ref.vk);
 }
 
 
@@ -547,8 +556,8 @@ __global__ __launch_bounds__(64) void k_vb_miller(const VbPair *__restrict__ pai
 
 // device-side image of a verifying key: the K bases prepared for batched MSMs
 struct VkDevice {
-    const VerifyingKey *src = nullptr;      // identity of the key it was built from
-    uint64_t version = 0;
+    uint64_t version = 0;                   // version of the key it was built from (VkRef::version; 0 = nothing built)
+    int device = -1;                        // ... and the device that holds it
     MsmBasesG1 K;                           // K_1 .. K_npub, row j = public input j
     size_t npub = 0;
     MsmScratch scratch;
@@ -556,28 +565,41 @@ struct VkDevice {
 };
 static std::mutex g_vb_lock;                // one batch at a time (device buffers are shared)
 static VkDevice g_vkdev[3];
-static uint64_t g_vk_version[3] = {0, 0, 0};      // bumped by ZkpInitVerifier
 
 static constexpr int C_VK = 8;              // window bits of the (rare) non-0/1 public inputs: bytes and 32-bit counters of the AES circuits
 
 // true: the random-linear-combination check holds for proofs idx[]; false: it does not (or the device path declined)
-static bool verify_batch_device(int alg, const VerifyingKey &vk, const std::vector<ParsedReq> &reqs, const std::vector<size_t> &idx, double *ms_out) {
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+    EventPair() { ZK_HIP(hipEventCreate(&a)); if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); throw ZkError("hipEventCreate failed"); } }
+    ~EventPair() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
+    EventPair(const EventPair &) = delete;
+    EventPair &operator=(const EventPair &) = delete;
+};
+static bool verify_batch_device(int alg, const VkRef &ref, const std::vector<ParsedReq> &reqs, const std::vector<size_t> &idx, double *ms_out) {
+    const VerifyingKey &vk = *ref.vk;
     const size_t n = idx.size(), npub = reqs[idx[0]].pub.size();
     const bool has_commit = !vk.ckeys.empty();
     if (vk.K.size() != 1 + npub + (has_commit ? 1 : 0)) return false;
     if (has_commit && (vk.ckeys.size() != 1 || vk.pub_committed.size() != 1 || !vk.pub_committed[0].empty())) return false;
     std::lock_guard<std::mutex> lk(g_vb_lock);
-    bind_default_device();
+    const int dev = default_device();
+    DeviceScope on_device(dev);             // the caller thread's current device is the host application's: put back on exit
     hipStream_t st = 0;
     VkDevice &vd = g_vkdev[alg];
-    if (vd.version != g_vk_version[alg] || vd.npub != npub || !vd.K.n) {
+    if (vd.device != dev && vd.device >= 0) {
+        // ZkpSetDevice / ZkpReset chose another GPU since the image was built: its buffers belong to the old device
+        DeviceScope old(vd.device);
+        vd = VkDevice();
+    }
+    if (vd.version != ref.version || vd.npub != npub || !vd.K.n) {
         DevBuf<G1Affine> pts(npub);
         ZK_HIP(hipMemcpy(pts.p, vk.K.data() + 1, npub * sizeof(G1Affine), hipMemcpyHostToDevice));
         std::vector<uint32_t> rows(npub);
         for (size_t j = 0; j < npub; j++) rows[j] = (uint32_t)j;
         vd.K = MsmBasesG1();
         msm_bases_build(vd.K, pts.p, npub, rows.data(), C_VK, st);
-        vd.npub = npub; vd.version = g_vk_version[alg]; vd.cap = 0;
+        vd.npub = npub; vd.version = ref.version; vd.device = dev; vd.cap = 0;
     }
     if (vd.cap < n) {
         vd.scratch.reserve(n, npub * (size_t)vd.K.W, (size_t)1 << (C_VK - 1), msm_part_stride(npub, C_VK));
@@ -585,9 +607,8 @@ static bool verify_batch_device(int alg, const VerifyingKey &vk, const std::vect
         vd.scratch.reserve_sums(n, (size_t)1 << (C_VK - 1), 1);
         vd.cap = n;
     }
-    hipEvent_t e0, e1;
-    ZK_HIP(hipEventCreate(&e0)); ZK_HIP(hipEventCreate(&e1));
-    ZK_HIP(hipEventRecord(e0, st));
+    EventPair ev;
+    ZK_HIP(hipEventRecord(ev.a, st));
     // ---- proofs: compressed points gathered per kind
     std::vector<uint8_t> hA(n * 32), hB(n * 64), hC(n * 32), hCom(has_commit ? n * 32 : 0), hPok(has_commit ? n * 32 : 0);
     std::vector<uint32_t> hpub(n * npub);
@@ -659,11 +680,10 @@ static bool verify_batch_device(int alg, const VerifyingKey &vk, const std::vect
     uint32_t nbad = 0;
     fv.download(hf.data(), n + 5, st);
     bad.download(&nbad, 1, st);
-    ZK_HIP(hipEventRecord(e1, st));
+    ZK_HIP(hipEventRecord(ev.b, st));
     ZK_HIP(hipStreamSynchronize(st));
     float ms = 0;
-    ZK_HIP(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    ZK_HIP(hipEventElapsedTime(&ms, ev.a, ev.b));
     if (ms_out) *ms_out = ms;
     if (nbad) return false;                   // an undecodable point / a G2 point outside the subgroup somewhere in the batch
     // ---- host: product of the Miller values (tree over the host threads), one final exponentiation
@@ -694,33 +714,31 @@ static std::string verify_batch_json(const char *data, size_t len, double *devic
     if (!json_split_array(data, len, el, off, not_array)) return "[]";
     const size_t n = el.size();
     std::vector<ParsedReq> reqs(n);
-    std::vector<uint8_t> parsed(n, 0), result(n, 0), decided(n, 0);
+    std::vector<uint8_t> parsed(n, 0), result(n, 0);
     parallel_for(n, [&](size_t i) {
         try { parsed[i] = parse_request((const uint8_t *)data + el[i].first, el[i].second - el[i].first, reqs[i]) ? 1 : 0; } catch (const std::exception &) { parsed[i] = 0; }
     });
     // the requests of each algorithm form one device batch
     for (int alg = 0; alg < 3; alg++) {
-        const VerifyingKey *vkp = nullptr;
         std::vector<size_t> idx, host_only;
         for (size_t i = 0; i < n; i++) if (parsed[i] && reqs[i].alg == alg) idx.push_back(i);
         if (idx.empty()) continue;
-        vkp = load_vk(alg);
-        if (!vkp) { printf("verifying key for %s is not initialised\n", NAMES[alg]); for (size_t i : idx) decided[i] = 1; continue; }
-        const VerifyingKey vk = *vkp;
+        const VkRef ref = load_vk(alg);
+        if (!ref) { printf("verifying key for %s is not initialised\n", NAMES[alg]); continue; }
+        const VerifyingKey &vk = *ref.vk;
         std::vector<size_t> dev;
         for (size_t i : idx) (proof_fits_device_path(reqs[i].proof, !vk.ckeys.empty()) ? dev : host_only).push_back(i);
         bool batch_ok = false;
         int ndev = 0;
         if (dev.size() >= 16 && hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0) {
-            try { batch_ok = verify_batch_device(alg, vk, reqs, dev, device_ms); } catch (const std::exception &e) { fprintf(stderr, "zkprove: batch verifier: %s\n", e.what()); }
+            try { batch_ok = verify_batch_device(alg, ref, reqs, dev, device_ms); } catch (const std::exception &e) { fprintf(stderr, "zkprove: batch verifier: %s\n", e.what()); }
         }
-        if (batch_ok) { for (size_t i : dev) { result[i] = 1; decided[i] = 1; } }
+        if (batch_ok) { for (size_t i : dev) result[i] = 1; }
         else host_only.insert(host_only.end(), dev.begin(), dev.end());
         // everything else (and every proof of a batch that failed) individually, as Verify does
         parallel_for(host_only.size(), [&](size_t q) {
             const size_t i = host_only[q];
             try { result[i] = verify_parsed(reqs[i], vk) ? 1 : 0; } catch (const std::exception &) { result[i] = 0; }
-            decided[i] = 1;
         });
     }
     std::string out = "[";
@@ -729,6 +747,69 @@ static std::string verify_batch_json(const char *data, size_t len, double *devic
 }
 
 }  // namespace
+
+// ---- test hooks (C wrappers in test_api.hip; only the test library exports them) ---------------------------------------------------
+// prod_i e(P_i, Q_i) == 1 ?  Points in gnark-crypto's uncompressed encoding (G1: X | Y, G2: X.A1 | X.A0 | Y.A1 | Y.A0, big-endian),
+// decoded by the verifier's own reader (on-curve and subgroup checks included).  on_device: the Miller loops run in k_vb_miller, the
+// kernel of the batch verifier; product and final exponentiation on the host either way.  1 / 0, -1 on undecodable input.
+static int pairs_check(const std::vector<std::pair<G1Affine, G2Affine>> &pairs, bool on_device) {
+    if (!on_device) return pairing_product_is_one(pairs) ? 1 : 0;
+    const size_t n = pairs.size();
+    DeviceScope on_dev(default_device());
+    std::vector<VbPair> h(n);
+    for (size_t i = 0; i < n; i++) { h[i].p = pairs[i].first; h[i].q = pairs[i].second; }
+    DevBuf<VbPair> d(n);
+    DevBuf<Fp12> f(n);
+    DevBuf<uint32_t> bad(1);
+    bad.zero(0);
+    d.upload(h.data(), n, 0);
+    hipLaunchKernelGGL(k_vb_miller, dim3(ceil_div(n, 64)), dim3(64), 0, 0, d.p, n, f.p, bad.p);
+    ZK_HIP(hipGetLastError());
+    std::vector<Fp12> hf(n);
+    uint32_t nbad = 0;
+    f.download(hf.data(), n, 0);
+    bad.download(&nbad, 1, 0);
+    ZK_HIP(hipStreamSynchronize(0));
+    if (nbad) return 0;
+    Fp12 acc = Fp12::one();
+    for (auto &x : hf) acc = mul(acc, x);
+    return final_exp_is_one(acc) ? 1 : 0;
+}
+int pairing_product_check(const uint8_t *g1_raw, const uint8_t *g2_raw, size_t n, bool on_device) {
+    consts_init();
+    std::vector<std::pair<G1Affine, G2Affine>> pairs;
+    Cur c1{g1_raw, n * 64}, c2{g2_raw, n * 128};
+    for (size_t i = 0; i < n; i++) {
+        G1Affine p = c1.g1();
+        G2Affine q = c2.g2();
+        pairs.push_back({p, q});
+    }
+    return pairs_check(pairs, on_device);
+}
+// a verifying key in gnark's VerifyingKey.WriteTo layout through the verifier's own vk reader: bit 0 = e(beta1, G2) == e(G1, beta2),
+// bit 1 = e(delta1, G2) == e(G1, delta2) -- the two identities every honestly generated Groth16 key satisfies (G1, G2: the generators)
+int vk_pairing_identities(const uint8_t *vk_bytes, size_t len, bool on_device) {
+    consts_init();
+    VerifyingKey vk;
+    vk_parse(vk_bytes, len, vk);
+#include "g2_generator.inc"
+    auto fp = [](const uint32_t *l) { Fp t; for (int k = 0; k < 8; k++) t.l[k] = l[k]; return t.to_mont(); };
+    const G1Affine g1{Fp::from_u32(1), Fp::from_u32(2)};
+    const G2Affine g2{Fp2{fp(G2_GEN_X0), fp(G2_GEN_X1)}, Fp2{fp(G2_GEN_Y0), fp(G2_GEN_Y1)}};
+    int out = 0;
+    if (pairs_check({{vk.beta1, g2}, {g1_neg(g1), vk.beta2}}, on_device) == 1) out |= 1;
+    if (pairs_check({{vk.delta1, g2}, {g1_neg(g1), vk.delta2}}, on_device) == 1) out |= 2;
+    return out;
+}
+
+// ZkpReset: the device images of the verifying keys go with the prover's buffers (the host-side keys stay: they are not device state)
+void verifier_reset() {
+    std::lock_guard<std::mutex> lk(g_vb_lock);
+    for (auto &vd : g_vkdev) {
+        if (vd.device < 0) continue;
+        try { DeviceScope on_device(vd.device); vd = VkDevice(); } catch (const std::exception &) { vd = VkDevice(); }
+    }
+}
 }  // namespace zk
 
 extern "C" {
@@ -782,7 +863,7 @@ unsigned char ZkpInitVerifier(unsigned char algorithmID, GoSlice vk) {
     if (algorithmID >= 3) return 0;
     try {
         zk::consts_init();
-        std::unique_ptr<zk::VerifyingKey> k(new zk::VerifyingKey());
+        std::shared_ptr<zk::VerifyingKey> k(new zk::VerifyingKey());
         zk::vk_parse((const uint8_t *)vk.data, (size_t)vk.len, *k);
         std::lock_guard<std::mutex> lk(zk::g_vk_lock);
         zk::g_vk[algorithmID] = std::move(k);
