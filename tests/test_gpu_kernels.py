@@ -429,10 +429,15 @@ def test_msm_doubling_and_cancellation_inside_a_bucket(zk, oracle, group):
     ({"ZKPROVE_NTT_F9": "1"}, "test_ntt_matches_oracle or test_compute_h_matches_oracle or test_full_size_ntt"),
     ({"ZKPROVE_NTT_EIGHT": "1"}, "test_ntt_matches_oracle or test_compute_h_matches_oracle"),
     ({"ZKPROVE_MSM_F9": "0"}, "test_msm_g1_matches_oracle or test_msm_g2_matches_oracle or doubling"),
-], ids=["transforms_9limb", "transforms_two_pass_and_unfolded_compute_h", "buckets_8x32"])
+    ({"ZKPROVE_SOLVER_PERSIST": "16", "ZKP_CHILD_FILE": "test_gpu_prove.py"}, "test_batch_wires_quotient_and_proofs or test_prove_matches_oracle or test_unsatisfiable"),
+    ({"ZKPROVE_NTT_FUSE": "1", "ZKP_CHILD_FILE": "test_gpu_prove.py"}, "test_batch_wires_quotient_and_proofs"),
+], ids=["transforms_9limb", "transforms_two_pass_and_unfolded_compute_h", "buckets_8x32", "persistent_solver", "fused_middle_transform_pass"])
 def test_alternative_field_paths_stay_bit_exact(env, select):
     """The alternatives that were measured and lost -- the 9-limb butterflies of the transforms (ZKPROVE_NTT_F9=1, csrc/ntt.hip), the
-    bucket kernels on the 8 x 32 field (ZKPROVE_MSM_F9=0) and the batch-affine tree (ZKPROVE_MSM_TREE=1) -- are not in the product
+    bucket kernels on the 8 x 32 field (ZKPROVE_MSM_F9=0), the batch-affine tree (ZKPROVE_MSM_TREE=1) and the persistent small-batch
+    solver with the instructions on the lanes (ZKPROVE_SOLVER_PERSIST=16, csrc/solver.hip: wires, quotient and proofs of batches of
+    1, 7 and 12 against the oracle, unsatisfied instances flagged) and the fused middle pass of the transform pair (ZKPROVE_NTT_FUSE=1: the
+    quotient stage of 70- and 66-proof batches at the real domain sizes against the oracle) -- are not in the product
     library: they are compiled with -DZK_EXPERIMENTS into libzkprove_exp.so (make experiments), which this test loads through
     ZKPROVE_LIB and keeps bit-exact.  Same tests, own process (the switches are read once)."""
     import os, subprocess, sys
@@ -440,6 +445,7 @@ def test_alternative_field_paths_stay_bit_exact(env, select):
     exp = os.path.join(H.ROOT, "zk-symmetric-crypto_amd", "libzkprove_exp.so")
     assert os.path.exists(exp), "libzkprove_exp.so missing: run `make -C zk-symmetric-crypto_amd experiments` (__graft_entry__.build() does)"
     env = dict(env, ZKPROVE_LIB=exp)
-    res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(H.ROOT, "tests", "test_gpu_kernels.py"), "-x", "-q", "-m", "gpu", "-k", "(%s) and not alternative_field_paths" % select,      # never itself: the child would spawn a child
+    child_file = env.pop("ZKP_CHILD_FILE", "test_gpu_kernels.py")
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(H.ROOT, "tests", child_file), "-x", "-q", "-m", "gpu", "-k", "(%s) and not alternative_field_paths" % select,      # never itself: the child would spawn a child
                           "-p", "no:cacheprovider"], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600, cwd=H.ROOT)
     assert res.returncode == 0 and " passed" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]

@@ -756,6 +756,169 @@ static void dit_passes(int logn, Fr *data, size_t B, const Fr *tw, const Fr *pre
         logS += k;
     }
 }
+#ifdef ZK_EXPERIMENTS
+// ---------------------------------------------------------------------------------------------
+// EXPERIMENT (VERDICT r3 task 6; ZKPROVE_NTT_FUSE=1 in the experiments build): five HBM round trips per transform pair instead of six.
+// Bit-exact and SLOWER: 24.0 vs 22.3 ms for the four transforms of a 1024-batch at N = 2^16, 51.3 vs 46.8 ms at 2^17 (one box,
+// scripts/debug/ntt_prof.sh, profiles/r04d_ntt_fuse*.txt).  Per butterfly stage (a pair is 32 stages + the scaling = 2 more stages'
+// worth of products): the (3,3) passes 0.36 ms, the (3,2) passes 0.32, this 12-stage pass 0.34 -- every pass runs at the rate of its
+// products (2.3 G Fr products per batch at ~120 G/s), so a saved round trip through HBM saves nothing; the 5 + 5 split that makes
+// room for it replaces the cheap (2,2) passes (0.2 ms per stage: half of their twiddles are 1 and cost no product).
+// The prover only ever runs the PAIR inverse (DIF) + coset-forward (DIT) on a vector (to_coset).  The last six DIF stages (block
+// lengths 64 .. 2) and the first six DIT stages (half-distances 1 .. 32) both live inside blocks of 64 CONSECUTIVE positions, so one
+// tile visit does all twelve, with the scaling g^rev(i) / n between them: 5 HBM round trips per pair at N = 2^16 / 2^17
+// (DIF 5+5 | 6+6 fused | DIT 5+5; DIF 6+5 | fused | DIT 6+5) instead of 6 (6+6+4 twice).  Inside the tile: DIF distances 32,16,8 with
+// the thread holding e = q + 8m, LDS exchange, then DIF distances 4,2,1, the scaling and DIT distances 1,2,4 all on the SAME eight
+// elements e = 8q + m (no exchange between the two transforms), LDS exchange, DIT distances 8,16,32 on e = q + 8m.  Same butterflies,
+// same twiddle indices and the same weak-form arithmetic as the separate passes, hence bit-identical results (fr/fft difFFT /
+// ditFFT of gnark-crypto).  Software-pipelined like the passes above: the next tile's loads fly under the middle section.
+template <class P, int TPW>
+__global__ __launch_bounds__(ZK_NTT_TILE / 8) void k_ntt_mid_lds_pipe(Fr *__restrict__ data, size_t B, int logn, const Fr *__restrict__ tw_inv,
+                                                          const Fr *__restrict__ tw_fwd, const Fr *__restrict__ premul) {
+    using T = LdsTile<P, 3, 3>;
+    using El = typename P::E;
+    constexpr int E = T::E, TI = T::TI, NT = T::THREADS, R = 8;
+    static_assert(E == 64 && NT / TI == 8 && !P::F9, "tile shape of the fused middle pass");
+    extern __shared__ uint4 lds_raw[];
+    El *lds = (El *)lds_raw;                       // [E][TI]
+    const int tid = threadIdx.x;
+    const int bl = tid % TI, q = tid / TI;         // q in [0, 8)
+    const size_t b = (size_t)blockIdx.x * TI + bl;
+    const bool active = b < B;
+    const size_t g0 = (size_t)blockIdx.y * TPW;
+    Fr raw[R];
+#pragma unroll
+    for (int m = 0; m < R; m++) raw[m] = active ? data[((g0 << 6) + (size_t)(q + 8 * m)) * B + b] : Fr::zero();
+#pragma unroll 1
+    for (int it = 0; it < TPW; it++) {
+        const size_t base = (g0 + it) << 6;
+        El x[R];
+#pragma unroll
+        for (int m = 0; m < R; m++) x[m] = P::load(raw[m]);
+        // inverse transform, block lengths 64, 32, 16: element e = q + 8 m
+#pragma unroll
+        for (int st = 0; st < 3; st++) {
+            const int half = 4 >> st;
+            const int twshift = logn - (6 - st);
+#pragma unroll
+            for (int m = 0; m < R; m++) {
+                if ((m / half) & 1) continue;
+                const size_t j = (size_t)q + 8 * (size_t)(m % half);
+                P::dif(x[m], x[m + half], j == 0 ? nullptr : &tw_inv[j << twshift]);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < R; m++) lds[(q + 8 * m) * TI + bl] = x[m];
+        __syncthreads();
+        if (it + 1 < TPW) {
+            const size_t nbase = (g0 + it + 1) << 6;
+#pragma unroll
+            for (int m = 0; m < R; m++) raw[m] = active ? data[(nbase + (size_t)(q + 8 * m)) * B + b] : Fr::zero();
+        }
+        // element e = 8 q + m: inverse block lengths 8, 4, 2; scaling; forward half-distances 1, 2, 4
+        El y[R];
+#pragma unroll
+        for (int m = 0; m < R; m++) y[m] = lds[(q * 8 + m) * TI + bl];
+#pragma unroll
+        for (int st = 0; st < 3; st++) {
+            const int half = 4 >> st;
+            const int twshift = logn - (3 - st);
+#pragma unroll
+            for (int m = 0; m < R; m++) {
+                if ((m / half) & 1) continue;
+                const size_t j = (size_t)(m % half);
+                P::dif(y[m], y[m + half], j == 0 ? nullptr : &tw_inv[j << twshift]);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < R; m++) y[m] = P::mul(y[m], premul[base + (size_t)(q * 8 + m)]);
+#pragma unroll
+        for (int st = 0; st < 3; st++) {
+            const int h = 1 << st;
+            const int twshift = logn - (st + 1);
+#pragma unroll
+            for (int m = 0; m < R; m++) {
+                if ((m >> st) & 1) continue;
+                const size_t j = (size_t)(m & (h - 1));
+                P::dit(y[m], y[m + h], j == 0 ? nullptr : &tw_fwd[j << twshift]);
+            }
+        }
+        // (each thread writes back exactly the rows it read: no barrier in front of the stores)
+#pragma unroll
+        for (int m = 0; m < R; m++) lds[(q * 8 + m) * TI + bl] = y[m];
+        __syncthreads();
+        // forward half-distances 8, 16, 32: element e = q + 8 m
+        El z[R];
+#pragma unroll
+        for (int m = 0; m < R; m++) z[m] = lds[(q + 8 * m) * TI + bl];
+#pragma unroll
+        for (int st = 0; st < 3; st++) {
+            const int h = 1 << st;
+            const int twshift = logn - (3 + st + 1);
+#pragma unroll
+            for (int m = 0; m < R; m++) {
+                if ((m >> st) & 1) continue;
+                const size_t j = (size_t)q + 8 * (size_t)(m & (h - 1));
+                P::dit(z[m], z[m + h], j == 0 ? nullptr : &tw_fwd[j << twshift]);
+            }
+        }
+        if (active) {
+#pragma unroll
+            for (int m = 0; m < R; m++) data[(base + (size_t)(q + 8 * m)) * B + b] = P::store(z[m], false);
+        }
+        __syncthreads();                           // the tile buffer is rewritten by the next iteration
+    }
+}
+// pass sizes for `rem` butterfly stages: as few passes as 6 stages each allow, balanced (10 -> 5 + 5, 11 -> 6 + 5)
+static int balanced_passes(int rem, int (&sizes)[8]) {
+    if (rem <= 0) return 0;
+    const int k = (rem + 5) / 6;
+    for (int i = 0; i < k; i++) sizes[i] = rem / k + (i < rem % k ? 1 : 0);
+    return k;
+}
+template <class P>
+static void launch_dif_pass(int k, Fr *data, size_t B, int logn, int loglen, const Fr *tw, const Fr *pm, bool last, hipStream_t s) {
+    switch (k) {
+        case 6: launch_dif_lds<P, 3, 3>(data, B, logn, loglen, tw, pm, last, s); break;
+        case 5: launch_dif_lds<P, 3, 2>(data, B, logn, loglen, tw, pm, last, s); break;
+        case 4: launch_dif_lds<P, 2, 2>(data, B, logn, loglen, tw, pm, last, s); break;
+        case 3: launch_dif<P, 3>(data, B, logn, loglen, tw, pm, last, s); break;
+        case 2: launch_dif<P, 2>(data, B, logn, loglen, tw, pm, last, s); break;
+        default: launch_dif<P, 1>(data, B, logn, loglen, tw, pm, last, s); break;
+    }
+}
+template <class P>
+static void launch_dit_pass(int k, Fr *data, size_t B, int logn, int logS, const Fr *tw, const Fr *pm, bool last, hipStream_t s) {
+    switch (k) {
+        case 6: launch_dit_lds<P, 3, 3>(data, B, logn, logS, tw, pm, last, s); break;
+        case 5: launch_dit_lds<P, 3, 2>(data, B, logn, logS, tw, pm, last, s); break;
+        case 4: launch_dit_lds<P, 2, 2>(data, B, logn, logS, tw, pm, last, s); break;
+        case 3: launch_dit<P, 3>(data, B, logn, logS, tw, pm, last, s); break;
+        case 2: launch_dit<P, 2>(data, B, logn, logS, tw, pm, last, s); break;
+        default: launch_dit<P, 1>(data, B, logn, logS, tw, pm, last, s); break;
+    }
+}
+// inverse + coset-forward of one [n][B] vector with the fused middle pass; false: shape not covered (the caller runs the two transforms)
+static bool to_coset_fused(const NttDomain &dom, Fr *data, size_t B, hipStream_t s) {
+    using T = LdsTile<NttWords, 3, 3>;
+    constexpr int TPW = ZK_NTT_TPW;
+    const int logn = dom.logn;
+    const size_t tiles = dom.n >> 6;
+    if (logn < 12 || tiles % TPW != 0) return false;
+    int sizes[8];
+    const int np = balanced_passes(logn - 6, sizes);
+    int loglen = logn;
+    for (int i = 0; i < np; i++) { launch_dif_pass<NttWords>(sizes[i], data, B, logn, loglen, dom.tw_inv.p, nullptr, false, s); loglen -= sizes[i]; }
+    static PerDeviceOnce attr;
+    attr.run([] { ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_mid_lds_pipe<NttWords, TPW>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES)); });
+    hipLaunchKernelGGL((k_ntt_mid_lds_pipe<NttWords, TPW>), dim3(ceil_div(B, T::TI), (unsigned)(tiles / TPW)), dim3(T::THREADS), T::LDS_BYTES, s, data, B, logn, dom.tw_inv.p,
+                       dom.tw_fwd.p, dom.coset_pre.p);
+    int logS = 6;
+    for (int i = np - 1; i >= 0; i--) { launch_dit_pass<NttWords>(sizes[i], data, B, logn, logS, dom.tw_fwd.p, nullptr, logS + sizes[i] == logn, s); logS += sizes[i]; }
+    return true;
+}
+#endif  // ZK_EXPERIMENTS
+
 // ---------------------------------------------------------------------------------------------
 // Small batches (a single Prove() call: B = 1 .. 16).  The tiled kernels above put 32 INSTANCES on the lanes of a tile, so one proof
 // keeps 1 lane in 32 busy and the four transforms of a Prove() call cost 2.2 ms of pure launch latency.  Here the lanes are the
@@ -956,6 +1119,15 @@ void NttDomain::compute_h(Fr *a, Fr *b, Fr *c, size_t B, hipStream_t s) const {
 // The prover's quotient stage (see keyfold.hip): only a and b are transformed; the remaining linear maps of computeH
 // live in the folded bases.
 void NttDomain::to_coset(Fr *a, Fr *b, size_t B, hipStream_t s) const {
+#ifdef ZK_EXPERIMENTS
+    static const bool fuse = [] { const char *e = getenv("ZKPROVE_NTT_FUSE"); return e && e[0] == '1'; }();
+    static const int diag = [] { const char *e = getenv("ZKPROVE_NTT_DIAG"); return e ? atoi(e) : 0; }();
+    static const bool eight = [] { const char *e = getenv("ZKPROVE_NTT_EIGHT"); return e && e[0] == '1'; }();
+    if (fuse && B > NTT_SMALL_B && !f9 && diag == 0 && !eight && to_coset_fused(*this, a, B, s) && to_coset_fused(*this, b, B, s)) {
+        ZK_HIP(hipGetLastError());
+        return;
+    }
+#endif
     dif(a, B, true, nullptr, s);
     dif(b, B, true, nullptr, s);
     dit(a, B, false, coset_pre.p, s);

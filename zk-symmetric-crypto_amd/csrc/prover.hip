@@ -2,6 +2,7 @@
 #include "prover.h"
 #include "fixedbase.cuh"
 #include "xmd.cuh"
+#include "glv.cuh"
 #include <string.h>
 #include <algorithm>
 
@@ -333,15 +334,17 @@ __global__ __launch_bounds__(64) void k_finalize_stage2(const G1Affine *__restri
                                                         const U256 *__restrict__ s, G1XYZZ *__restrict__ u_out, G1XYZZ *__restrict__ v_out, size_t B) {
     const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
+    // through the curve's endomorphism (glv.cuh): one chain of 127 doublings instead of 254 -- these two multiplications are a
+    // dependent chain on one thread each, i.e. latency of every Prove() call whatever the batch size
     uint32_t k[8];
     if (blockIdx.y == 0) {
 #pragma unroll
         for (int i = 0; i < 8; i++) k[i] = s[b].l[i];
-        u_out[b] = scalar_mul(ar_aff[b], k);
+        u_out[b] = scalar_mul_glv(ar_aff[b], k);
     } else {
 #pragma unroll
         for (int i = 0; i < 8; i++) k[i] = r[b].l[i];
-        v_out[b] = scalar_mul(bs1_aff[b], k);
+        v_out[b] = scalar_mul_glv(bs1_aff[b], k);
     }
 }
 // Stage 3: Krs = K + Z + T + U + V ; canonical outputs

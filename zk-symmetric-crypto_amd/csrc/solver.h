@@ -28,6 +28,7 @@ struct SolverProgram {
     int log_domain = 0;
     std::vector<SolverLevel> levels;
     DevBuf<uint32_t> prog, instr_off, level_instr;
+    DevBuf<uint32_t> level_desc;                    // (first, count, wide) per level: what k_solve_persistent reads on the device
     DevBuf<Fr> coeffs, coeff_inv, lookup_tables, count_tables;   // lookup_tables: [table][256]
     DevBuf<uint32_t> div_list;                      // (constraint, loc, wire, coeff) x deferred divisions, grouped by level
     size_t n_count_rows = 0, n_count_slots = 0;     // countHint scratch sizing: [slot][row][B]

@@ -14,6 +14,7 @@
 // Data layout: wires[w * B + b], a/b/c[constraint * B + b]  (Fr, Montgomery).
 #include "solver.h"
 #include <string.h>
+#include <algorithm>
 #include <string>
 
 namespace zk {
@@ -237,6 +238,40 @@ void SolverProgram::build(const R1cs &cs, hipStream_t s) {
         for (int pass = 0; pass < 2; pass++)
             for (uint32_t i : l)
                 if ((int)is_wide_instr[i] == 1 - pass) ordered.push_back(i);
+        // ... and, within the two parts, by SHAPE (opcode, term counts, coefficient ids -- everything but the wire / constraint
+        // numbers): the circuits repeat a few gadgets thousands of times, so instructions of one shape end up side by side.  The level
+        // kernels do not care (one instruction per workgroup row); the persistent kernel, whose LANES are instructions, then runs
+        // wavefronts of same-shaped instructions and its branches on the program words stay (nearly) uniform.
+        {
+            auto shape = [&](uint32_t i) {
+                const uint32_t *rec = prg.data() + off[i];
+                const size_t end = i + 1 < ni ? off[i + 1] : prg.size();
+                uint64_t h = 1469598103934665603ull;
+                auto mix = [&](uint32_t v) { h = (h ^ v) * 1099511628211ull; };
+                const size_t n = end - off[i];
+                mix(rec[0]);
+                if (rec[0] == OP_R1C) {
+                    mix(rec[2]); mix(rec[3]); mix(rec[4]); mix(rec[5]); mix(rec[7]);
+                    for (size_t k = 8; k < n; k += 2) mix(rec[k]);                           // coefficient ids of the terms
+                } else if (rec[0] == OP_NBITS) {
+                    mix(rec[1]); mix(rec[3]);
+                    for (size_t k = 4; k < n; k += 2) mix(rec[k]);
+                } else if (rec[0] == OP_LOOKUP) {
+                    mix(rec[1]); mix(rec[2]);
+                } else mix((uint32_t)n);
+                return h;
+            };
+            std::vector<std::pair<uint64_t, uint32_t>> keyed;
+            size_t nwide_l = 0;
+            for (uint32_t i : l) nwide_l += is_wide_instr[i];
+            for (int part = 0; part < 2; part++) {
+                const size_t lo = part == 0 ? 0 : nwide_l, hi = part == 0 ? nwide_l : ordered.size();
+                keyed.clear();
+                for (size_t q = lo; q < hi; q++) keyed.push_back({shape(ordered[q]), ordered[q]});
+                std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<uint64_t, uint32_t> &x, const std::pair<uint64_t, uint32_t> &y) { return x.first < y.first; });
+                for (size_t q = lo; q < hi; q++) ordered[q] = keyed[q - lo].second;
+            }
+        }
         lv.wide = 0;
         for (uint32_t i : l) lv.wide += is_wide_instr[i];
         for (uint32_t i : ordered) {
@@ -253,6 +288,13 @@ void SolverProgram::build(const R1cs &cs, hipStream_t s) {
     prog.upload(prg.data(), prg.size(), s);
     instr_off.upload(off.data(), off.size(), s);
     level_instr.upload(li.data(), li.size(), s);
+    {
+        std::vector<uint32_t> desc;
+        size_t max_counts = 0;
+        for (auto &lv : levels) desc.insert(desc.end(), {lv.first, lv.count, lv.wide});
+        (void)max_counts;
+        level_desc.upload(desc.data(), desc.size(), s);
+    }
     coeffs.alloc(cs.coeffs.size());
     ZK_HIP(hipMemcpyAsync(coeffs.p, cs.coeffs.data(), cs.coeffs.size() * 32, hipMemcpyHostToDevice, s));
     coeff_inv.alloc(cs.coeffs.size());
@@ -400,7 +442,56 @@ __device__ __forceinline__ bool small_index(const Fr &v_mont, uint32_t bound, ui
 
 // One instruction.  COOP: the SL slices of the workgroup work on it together (long linear expressions, countHint queries; slice 0
 // finishes it); !COOP: the calling wave owns it (no barriers, no LDS) -- lead = live.
-template <int LX, int SL, bool COOP>
+// The tail of an R1C instruction once its three linear expressions are known: check (loc 0) or solve for the one unknown wire and
+// write the constraint's a / b / c values.  INLINE_DIV: an unknown in L or R is divided out here (one inversion per instruction:
+// the persistent small-batch kernel); otherwise that case is left to k_solve_divisions, which shares one inversion between 16.
+template <bool INLINE_DIV>
+__device__ __forceinline__ void finish_r1c(const SolveCtx &cx, size_t b, uint32_t cons, uint32_t loc, uint32_t sw, uint32_t sc, Fr vL, Fr vR, Fr vO) {
+    const size_t B = cx.B;
+    if (loc == 0) {
+        if (mul_fast(vL, vR) != vO) report(cx, b, SERR_UNSATISFIED, cons);
+    } else {
+        Fr x = Fr::zero();
+        if (loc == 3) {
+            x = mul_fast(vL, vR) - vO;
+            vO = vO + x;
+        } else if constexpr (INLINE_DIV) {
+            // x = O / R - L (loc 1) or O / L - R (loc 2); same case analysis as k_solve_divisions
+            const Fr den = loc == 1 ? vR : vL;
+            if (!den.is_zero()) {
+                const Fr di = den.inv();
+                if (loc == 1) { x = vO * di - vL; vL = vL + x; }
+                else { x = vO * di - vR; vR = vR + x; }
+            } else if (!vO.is_zero()) {
+                report(cx, b, SERR_UNSATISFIED, cons);
+            }
+        } else {
+            // unknown wire sits in L or R: x = O / R - L needs a field inversion.  Deferred to k_solve_divisions,
+            // which shares ONE inversion between up to 16 such constraints of this level (Montgomery's trick);
+            // a/b/c written below carry the partial sums it needs.
+            cx.a[(size_t)cons * B + b] = vL;
+            cx.b[(size_t)cons * B + b] = vR;
+            cx.c[(size_t)cons * B + b] = vO;
+            return;
+        }
+        if (sc == 3) x = x.neg();
+        else if (sc != 1) x = x * cx.coeff_inv[sc];
+        cx.wires[(size_t)sw * B + b] = x;
+    }
+    cx.a[(size_t)cons * B + b] = vL;
+    cx.b[(size_t)cons * B + b] = vR;
+    cx.c[(size_t)cons * B + b] = vO;
+}
+__device__ __forceinline__ void finish_nbits(const SolveCtx &cx, size_t b, uint32_t nout, uint32_t out0, Fr v) {
+    v = v.from_mont();
+    const Fr one = Fr::one(), zero = Fr::zero();
+    for (uint32_t k = 0; k < nout; k++) {
+        const bool bit = k < 256 && ((v.l[k >> 5] >> (k & 31)) & 1);
+        cx.wires[(size_t)(out0 + k) * cx.B + b] = bit ? one : zero;
+    }
+}
+
+template <int LX, int SL, bool COOP, bool INLINE_DIV = false>
 __device__ __forceinline__ void solve_instruction(const SolveCtx &cx, const uint32_t *__restrict__ instr_off, uint32_t instr, size_t b, bool live, bool lead, Fr *red) {
     const size_t B = cx.B;
     const uint32_t *p = cx.prog + instr_off[instr];
@@ -419,29 +510,8 @@ __device__ __forceinline__ void solve_instruction(const SolveCtx &cx, const uint
             vO = eval_terms(cx, p, nO, b);
         }
         if (!lead) return;
-        if (loc == 0) {
-            if (mul_fast(vL, vR) != vO) report(cx, b, SERR_UNSATISFIED, cons);
-        } else {
-            Fr x = Fr::zero();
-            if (loc == 3) {
-                x = mul_fast(vL, vR) - vO;
-                vO = vO + x;
-            } else {
-                // unknown wire sits in L or R: x = O / R - L needs a field inversion.  Deferred to k_solve_divisions,
-                // which shares ONE inversion between up to 16 such constraints of this level (Montgomery's trick);
-                // a/b/c written below carry the partial sums it needs.
-                cx.a[(size_t)cons * B + b] = vL;
-                cx.b[(size_t)cons * B + b] = vR;
-                cx.c[(size_t)cons * B + b] = vO;
-                return;
-            }
-            if (sc == 3) x = x.neg();
-            else if (sc != 1) x = x * cx.coeff_inv[sc];
-            cx.wires[(size_t)sw * B + b] = x;
-        }
-        cx.a[(size_t)cons * B + b] = vL;
-        cx.b[(size_t)cons * B + b] = vR;
-        cx.c[(size_t)cons * B + b] = vO;
+        finish_r1c<INLINE_DIV>(cx, b, cons, loc, sw, sc, vL, vR, vO);
+        return;
     } else if (op == OP_NBITS) {
         const uint32_t nout = p[1], out0 = p[2];
         p += 3;
@@ -449,12 +519,7 @@ __device__ __forceinline__ void solve_instruction(const SolveCtx &cx, const uint
         if constexpr (COOP) v = eval_linexp_coop<LX, SL>(cx, p, b, red);
         else v = eval_linexp(cx, p, b);
         if (!lead) return;
-        v = v.from_mont();
-        const Fr one = Fr::one(), zero = Fr::zero();
-        for (uint32_t k = 0; k < nout; k++) {
-            const bool bit = k < 256 && ((v.l[k >> 5] >> (k & 31)) & 1);
-            cx.wires[(size_t)(out0 + k) * B + b] = bit ? one : zero;
-        }
+        finish_nbits(cx, b, nout, out0, v);
     } else if (COOP && op == OP_COUNT) {
         // countHint of a log-derivative lookup: multiplicity of every table row among nq (~3 600 for the AES S-box) queries.
         // The slices take every SL-th query (one lane used to walk all of them: the three longest levels of the AES circuits,
@@ -535,6 +600,125 @@ __global__ __launch_bounds__(256, MINB) void k_solve_level(SolveCtx cx, const ui
     }
 }
 
+#ifdef ZK_EXPERIMENTS
+// ---------------------------------------------------------------------------------------- persistent small-batch solver (EXPERIMENT: lost)
+// A single Prove() call (what the reference's own harness and the unchanged JS operator issue, gnark/libraries/core_test.go:121-150) is
+// latency: the level-per-launch kernels above cost 163 / 457 dependent launches at ~15 us each for ONE proof (2.9 / 6.8 ms).  Proofs
+// are independent, so no device-wide barrier is needed to keep a whole solve inside one kernel (VERDICT r3 task 3): a workgroup owns
+// ONE instance and walks ALL levels of [l0, l1) with __syncthreads() between them.  Measured (scripts/latency_probe.py, one box,
+// profiles/r04c_lat_*.txt): SLOWER -- ChaCha20 solve stage 3.6 ms (512 threads) / 4.3 (1 024) against 2.9 ms for the 163 launches,
+// AES-256 16.9 / 19.2 against 6.8 -- although every level's instructions are sorted by shape: with the INSTRUCTIONS on the lanes
+// every program word is a vector load, every branch of the term loop (coefficient 0 / 1 / 2 / -1 / general, operand 0 / +-1) is
+// taken by some lane of the wavefront, and a lane that needs the 254-bit product makes all 64 pay for it; the level kernels keep the
+// instruction uniform per workgroup (scalar loads, uniform branches) and put the INSTANCES (or, for B <= 8, the terms) on the lanes.
+// Kept in the experiments build (ZKPROVE_SOLVER_PERSIST=n: batches up to n), parity-tested there.
+// Within a level the lanes are the INSTRUCTIONS (they are independent by construction of the levels):
+//   phase A  wide instructions -- a linear expression of >= COOP_MIN_TERMS terms: the ~100-term add32 / FromBinary rows that used to
+//            set every level's latency -- are shared by 16 lanes each (partial sums through LDS, the group's first lane finishes);
+//   counts   a countHint (AES: 3 600 S-box queries) is worked on by the whole workgroup, counters in global memory as above;
+//   phase B  every other instruction by one lane; an unknown in L or R is divided out in place (one binary-GCD inversion per
+//            instruction -- there is nobody to share it with).
+// Same arithmetic, same case analysis, hence the same wires and a / b / c rows as k_solve_level + k_solve_divisions (parity tests:
+// batches of 1, 7, 12 against the oracle's wire vectors).  grid = B workgroups; used up to PERSIST_MAX_B instances.
+template <int G>
+__device__ __forceinline__ Fr eval_terms_slice(const SolveCtx &cx, const uint32_t *p, uint32_t n, size_t b, int gl) {
+    if (n < (uint32_t)COOP_MIN_TERMS) {
+        if (gl != 0) return Fr::zero();
+        return eval_terms(cx, p, n, b);
+    }
+    const uint32_t chunk = (n + G - 1) / G;
+    const uint32_t lo = gl * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    if (lo >= hi) return Fr::zero();
+    const uint32_t *q = p + 2 * lo;
+    return eval_terms(cx, q, hi - lo, b);
+}
+template <int NT>
+__global__ __launch_bounds__(NT) void k_solve_persistent(SolveCtx cx, const uint32_t *__restrict__ instr_off, const uint32_t *__restrict__ level_instr,
+                                                        const uint32_t *__restrict__ level_desc, uint32_t l0, uint32_t l1) {
+    constexpr int G = 16, NG = NT / G;
+    extern __shared__ uint4 lds_raw[];
+    Fr *red = (Fr *)lds_raw;                          // [3][NT] partial sums of L, R, O
+    __shared__ uint32_t n_counts, count_idx[16];
+    const int tid = threadIdx.x, grp = tid / G, gl = tid % G;
+    const size_t b = blockIdx.x, B = cx.B;
+    for (uint32_t l = l0; l < l1; l++) {
+        const uint32_t first = level_desc[3 * l], count = level_desc[3 * l + 1], wide = level_desc[3 * l + 2];
+        const uint32_t *li = level_instr + first;
+        if (tid == 0) n_counts = 0;
+        if (wide) __syncthreads();
+        // ---- phase A
+        for (uint32_t base = 0; base < wide; base += NG) {
+            const uint32_t idx = base + grp;
+            const bool mine = idx < wide;
+            Fr pL = Fr::zero(), pR = Fr::zero(), pO = Fr::zero();
+            uint32_t op = 0, h1 = 0, h2 = 0, h5 = 0, h6 = 0, h7 = 0;
+            if (mine) {
+                const uint32_t *p = cx.prog + instr_off[li[idx]];
+                op = p[0];
+                if (op == OP_R1C) {
+                    const uint32_t nL = p[2], nR = p[3], nO = p[4];
+                    h1 = p[1]; h5 = p[5]; h6 = p[6]; h7 = p[7];
+                    p += 8;
+                    pL = eval_terms_slice<G>(cx, p, nL, b, gl); p += 2 * nL;
+                    pR = eval_terms_slice<G>(cx, p, nR, b, gl); p += 2 * nR;
+                    pO = eval_terms_slice<G>(cx, p, nO, b, gl);
+                } else if (op == OP_NBITS) {
+                    h1 = p[1]; h2 = p[2];
+                    pL = eval_terms_slice<G>(cx, p + 4, p[3], b, gl);
+                } else if (op == OP_COUNT && gl == 0) {
+                    const uint32_t k = atomicAdd(&n_counts, 1u);
+                    if (k < 16) count_idx[k] = idx;
+                }
+            }
+            red[tid] = pL; red[NT + tid] = pR; red[2 * NT + tid] = pO;
+            __syncthreads();
+            if (mine && gl == 0 && (op == OP_R1C || op == OP_NBITS)) {
+                Fr vL = Fr::zero(), vR = Fr::zero(), vO = Fr::zero();
+#pragma unroll 4
+                for (int k = 0; k < G; k++) vL = vL + red[tid + k];
+                if (op == OP_R1C) {
+#pragma unroll 4
+                    for (int k = 0; k < G; k++) { vR = vR + red[NT + tid + k]; vO = vO + red[2 * NT + tid + k]; }
+                    finish_r1c<true>(cx, b, h1, h5, h6, h7, vL, vR, vO);
+                } else finish_nbits(cx, b, h1, h2, vL);
+            }
+            __syncthreads();
+        }
+        // ---- countHints of this level (collected above), the whole workgroup on each
+        const uint32_t nc = wide ? (n_counts < 16u ? n_counts : 16u) : 0u;
+        for (uint32_t c = 0; c < nc; c++) {
+            const uint32_t instr = li[count_idx[c]];
+            const uint32_t *p = cx.prog + instr_off[instr];
+            const uint32_t ntab = p[1], ncol = p[2], nq = p[3], out0 = p[4], slot = p[5], toff = p[6];
+            const uint32_t *row_start = p + 8 + p[7];
+            p += 8;
+            uint32_t *cnt = cx.count_scratch + (size_t)slot * cx.count_rows * B;
+            for (uint32_t r = tid; r < ntab; r += NT) cnt[(size_t)r * B + b] = 0;
+            __syncthreads();
+            const Fr *tab = cx.count_tables + toff;
+            for (uint32_t j = tid; j < nq; j += NT) {
+                const uint32_t *pq = p + row_start[j];
+                uint32_t row = 0;
+                bool ok = true;
+                for (uint32_t col = 0; col < ncol; col++) {
+                    const Fr qv = eval_linexp(cx, pq, b);
+                    if (col == 0) ok = small_index(qv, ntab, row);
+                    if (ok && tab[(size_t)row * ncol + col] != qv) ok = false;
+                }
+                if (ok) atomicAdd(&cnt[(size_t)row * B + b], 1u);
+                else report(cx, b, SERR_COUNT_QUERY, instr);
+            }
+            __syncthreads();
+            for (uint32_t r = tid; r < ntab; r += NT) cx.wires[(size_t)(out0 + r) * B + b] = Fr::from_u32(cnt[(size_t)r * B + b]);
+        }
+        // ---- phase B
+        for (uint32_t i = wide + tid; i < count; i += NT) solve_instruction<1, 1, false, true>(cx, instr_off, li[i], b, true, true, nullptr);
+        __syncthreads();                                   // the level's wires are written: the next level may read them
+    }
+}
+
+#endif  // ZK_EXPERIMENTS
+
 // Deferred divisions of one level: thread = (instance, group of up to DIV_GROUP constraints).
 // rec = (constraint, loc, wire, coeff id).  loc 1: x = c/b - a ; loc 2: x = c/a - b.
 static constexpr int DIV_GROUP = 16;
@@ -604,9 +788,39 @@ void solver_begin(const SolverProgram &p, SolverBuffers &buf, hipStream_t s) {
     ZK_HIP(hipGetLastError());
 }
 
+#ifdef ZK_EXPERIMENTS
+// batches up to this size take the persistent kernel (one workgroup per instance): ZKPROVE_SOLVER_PERSIST=n, default never
+static size_t persist_max_b() {
+    static const size_t v = [] { const char *e = getenv("ZKPROVE_SOLVER_PERSIST"); return e ? (size_t)atol(e) : (size_t)0; }();
+    return v;
+}
+#endif
 void solver_run_levels(const SolverProgram &p, SolverBuffers &buf, size_t first_level, size_t last_level, hipStream_t s) {
     SolveCtx cx{p.prog.p, p.coeffs.p, p.coeff_inv.p, p.lookup_tables.p, p.count_tables.p, buf.wires.p, buf.a.p, buf.b.p, buf.c.p,
                 buf.randomize.p, buf.challenge.p, buf.err.p, buf.count_scratch.p, buf.B, p.n_count_rows};
+    if (last_level > p.levels.size()) last_level = p.levels.size();
+#ifdef ZK_EXPERIMENTS
+    if (buf.B <= persist_max_b() && first_level < last_level) {
+        static const int nt_env = [] { const char *e = getenv("ZKPROVE_SOLVER_PERSIST_NT"); return e ? atoi(e) : 1024; }();
+        static PerDeviceOnce attr;
+        attr.run([] {
+            ZK_HIP(hipFuncSetAttribute((const void *)k_solve_persistent<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 1024 * (int)sizeof(Fr)));
+            ZK_HIP(hipFuncSetAttribute((const void *)k_solve_persistent<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 512 * (int)sizeof(Fr)));
+            ZK_HIP(hipFuncSetAttribute((const void *)k_solve_persistent<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 256 * (int)sizeof(Fr)));
+        });
+        if (nt_env == 256)
+            hipLaunchKernelGGL(k_solve_persistent<256>, dim3((unsigned)buf.B), dim3(256), 3 * 256 * sizeof(Fr), s, cx, p.instr_off.p, p.level_instr.p, p.level_desc.p,
+                               (uint32_t)first_level, (uint32_t)last_level);
+        else if (nt_env == 512)
+            hipLaunchKernelGGL(k_solve_persistent<512>, dim3((unsigned)buf.B), dim3(512), 3 * 512 * sizeof(Fr), s, cx, p.instr_off.p, p.level_instr.p, p.level_desc.p,
+                               (uint32_t)first_level, (uint32_t)last_level);
+        else
+            hipLaunchKernelGGL(k_solve_persistent<1024>, dim3((unsigned)buf.B), dim3(1024), 3 * 1024 * sizeof(Fr), s, cx, p.instr_off.p, p.level_instr.p, p.level_desc.p,
+                               (uint32_t)first_level, (uint32_t)last_level);
+        ZK_HIP(hipGetLastError());
+        return;
+    }
+#endif
     for (size_t l = first_level; l < last_level && l < p.levels.size(); l++) {
         const SolverLevel &lv = p.levels[l];
         if (!lv.count) continue;
