@@ -65,6 +65,13 @@ int zkp_expand_message_xmd(const uint8_t *msg, long mlen, const uint8_t *dst, lo
 int zkp_bsb22_challenge(const uint8_t *com, long n, uint8_t *out);
 /* the verifier's host path for the same: commitments as X | Y 32-byte big-endian (G1Affine.Marshal) */
 int zkp_bsb22_challenge_host(const uint8_t *com_be64, long n, uint8_t *out);
+/* ---- request layer */
+/* the two request decoders (single-pass scanner for the canonical shape, DOM reader with Go's encoding/json semantics) on one input:
+ * 1 = the scanner took it and agrees with the DOM reader field by field, 0 = the scanner declined, -1 = they disagree */
+int zkp_request_decode_both(const uint8_t *json, long len);
+/* host stages of a streamed ProveBatch without a device (decode + cipher + pack per 1 024-chunk; response serialisation):
+ * out4 = {decode stage requests/s, serialise stage requests/s, requests the scanner took, requests that produced a record} */
+int zkp_host_stage_bench(const uint8_t *json_array, long len, int iters, double *out4);
 #ifdef ZK_EXPERIMENTS
 int zkp_debug_tree(int n, int c, int piece, int dbg);
 #endif

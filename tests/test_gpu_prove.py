@@ -443,3 +443,30 @@ def test_init_rejects_invalid_key_points(zk, oracle):
     assert refused(bad)
     assert zk.init_algorithm(0, bytes(pk), r1cs)                                     # untouched key loads
     zk.lib.ZkpReset()
+
+
+def test_init_answers_truncated_and_length_inflated_keys(zk, oracle):
+    """the proving-key reader against structural damage (the reader of untrusted-size fields; ProvingKey.ReadFrom errors ->
+    InitAlgorithm false, impl/library.go:104-108): every truncation, and section counts that promise more points than the file holds,
+    fewer, none, or 2^32 - 1, are refused with a message -- no crash, no allocation by the inflated count -- and the library is usable
+    afterwards"""
+    import struct
+    zk.lib.ZkpAllowUnpinnedKeys(1)
+    zk.lib.ZkpReset()
+    r1cs = rf.load_r1cs_bytes("chacha20")
+    for raw in (True, False):
+        pk = H.pk_file_bytes(0, raw=raw)
+        off = 8 + 5 * 32 + 1 + 3 * (64 if raw else 32)                            # the u32 count of G1.A
+        n_a = int.from_bytes(pk[off:off + 4], "big")
+        cuts = list(range(0, 24)) + [off - 1, off, off + 3, off + 4, off + 5, len(pk) // 3, len(pk) // 2, len(pk) - 200, len(pk) - 9, len(pk) - 1]
+        cases = [pk[:c] for c in cuts] + [pk + b"\x00", pk + pk[:64]]
+        for v in (0, 1, n_a - 1, n_a + 1, 0x7FFFFFFF, 0xFFFFFFFF):
+            cases.append(pk[:off] + struct.pack(">I", v) + pk[off + 4:])
+        cases.append(struct.pack(">Q", 1 << 40) + pk[8:])                          # domain cardinality
+        cases.append(pk[:-4] + b"\xff\xff\xff\xff")
+        for bad in cases:
+            assert not zk.init_algorithm(0, bad, r1cs)
+            assert zk.lib.ZkpDeviceReplicas(0) == 0
+    assert not zk.init_algorithm(0, H.pk_file_bytes(0), r1cs[:-1])                  # the R1CS pin always holds
+    assert zk.init_algorithm(0, H.pk_file_bytes(0), r1cs)
+    zk.lib.ZkpReset()

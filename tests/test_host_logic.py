@@ -176,3 +176,63 @@ def test_prove_batch_array_structure_and_per_element_answers(zk):
     assert got[3] == {"Offset": 70} and got[4] == {}          # the quote of "x" (index 69), counted in the whole call's bytes
     # the decodable request names the algorithm: not initialised -> the reference's message, per element
     assert pb(b"[" + _req() + b"," + _req() + b"]") == ["proving params are not initialized for cipher: chacha20"] * 2
+
+
+def _both(zk, body: bytes) -> int:
+    b = np.frombuffer(body, np.uint8).copy() if body else np.zeros(1, np.uint8)
+    return zk.testlib.zkp_request_decode_both(b.ctypes.data, len(body))
+
+
+def test_request_scanner_takes_the_canonical_shape_and_declines_everything_else(zk):
+    """csrc/request.cpp: the single-pass scanner (streamed ProveBatch's decode stage) reads exactly the shape the JS client sends and
+    agrees with the DOM reader field by field (1); whatever needs Go's encoding/json semantics -- differently-cased or repeated keys,
+    escapes, nulls, arrays of numbers, nested unknown members, out-of-range counters, syntax errors -- it DECLINES (0) and the DOM
+    reader decides alone, as before.  Never -1 (disagreement)."""
+    for alg in (0, 1, 2):
+        inst = H.make_instance(alg, H.SplitMix64(11 + alg))
+        req = json.loads(H.request_json(alg, inst))
+        canon = json.dumps(req, separators=(",", ":")).encode()
+        assert _both(zk, canon) == 1
+        assert _both(zk, json.dumps(req).encode()) == 1                                   # Python's spacing
+        assert _both(zk, json.dumps(req, indent=2).encode()) == 1
+        assert _both(zk, b" \n" + canon + b"\t ") == 1
+        extra = dict(req, ciphertext="AAAA", id=7, tag=None)                              # aux_test.go:150-185 carries an ignored "ciphertext"
+        assert _both(zk, json.dumps(extra).encode()) == 1
+        for blk in req["blocks"]:
+            blk["boundary"] = None
+        assert _both(zk, json.dumps(req).encode()) == 1
+        req["blocks"][0]["boundary"] = 5
+        req["blocks"][0]["counter"] = 4294967295
+        assert _both(zk, json.dumps(req).encode()) == 1
+        declined = [
+            canon.replace(b'"cipher"', b'"Cipher"'), canon.replace(b'"key"', b'"KEY"'), canon[:-1] + b',"key":"AAAA"}', canon.replace(b'"nonce"', b'"Nonce"', 1),
+            canon.replace(b'"cipher":"', b'"cipher":"\\u0063', 1), canon[:-1] + b',"x":{"a":1}}', canon[:-1] + b',"x":[1]}', canon[:-1] + b',"x":1.5}', canon[:-1] + b',"x":true}',
+            canon.replace(b'"counter":', b'"counter":0', 1), canon.replace(b'"counter":', b'"counter":-', 1), canon.replace(b'"toprf":{}', b'"toprf":{"a":1}'),
+            canon[:-1], canon + b"x", canon.replace(b'"blocks":[{', b'"blocks":[null,{', 1), canon.replace(b'"key":"', b'"key":"\\n', 1), b"{}", b"[]", b"null", b"",
+            json.dumps(dict(req, cipher="chacha20-toprf")).encode(), json.dumps(dict(req, cipher="rot13")).encode(), json.dumps(dict(req, key=[1, 2, 3])).encode(),
+            json.dumps(dict(req, key=None)).encode(), json.dumps(dict(req, key="A" + req["key"][1:-1])).encode(),
+        ]
+        req["blocks"][0]["counter"] = 4294967296
+        declined.append(json.dumps(req).encode())
+        for d in declined:
+            assert _both(zk, d) == 0, d[:120]
+
+
+def test_request_decoders_never_disagree_hypothesis(zk):
+    from hypothesis import given, settings, strategies as st
+    b64 = st.binary(max_size=40).map(lambda b: base64.b64encode(b).decode())
+    block = st.fixed_dictionaries({"nonce": b64, "counter": st.integers(min_value=0, max_value=2**33)}, optional={"boundary": st.one_of(st.none(), st.integers(0, 2**32 - 1))})
+    req = st.fixed_dictionaries({"cipher": st.sampled_from(["chacha20", "aes-128-ctr", "aes-256-ctr", "x"]), "key": b64, "blocks": st.lists(block, max_size=7), "input": b64},
+                                optional={"toprf": st.just({}), "ciphertext": b64, "n": st.integers(0, 10)})
+    seen = {0: 0, 1: 0}
+
+    @settings(max_examples=400, deadline=None)
+    @given(r=req, compact=st.booleans(), cut=st.integers(0, 600))
+    def run(r, compact, cut):
+        body = json.dumps(r, separators=(",", ":") if compact else None).encode()
+        for b in (body, body[:cut]):
+            v = _both(zk, b)
+            assert v in (0, 1), b
+            seen[v] += 1
+    run()
+    assert seen[1] > 50 and seen[0] > 50

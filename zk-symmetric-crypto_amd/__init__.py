@@ -76,7 +76,9 @@ def _load_testlib():
                 ("zkp_vk_pairing_identities", _i32, [_vp, _i64, _i32]),
                 ("zkp_expand_message_xmd", _i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i32]),
                 ("zkp_bsb22_challenge", _i32, [_vp, _i64, _vp]),
-                ("zkp_bsb22_challenge_host", _i32, [_vp, _i64, _vp])):
+                ("zkp_bsb22_challenge_host", _i32, [_vp, _i64, _vp]),
+                ("zkp_request_decode_both", _i32, [_vp, _i64]),
+                ("zkp_host_stage_bench", _i32, [_vp, _i64, _i32, _vp])):
             _sig(name, res, args, of=t)
         _testlib = t
     return _testlib

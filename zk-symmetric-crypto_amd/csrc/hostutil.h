@@ -6,6 +6,7 @@
 #include <mutex>
 #include <thread>
 #include <atomic>
+#include <condition_variable>
 #include <stdint.h>
 #include <map>
 #include <memory>
@@ -41,34 +42,15 @@ std::string json_quote(const std::string &s);   // Go json.Marshal string escapi
 // value is something else
 bool json_split_array(const char *p, size_t n, std::vector<std::pair<size_t, size_t>> &el, size_t &err_off, bool &not_array);
 
-// host-side parallel loop (request decoding, witness packing, proof serialisation are independent per request)
+// host-side parallel loop (request decoding, witness packing, proof serialisation are independent per request).  The loops run on a
+// small persistent pool (at most 15 workers + the caller, started on first use): creating 15 threads per call cost ~0.5 ms, half of
+// what a 1 024-request chunk needs in all.  Several callers may loop at the same time (the decode stage and the serialise stage of a
+// streamed ProveBatch do); an exception thrown by fn reaches the caller.
+void parallel_for_impl(size_t n, void (*call)(void *ctx, size_t i), void *ctx);
 template <class Fn>
 inline void parallel_for(size_t n, Fn fn) {
-    unsigned nt = std::thread::hardware_concurrency();
-    if (nt > 16) nt = 16;
-    if (n < 64 || nt <= 1) { for (size_t i = 0; i < n; i++) fn(i); return; }
-    std::atomic<size_t> next{0};
-    std::exception_ptr first_error;
-    std::mutex err_lock;
-    auto worker = [&] {
-        try {
-            for (;;) {
-                const size_t i0 = next.fetch_add(32);
-                if (i0 >= n) return;
-                const size_t i1 = i0 + 32 < n ? i0 + 32 : n;
-                for (size_t i = i0; i < i1; i++) fn(i);
-            }
-        } catch (...) {          // an exception must not leave a std::thread: keep the first one for the caller
-            std::lock_guard<std::mutex> lk(err_lock);
-            if (!first_error) first_error = std::current_exception();
-            next.store(n);
-        }
-    };
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < nt; t++) th.emplace_back(worker);
-    worker();
-    for (auto &t : th) t.join();
-    if (first_error) std::rethrow_exception(first_error);
+    if (n < 64) { for (size_t i = 0; i < n; i++) fn(i); return; }
+    parallel_for_impl(n, [](void *ctx, size_t i) { (*static_cast<Fn *>(ctx))(i); }, &fn);
 }
 
 

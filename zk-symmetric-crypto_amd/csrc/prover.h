@@ -49,7 +49,9 @@ struct PhaseTimes {   // milliseconds, device time measured with HIP events on t
 struct ChunkFeed {
     struct Chunk {
         size_t id = 0, count = 0;                 // count <= Algorithm::max_chunk
-        const uint32_t *inputs = nullptr;         // [count][n_inputs]
+        const uint32_t *inputs = nullptr;         // [count][n_inputs]  -- or, the request path's compact form:
+        const uint8_t *raw = nullptr;             // [count][SOLVER_RAW_STRIDE] records (request.h RawWitness), expanded on the device
+        int raw_alg = -1;                         // algorithm id the records are laid out for (raw != nullptr)
         const U256 *r = nullptr, *s = nullptr, *rnd = nullptr;
         ProofPoints *out = nullptr;               // [count], written before done()
         uint32_t *errs = nullptr;
@@ -88,13 +90,18 @@ class Algorithm {
     // wide (optional, single-chunk batches only): elements of the assignment that are wider than 32 bits
     void prove_batch(size_t batch, const uint32_t *inputs, const U256 *r, const U256 *s, const U256 *randomize, ProofPoints *out,
                      uint32_t *errs, PhaseTimes *times = nullptr, const WideInput *wide = nullptr, size_t n_wide = 0);
+    // the same from the request path's records: raw = [batch][SOLVER_RAW_STRIDE] bytes laid out for algorithm raw_alg
+    void prove_batch_raw(size_t batch, const uint8_t *raw, int raw_alg, const U256 *r, const U256 *s, const U256 *randomize, ProofPoints *out, uint32_t *errs);
+    void prove_batch_impl(size_t batch, const uint32_t *inputs, const uint8_t *raw, int raw_alg, const U256 *r, const U256 *s, const U256 *randomize, ProofPoints *out,
+                          uint32_t *errs, PhaseTimes *times, const WideInput *wide, size_t n_wide);
 
     // the same over chunks pulled from a feed (several replicas may pull from one feed: dynamic sharing of a batch between devices)
     void prove_stream(ChunkFeed &feed, PhaseTimes *times = nullptr);
 
     // device-resident variant for the benchmark: inputs already in HBM as [n_inputs][B] (see bench.py)
     struct Resident;
-    void upload_set(struct SolveSet &S, size_t B, const uint32_t *inputs, const U256 *r, const U256 *s, const U256 *randomize, hipStream_t st);
+    void upload_set(struct SolveSet &S, size_t B, const uint32_t *inputs, const U256 *r, const U256 *s, const U256 *randomize, hipStream_t st,
+                    const uint8_t *raw = nullptr, int raw_alg = -1);
     void ensure_second_set(int nsets = 2);
     void ensure_second_set_once(int nsets);
     void enqueue_solve(struct SolveSet &S, MsmScratch &commit_scratch, hipStream_t st);
@@ -132,7 +139,8 @@ class Algorithm {
     void collect_times(struct SolveSet &S, PhaseTimes *times);
     std::unique_ptr<Resident> res;
     void resident_reserve(size_t B);
-    void resident_upload(size_t B, const uint32_t *inputs_rowmajor_instance, const U256 *r, const U256 *s, const U256 *randomize, const WideInput *wide = nullptr, size_t n_wide = 0);
+    void resident_upload(size_t B, const uint32_t *inputs_rowmajor_instance, const U256 *r, const U256 *s, const U256 *randomize, const WideInput *wide = nullptr, size_t n_wide = 0,
+                         const uint8_t *raw = nullptr, int raw_alg = -1);
     void resident_prove(PhaseTimes *times);                  // one batch, one stream
     void resident_prove_pipelined(int nsteps, PhaseTimes *times);   // timed region of bench.py: solve(k+1) under NTT+MSM(k)
     void resident_download(ProofPoints *out, uint32_t *errs);

@@ -713,21 +713,25 @@ void Algorithm::resident_reserve_buffers(size_t B) {
 }
 
 // inputs [B][n_inputs] (instance-major, as the host builds them), r / s / randomize [B] canonical -> set S, on stream st
-void Algorithm::upload_set(SolveSet &S, size_t B, const uint32_t *inputs, const U256 *r, const U256 *s, const U256 *randomize, hipStream_t st) {
+void Algorithm::upload_set(SolveSet &S, size_t B, const uint32_t *inputs, const U256 *r, const U256 *s, const U256 *randomize, hipStream_t st, const uint8_t *raw,
+                           int raw_alg) {
     S.n_wide = 0;
-    ZK_HIP(hipMemcpyAsync(S.sb.inputs.p, inputs, prog.n_inputs * B * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    S.sb.raw_alg = raw ? raw_alg : -1;
+    if (raw) ZK_HIP(hipMemcpyAsync(S.sb.raw.p, raw, SOLVER_RAW_STRIDE * B, hipMemcpyHostToDevice, st));
+    else ZK_HIP(hipMemcpyAsync(S.sb.inputs.p, inputs, prog.n_inputs * B * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     ZK_HIP(hipMemcpyAsync(S.r.p, r, B * sizeof(U256), hipMemcpyHostToDevice, st));
     ZK_HIP(hipMemcpyAsync(S.s.p, s, B * sizeof(U256), hipMemcpyHostToDevice, st));
     if (randomize) ZK_HIP(hipMemcpyAsync(S.rnd.p, randomize, B * sizeof(U256), hipMemcpyHostToDevice, st));
     else ZK_HIP(hipMemsetAsync(S.rnd.p, 0, B * sizeof(U256), st));
 }
 
-void Algorithm::resident_upload(size_t B, const uint32_t *inputs, const U256 *r, const U256 *s, const U256 *randomize, const WideInput *wide, size_t n_wide) {
+void Algorithm::resident_upload(size_t B, const uint32_t *inputs, const U256 *r, const U256 *s, const U256 *randomize, const WideInput *wide, size_t n_wide,
+                                const uint8_t *raw, int raw_alg) {
     resident_reserve(B);
     Resident &R = *res;
     for (auto &S : R.set)
         if (S.ready) {
-            upload_set(S, B, inputs, r, s, randomize, R.stream);
+            upload_set(S, B, inputs, r, s, randomize, R.stream, raw, raw_alg);
             if (n_wide) {
                 for (size_t i = 0; i < n_wide; i++)
                     if (wide[i].instance >= B || wide[i].index >= prog.n_inputs) throw ZkError("wide witness element out of range");
@@ -1117,6 +1121,8 @@ void Algorithm::ensure_second_set_once(int nsets) {
         R.set[i].sb.B = R.B;
         SolveSet &a = R.set[0], &b = R.set[i];
         ZK_HIP(hipMemcpy(b.sb.inputs.p, a.sb.inputs.p, prog.n_inputs * R.B * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+        ZK_HIP(hipMemcpy(b.sb.raw.p, a.sb.raw.p, SOLVER_RAW_STRIDE * R.B, hipMemcpyDeviceToDevice));
+        b.sb.raw_alg = a.sb.raw_alg;
         ZK_HIP(hipMemcpy(b.r.p, a.r.p, R.B * sizeof(U256), hipMemcpyDeviceToDevice));
         ZK_HIP(hipMemcpy(b.s.p, a.s.p, R.B * sizeof(U256), hipMemcpyDeviceToDevice));
         ZK_HIP(hipMemcpy(b.rnd.p, a.rnd.p, R.B * sizeof(U256), hipMemcpyDeviceToDevice));
@@ -1268,8 +1274,16 @@ void Algorithm::resident_download(ProofPoints *out, uint32_t *errs) {
 // batch proofs, chunked to max_chunk instances per device pass.  More than one chunk: the chunks are software-pipelined exactly as
 // resident_prove_pipelined does with repeated passes (solve of chunk k+1 and tail of chunk k-1 under the NTT + MSM stage of chunk k),
 // with the uploads / downloads on a copy stream, so callers of ProveBatch see the pipelined rate.
+void Algorithm::prove_batch_raw(size_t batch, const uint8_t *raw, int raw_alg, const U256 *r, const U256 *s, const U256 *randomize, ProofPoints *out, uint32_t *errs) {
+    if (!raw || raw_alg < 0) throw ZkError("prove_batch_raw: no records");
+    prove_batch_impl(batch, nullptr, raw, raw_alg, r, s, randomize, out, errs, nullptr, nullptr, 0);
+}
 void Algorithm::prove_batch(size_t batch, const uint32_t *inputs, const U256 *r, const U256 *s, const U256 *randomize, ProofPoints *out,
                             uint32_t *errs, PhaseTimes *times, const WideInput *wide, size_t n_wide) {
+    prove_batch_impl(batch, inputs, nullptr, -1, r, s, randomize, out, errs, times, wide, n_wide);
+}
+void Algorithm::prove_batch_impl(size_t batch, const uint32_t *inputs, const uint8_t *raw, int raw_alg, const U256 *r, const U256 *s, const U256 *randomize,
+                                 ProofPoints *out, uint32_t *errs, PhaseTimes *times, const WideInput *wide, size_t n_wide) {
     std::unique_lock<std::mutex> lk(mu);
     last_use = ++g_use_clock;
     comb_second_chance();
@@ -1278,7 +1292,7 @@ void Algorithm::prove_batch(size_t batch, const uint32_t *inputs, const U256 *r,
     const size_t nchunks = (batch + max_chunk - 1) / max_chunk;
     if (n_wide && nchunks > 1) throw ZkError("prove_batch: wide witness elements are supported for single-chunk batches only");
     if (nchunks <= 1) {
-        resident_upload(batch, inputs, r, s, randomize, wide, n_wide);
+        resident_upload(batch, inputs, r, s, randomize, wide, n_wide, raw, raw_alg);
         PhaseTimes t;
         resident_prove(&t);
         resident_download(out, errs);
@@ -1289,11 +1303,13 @@ void Algorithm::prove_batch(size_t batch, const uint32_t *inputs, const U256 *r,
     struct ArrayFeed : ChunkFeed {
         size_t batch, chunk, ni, k = 0;
         const uint32_t *inputs; const U256 *r, *s, *rnd; ProofPoints *out; uint32_t *errs;
+        const uint8_t *raw = nullptr; int raw_alg = -1;
         bool next(Chunk &c) override {
             const size_t off = k * chunk;
             if (off >= batch) return false;
             c.id = k++; c.count = std::min(chunk, batch - off);
-            c.inputs = inputs + off * ni; c.r = r + off; c.s = s + off; c.rnd = rnd ? rnd + off : nullptr;
+            c.inputs = inputs ? inputs + off * ni : nullptr; c.r = r + off; c.s = s + off; c.rnd = rnd ? rnd + off : nullptr;
+            c.raw = raw ? raw + off * SOLVER_RAW_STRIDE : nullptr; c.raw_alg = raw_alg;
             c.out = out + off; c.errs = errs ? errs + off : nullptr;
             return true;
         }
@@ -1301,6 +1317,7 @@ void Algorithm::prove_batch(size_t batch, const uint32_t *inputs, const U256 *r,
     } feed;
     feed.batch = batch; feed.chunk = max_chunk; feed.ni = ni;
     feed.inputs = inputs; feed.r = r; feed.s = s; feed.rnd = randomize; feed.out = out; feed.errs = errs;
+    feed.raw = raw; feed.raw_alg = raw_alg;
     lk.unlock();
     prove_stream(feed, times);
 }
@@ -1354,7 +1371,7 @@ void Algorithm::prove_stream(ChunkFeed &feed, PhaseTimes *times) {
         nx.sb.B = c.count;
         // inputs go up on the solve stream itself (the set is free: its previous chunk has been downloaded); the copy stream carries
         // the ahead-prepared transforms / patterns / sort of earlier chunks, which wait for other streams
-        upload_set(nx, c.count, c.inputs, c.r, c.s, c.rnd, S);
+        upload_set(nx, c.count, c.inputs, c.r, c.s, c.rnd, S, c.raw, c.raw_alg);
         enqueue_solve(nx, has_commit ? R.ms2 : R.ms, S);
         ZK_HIP(hipEventRecord(nx.solved, S));
         if (ahead_eligible()) enqueue_ntt_sort(nx, side_chain_stream(S, nx), (int)(j & 1), j >= 2 ? R.set[(j - 2) % NS].zdone : nullptr);

@@ -44,6 +44,11 @@ struct SolverBuffers {
     DevBuf<Fr> wires;          // [n_wires][B]
     DevBuf<Fr> a, b, c;        // [N][B]
     DevBuf<uint32_t> inputs;   // [B][n_inputs] small integers (instance-major, as the host builds them)
+    // the request path's compact form (request.h, RawWitness): [B][SOLVER_RAW_STRIDE] bytes -- the request's own bytes and the cipher
+    // output, 320 B per proof instead of 10 KB of bit-expanded u32 (ChaCha20) -- expanded into the input wires on the device.
+    // raw_alg >= 0: the next solver_begin reads `raw` (algorithm id 0 chacha20 / 1 aes-128 / 2 aes-256), else `inputs`.
+    DevBuf<uint8_t> raw;
+    int raw_alg = -1;
     DevBuf<Fr> randomize;      // [B] Montgomery
     DevBuf<Fr> challenge;      // [B] Montgomery (commitment challenge)
     DevBuf<uint32_t> err;      // [B] (code | constraint<<8)
@@ -52,6 +57,7 @@ struct SolverBuffers {
 };
 
 
+constexpr size_t SOLVER_RAW_STRIDE = 320;      // == request.h RAW_STRIDE
 // inputs -> wires rows 0..n_inputs ; zero a,b,c ; clear errors
 void solver_begin(const SolverProgram &p, SolverBuffers &buf, hipStream_t s);
 // run levels [first_level, last_level)

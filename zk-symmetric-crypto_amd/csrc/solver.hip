@@ -313,6 +313,7 @@ void SolverBuffers::reserve(const SolverProgram &p, size_t B_) {
     wires.ensure(p.n_wires * B);
     a.ensure(N * B); b.ensure(N * B); c.ensure(N * B);
     inputs.ensure(p.n_inputs * B);
+    raw.ensure(SOLVER_RAW_STRIDE * B);
     randomize.ensure(B); challenge.ensure(B); err.ensure(B);
     count_scratch.ensure((p.n_count_rows ? p.n_count_rows : 1) * (p.n_count_slots ? p.n_count_slots : 1) * B);
 }
@@ -772,6 +773,40 @@ __global__ __launch_bounds__(256) void k_assign_inputs(const uint32_t *__restric
     wires[t] = v == 0 ? Fr::zero() : (v == 1 ? Fr::one() : Fr::from_u32(v));
 }
 
+// The same from the request path's 320-byte records (request.h: build_raw / expand_raw are the host mirror, and what the u32 path of
+// the benchmark entries is generated with): row r of instance b = one bit / byte / word of the record.
+//   chacha20 (provers.go:155-173, utils/bytes.go:12-48): Counter[2][32] | Nonce[2][3][32] (LE words) | In[32][32] | Out[32][32] (BE words) |
+//            Key[8][32] (LE words), bits LSB first;  record: counter[2] u32 LE | nonce[2][12] | in[128] | out[128] | key[32]
+//   aes (provers.go:240-263): Nonce[5][12] | Counter[5] | In[80] | Out[80] | Key[16|32] byte values;
+//            record: nonce[5][12] | counter[5] u32 LE | in[80] | out[80] | key
+__device__ __forceinline__ uint32_t raw_le32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+__device__ __forceinline__ uint32_t raw_be32(const uint8_t *p) { return (uint32_t)p[3] | ((uint32_t)p[2] << 8) | ((uint32_t)p[1] << 16) | ((uint32_t)p[0] << 24); }
+__global__ __launch_bounds__(256) void k_assign_inputs_raw(const uint8_t *__restrict__ raw, int alg, Fr *__restrict__ wires, size_t n_inputs, size_t B) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (n_inputs + 1) * B) return;
+    const size_t row = t / B, b = t % B;
+    if (row == 0) { wires[t] = Fr::one(); return; }
+    const uint8_t *r = raw + b * SOLVER_RAW_STRIDE;
+    const uint32_t i = (uint32_t)row - 1;
+    uint32_t v;
+    if (alg == 0) {
+        uint32_t word;
+        if (i < 64) word = raw_le32(r + 4 * (i >> 5));
+        else if (i < 256) word = raw_le32(r + 8 + 4 * ((i - 64) >> 5));              // nonce words: 12 * blk + 4 * k = 4 * (3 blk + k)
+        else if (i < 1280) word = raw_be32(r + 32 + 4 * ((i - 256) >> 5));
+        else if (i < 2304) word = raw_be32(r + 160 + 4 * ((i - 1280) >> 5));
+        else word = raw_le32(r + 288 + 4 * ((i - 2304) >> 5));
+        v = (word >> (i & 31)) & 1u;
+    } else {
+        if (i < 60) v = r[i];
+        else if (i < 65) v = raw_le32(r + 60 + 4 * (i - 60));
+        else if (i < 145) v = r[80 + (i - 65)];
+        else if (i < 225) v = r[160 + (i - 145)];
+        else v = r[240 + (i - 225)];
+    }
+    wires[t] = v == 0 ? Fr::zero() : (v == 1 ? Fr::one() : Fr::from_u32(v));
+}
+
 void solver_begin(const SolverProgram &p, SolverBuffers &buf, hipStream_t s) {
     const size_t B = buf.B, N = (size_t)1 << p.log_domain;
     // a and b: every row an R1C instruction owns is written by it; only the rows nobody writes must be zero again (the transforms
@@ -784,7 +819,12 @@ void solver_begin(const SolverProgram &p, SolverBuffers &buf, hipStream_t s) {
         ZK_HIP(hipMemsetAsync(buf.b.p + first_clear * B, 0, (N - first_clear) * B * sizeof(Fr), s));
     }
     ZK_HIP(hipMemsetAsync(buf.err.p, 0, B * sizeof(uint32_t), s));
-    hipLaunchKernelGGL(k_assign_inputs, dim3(ceil_div((p.n_inputs + 1) * B, 256)), dim3(256), 0, s, buf.inputs.p, buf.wires.p, p.n_inputs, B);
+    if (buf.raw_alg >= 0) {
+        const size_t want = buf.raw_alg == 0 ? 2560 : (buf.raw_alg == 1 ? 241 : 257);
+        if (p.n_inputs != want) throw ZkError("solver: raw witness records do not match the circuit");
+        hipLaunchKernelGGL(k_assign_inputs_raw, dim3(ceil_div((p.n_inputs + 1) * B, 256)), dim3(256), 0, s, buf.raw.p, buf.raw_alg, buf.wires.p, p.n_inputs, B);
+    } else
+        hipLaunchKernelGGL(k_assign_inputs, dim3(ceil_div((p.n_inputs + 1) * B, 256)), dim3(256), 0, s, buf.inputs.p, buf.wires.p, p.n_inputs, B);
     ZK_HIP(hipGetLastError());
 }
 

@@ -785,3 +785,18 @@ extern "C" int zkp_bsb22_challenge_host(const uint8_t *com_be64, long n, uint8_t
     }
     return 0;
 }
+
+// ---- request layer (cabi.cpp / request.cpp): decoder agreement and the device-free host-stage benchmark
+namespace zk {
+int request_decode_both(const char *p, size_t n);
+int host_stage_bench(const char *data, size_t len, int iters, double *out);
+}
+// 1: the single-pass scanner took the request and agrees with the DOM reader, 0: it declined, -1: the two disagree
+extern "C" int zkp_request_decode_both(const uint8_t *json, long len) { return zk::request_decode_both((const char *)json, (size_t)(len < 0 ? 0 : len)); }
+// host stages of a streamed ProveBatch without a device: out4 = {decode stage requests/s, serialise stage requests/s, requests the scanner
+// took, requests that produced a record}
+extern "C" int zkp_host_stage_bench(const uint8_t *json_array, long len, int iters, double *out4) {
+    try {
+        return zk::host_stage_bench((const char *)json_array, (size_t)len, iters, out4);
+    } catch (const std::exception &e) { zk::set_last_error(e.what()); return -1; }
+}
