@@ -26,14 +26,24 @@ package libraries_test
 import "C"
 
 import (
+	"bytes"
 	"crypto/rand"
 	"encoding/json"
+	"errors"
 	"os"
 	"testing"
 	"unsafe"
 
+	"github.com/consensys/gnark-crypto/ecc"
+	"github.com/consensys/gnark/backend/groth16"
+	"github.com/consensys/gnark/backend/witness"
+	"github.com/consensys/gnark/frontend"
+
+	aes_v2 "github.com/reclaimprotocol/zk-symmetric-crypto/gnark/circuits/aesV2"
+	"github.com/reclaimprotocol/zk-symmetric-crypto/gnark/circuits/chachaV3"
 	prover "github.com/reclaimprotocol/zk-symmetric-crypto/gnark/libraries/prover/impl"
 	verifier "github.com/reclaimprotocol/zk-symmetric-crypto/gnark/libraries/verifier/impl"
+	"github.com/reclaimprotocol/zk-symmetric-crypto/gnark/utils"
 )
 
 func goSlice(b []byte) C.GoSlice {
@@ -63,6 +73,71 @@ func gpuProve(t *testing.T, params []byte) *prover.OutputParams {
 		t.Fatalf("libzkprove Prove did not return a proof: %s", C.GoString((*C.char)(r.r0)))
 	}
 	return out
+}
+
+// gpuProveWitness is the shim of INTEGRATION.md section 2: groth16.Prove(cp.r1cs, cp.pk, wtns) replaced by ZkpProveWitness
+// (gnark/libraries/prover/impl/provers.go:179,269).  Convention pinned: witness.MarshalBinary's layout (header of three big-endian
+// u32, 32-byte big-endian elements, public part first without the constant one) and Proof.WriteTo / ReadFrom.
+func gpuProveWitness(id uint8, wtns witness.Witness) (groth16.Proof, error) {
+	wb, err := wtns.MarshalBinary()
+	if err != nil {
+		return nil, err
+	}
+	r := C.ZkpProveWitness(C.uchar(id), goSlice(wb))
+	defer C.Free(r.r0)
+	if r.r1 < 0 {
+		return nil, errors.New(string(C.GoBytes(r.r0, C.int(-r.r1))))
+	}
+	proof := groth16.NewProof(ecc.BN254)
+	_, err = proof.ReadFrom(bytes.NewReader(C.GoBytes(r.r0, C.int(r.r1))))
+	return proof, err
+}
+
+// the ChaCha20 witness exactly as ChaChaProver.Prove assigns it (provers.go:139-173), proved through the shim and checked with
+// gnark's own groth16.Verify against the vk the reference verifier embeds
+func TestLibzkproveWitnessBoundary(t *testing.T) {
+	gpuInit(t, 0, "chacha20")
+	key := make([]byte, 32)
+	nonce := make([]byte, 12)
+	input := make([]byte, 128)
+	rand.Read(key)
+	rand.Read(nonce)
+	rand.Read(input)
+	params, _ := json.Marshal(&prover.InputParams{Cipher: "chacha20", Key: key, Blocks: []prover.Block{{Nonce: nonce, Counter: 1}, {Nonce: nonce, Counter: 2}}, Input: input})
+	var ref *prover.OutputParams
+	json.Unmarshal(prover.Prove(params), &ref) // for the ciphertext (the native cipher of the reference)
+	w := &chachaV3.ChaChaCircuit{}
+	for b := 0; b < 2; b++ {
+		w.Counter[b] = utils.Uint32ToBits(uint32(1 + b))
+		copy(w.Nonce[b][:], utils.BytesToUint32LEBits(nonce))
+	}
+	copy(w.In[:], utils.BytesToUint32BEBits(input))
+	copy(w.Out[:], utils.BytesToUint32BEBits(ref.Ciphertext))
+	copy(w.Key[:], utils.BytesToUint32LEBits(key))
+	wtns, err := frontend.NewWitness(w, ecc.BN254.ScalarField())
+	if err != nil {
+		t.Fatal(err)
+	}
+	proof, err := gpuProveWitness(0, wtns)
+	if err != nil {
+		t.Fatalf("ZkpProveWitness: %v", err)
+	}
+	buf := &bytes.Buffer{}
+	proof.WriteTo(buf)
+	signals, _ := json.Marshal(&verifier.PublicSignalsJSON{Ciphertext: ref.Ciphertext, Blocks: []verifier.Block{{Nonce: nonce, Counter: 1}, {Nonce: nonce, Counter: 2}}, Input: input})
+	req, _ := json.Marshal(&verifier.InputVerifyParams{Cipher: "chacha20", Proof: buf.Bytes(), PublicSignals: signals})
+	if !verifier.Verify(req) {
+		t.Fatal("reference verifier rejected the proof ZkpProveWitness made from gnark's own witness")
+	}
+	// a witness that does not satisfy the circuit comes back as an error, as from groth16.Prove
+	wrong := append([]byte{}, ref.Ciphertext...)
+	wrong[0] ^= 1
+	copy(w.Out[:], utils.BytesToUint32BEBits(wrong))
+	bad, _ := frontend.NewWitness(w, ecc.BN254.ScalarField())
+	if _, err := gpuProveWitness(0, bad); err == nil {
+		t.Fatal("ZkpProveWitness proved an unsatisfied witness")
+	}
+	_ = aes_v2.BLOCKS
 }
 
 func runCase(t *testing.T, id uint8, ext, cipher string, keyLen, nBlocks, blockLen int) {
