@@ -88,6 +88,14 @@ class Leg:
         if not zk.init_algorithm(alg, pk, r1cs):
             raise SystemExit("InitAlgorithm failed")
         self.t_init = time.time() - t0
+        self.rank = rank
+        self.rb = None
+
+    def upload(self):
+        """synthetic instances -> witness assignments -> resident batch (reserves the working buffers; the first 1024-batch also makes
+        the library decide and build its comb tables, by a budget that looks at what is loaded on the device: both circuits of the
+        metric are initialised before either uploads)"""
+        zk, alg, B, rank, H = self.zk, self.alg, self.B, self.rank, self.zk.synth
         # synthetic instances: SplitMix64(0x5EED0000 + config index), independent stream per rank
         import numpy as np
         rng = H.SplitMix64(0x5EED0000 + (1 if alg == 0 else 2) + 1000 * rank)
@@ -379,11 +387,15 @@ def run_rank(args):
 
     manifest = profile_manifest()
     legs_out = {}
+    # both circuits of the metric are initialised first (a host that serves both ciphers: the library budgets its tables per loaded
+    # circuit), then each leg uploads its batch and is timed
     head = Leg(zk, args.alg, B, rank)
+    aes = Leg(zk, 2, B, rank) if (args.alg == 0 and not args.no_aes256) else None
+    head.upload()
     res = timed(head)
     algs = [(args.alg, head, res)]
-    if args.alg == 0 and not args.no_aes256:
-        aes = Leg(zk, 2, B, rank)
+    if aes is not None:
+        aes.upload()
         algs.append((2, aes, timed(aes)))
 
     if rank == 0:

@@ -138,7 +138,11 @@ bool release_neighbours(Algorithm *self) {
         if (a->release_comb_if_idle()) return true;
     return false;
 }
-const bool g_hook_set = [] { Algorithm::neighbours_release = release_neighbours; return true; }();
+// replicas (of every algorithm) the registry holds on `device`.  Called from a proving call's table decision; a slot whose lock is held
+// (being initialised or reset right now) is counted as it was.
+std::atomic<int> g_loaded_on[64];
+int loaded_on_device(int device) { return g_loaded_on[device & 63].load(); }
+const bool g_hook_set = [] { Algorithm::neighbours_release = release_neighbours; Algorithm::loaded_on_device = loaded_on_device; return true; }();
 // one decoded request with its witness assignment and cipher output (or the panic value it produced)
 struct Prepared {
     int alg = -1;
@@ -781,6 +785,7 @@ int ZkpDeviceReplicas(int algorithmID) {
 void ZkpReset(void) {
     for (auto &s : g_slots) {
         std::lock_guard<std::mutex> lk(s.lock);
+        for (auto &r : s.replicas) g_loaded_on[r->device & 63]--;
         s.replicas.clear();
     }
     g_chunk_pool.clear();
@@ -837,6 +842,7 @@ unsigned char InitAlgorithm(unsigned char algorithmID, GoSlice provingKey, GoSli
         for (auto &t : th) t.join();
         if (!reps[0]) throw ZkError(fail[0]);
         for (size_t k = 0; k < devs.size(); k++) {
+            if (reps[k]) g_loaded_on[devs[k] & 63]++;
             if (reps[k]) slot.replicas.push_back(std::move(reps[k]));
             else fprintf(stderr, "zkprove: %s not replicated on device %d: %s\n", ai.name, devs[k], fail[k].c_str());
         }

@@ -128,6 +128,7 @@ class Algorithm {
     // Memory pressure across algorithms: the hook (set by cabi.cpp, which owns the registry) asks every OTHER algorithm on this device
     // that is idle right now to give its comb tables back (release_comb_if_idle); true when something was freed
     static bool (*neighbours_release)(Algorithm *self);
+    static int (*loaded_on_device)(int device);             // replicas of ALL algorithms the registry holds on a device (cabi.cpp): the comb budget's divisor
     bool release_comb_if_idle();
     size_t comb_table_bytes() const;                        // quotient + wire comb tables held right now
     std::atomic<uint64_t> last_use{0};                      // stamp of the last proving call (prove_batch / prove_stream)

@@ -430,21 +430,23 @@ static size_t comb_min_batch() {
     static const size_t v = [] { const char *e = getenv("ZKPROVE_COMB_MIN_BATCH"); return e ? (size_t)atol(e) : (size_t)128; }();
     return v;
 }
-// Largest clump size whose table fits the budget.  The budget has two sides: a fixed share of the device (0.21 of its memory -- the k = 19
-// table of a 2^16 domain, the k = 18 table of a 2^17 one -- divided by the replicas the library keeps on this device), and what is left
-// once the buffers this replica will still allocate (working sets, pattern copies) are set aside.  Decisions are serialised per device
-// so that each one sees the tables of the replicas before it on the same GPU.
+// Largest clump size whose table fits the budget.  The budget has two sides: a share of the device -- 0.42 of its memory divided by
+// the algorithm replicas LOADED on this device when the decision is made (one circuit alone: k = 20 for a 2^16 domain, 19 for 2^17 --
+// +3.1 % / +2.3 % proofs/s, profiles/r03p_k_sweep.txt; two circuits: 0.21 each = k = 19 / 18, which together with the working sets fill
+// 254 of the 288 GB; the tables are built by the first large batch, i.e. normally after the host has initialised what it serves) --
+// and what is left once the buffers this replica will still allocate (working sets, pattern copies) are set aside.  Decisions are
+// serialised per device so that each one sees the tables of the replicas before it on the same GPU.
 static std::mutex g_comb_budget_lock[64];      // per device: replicas on different GPUs decide and build in parallel
 static int comb_pick_k(size_t n, size_t still_needed, int share) {
     static const int forced = [] { const char *e = getenv("ZKPROVE_COMB_K"); return e ? atoi(e) : 0; }();
     if (forced) return forced;
     size_t free_b = 0, total_b = 0;
     ZK_HIP(hipMemGetInfo(&free_b, &total_b));
-    const double by_share = 0.21 * (double)total_b / (double)(share < 1 ? 1 : share);
+    const double by_share = 0.42 * (double)total_b / (double)(share < 1 ? 1 : share);
     const double by_free = free_b > still_needed ? 0.75 * (double)(free_b - still_needed) : 0.0;
     const double budget = by_share < by_free ? by_share : by_free;
     int pick = 0;
-    for (int k = 19; k >= 12 && !pick; k--)
+    for (int k = 20; k >= 12 && !pick; k--)
         if ((double)comb_table_bytes(n, k) <= budget) pick = k;
     static const bool log = getenv("ZKPROVE_MEMLOG") != nullptr;
     if (log)
@@ -476,7 +478,8 @@ void Algorithm::comb_prepare(size_t B) {
         const size_t per_set = B * (prog.n_wires + 3 * N) * sizeof(Fr);
         const size_t sets_to_come = (R.set[1].ready ? 0 : 1) + (R.set[2].ready ? 0 : 1);      // (a second chance after a release finds them in place)
         const size_t still_needed = sets_to_come * per_set + 2 * ((pk.ze.n / 16 + 1) * 254 * B * sizeof(uint32_t)) + ((size_t)6 << 30);
-        const int k = comb_pick_k(pk.ze.n, still_needed, comb_share);
+        const int loaded = loaded_on_device ? loaded_on_device(device) : comb_share;      // algorithm replicas on this GPU right now, this one included
+        const int k = comb_pick_k(pk.ze.n, still_needed, std::max(loaded, comb_share));
         bool ok = false;
         std::string why = "not enough free device memory";
         if (k) {
@@ -1076,6 +1079,7 @@ bool Algorithm::comb_release() {
 // fit and it has no tables of its own to give back.  The tables of the algorithms that are idle at that moment go instead (they continue
 // on the bucket pipeline; the log line says so) -- a request must not fail for the sake of another circuit's optimisation.
 bool (*Algorithm::neighbours_release)(Algorithm *self) = nullptr;
+int (*Algorithm::loaded_on_device)(int device) = nullptr;
 bool Algorithm::release_comb_if_idle() {
     std::unique_lock<std::mutex> lk(mu, std::try_to_lock);
     if (!lk || !res) return false;
