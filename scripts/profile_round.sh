@@ -12,6 +12,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cc -o cc -- pyt
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_aes -o aes -- python3 bench.py --cpu-proofs 0 --alg 2 --abi-requests 0 > $O/bench_aes_under_rocprof.json 2> $O/stats_aes.log
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python3 bench.py --steps 1 --warmup 1 --cpu-proofs 0 --no-pipeline --no-aes256 --abi-requests 0 > /dev/null 2> $O/pmc_fetch.log
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- python3 bench.py --steps 1 --warmup 1 --cpu-proofs 0 --no-pipeline --no-aes256 --abi-requests 0 > /dev/null 2> $O/pmc_write.log
+# the same two passes for the AES-256 leg (its quotient walk is the dominant kernel of that half of the metric)
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_aes -o f -- python3 bench.py --steps 1 --warmup 1 --cpu-proofs 0 --no-pipeline --alg 2 --abi-requests 0 > /dev/null 2> $O/pmc_fetch_aes.log
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_aes -o w -- python3 bench.py --steps 1 --warmup 1 --cpu-proofs 0 --no-pipeline --alg 2 --abi-requests 0 > /dev/null 2> $O/pmc_write_aes.log
+python scripts/host_feed_bench.py > $O/host_feed.jsonl 2> /dev/null
 # one steady-state step of each circuit as a kernel timeline (which stream ran what when): scripts/debug/timeline_step.py
 for A in 0 2; do
   rocprofv3 --kernel-trace --output-format csv -d $O/tr$A -o t -- python3 bench.py --cpu-proofs 0 --alg $A --no-aes256 --abi-requests 0 > /dev/null 2> $O/tr$A.log

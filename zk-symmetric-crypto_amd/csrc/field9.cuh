@@ -24,10 +24,19 @@
 // Replaces the same gnark-crypto v0.19.2 fp / fr element arithmetic as field.cuh (ecc/bn254/fp/element.go Mul / Add / Sub reached
 // from MultiExp's bucket additions, provers.go:179,269).
 #pragma once
+#include <utility>
 #include "field.cuh"
 #include "field9_consts.inc"
 
 namespace zk {
+
+// ZK_F9_COLUMN_ASM=0 (A/B builds): one asm statement per multiply-add, as before round 4
+#ifndef ZK_F9_COLUMN_ASM
+#define ZK_F9_COLUMN_ASM 1
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#include "field9_mac.inc"
+#endif
 
 struct Fp9Params {
     using Base = FpParams;
@@ -82,6 +91,94 @@ struct Field9 {
     // Product scanning: column k of reduction j collects its products and the multiples m_i * M_(k-i) in one 64-bit accumulator,
     // m_k clears the column's low 29 bits, the rest carries into column k+1.  The K accumulator chains are independent and are
     // issued interleaved (a v_mad_i64_i32 that reads the result of the one just before it costs a wait state on gfx950).
+    // On the device a column's multiply-adds on one accumulator are ONE asm statement (field9_mac.inc, Mac9<N>): with a statement per
+    // multiply-add hipcc pads every one with an s_nop -- 1 203 of the 3 900 instructions of the comb walk's loop.
+    template <int N>
+    static ZK_HD void macn(int64_t &acc, const int32_t (&a)[N], const int32_t (&b)[N]) {
+#if defined(__HIP_DEVICE_COMPILE__) && ZK_F9_COLUMN_ASM
+        Mac9<N>::vv(acc, a, b);
+#elif defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int i = 0; i < N; i++) mac(acc, a[i], b[i]);
+#else
+        for (int i = 0; i < N; i++) acc += (int64_t)a[i] * (int64_t)b[i];
+#endif
+    }
+    template <int N>
+    static ZK_HD void macn_const(int64_t &acc, const int32_t (&a)[N], const int32_t (&b)[N]) {      // b: limbs of the modulus (scalar registers)
+#if defined(__HIP_DEVICE_COMPILE__) && ZK_F9_COLUMN_ASM
+        Mac9<N>::vs(acc, a, b);
+#elif defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int i = 0; i < N; i++) mac_const(acc, a[i], b[i]);
+#else
+        for (int i = 0; i < N; i++) acc += (int64_t)a[i] * (int64_t)b[i];
+#endif
+    }
+    template <int K, int k>
+    static ZK_HD void lockstep_column(const Term (&tm)[K][2], const int (&np)[K], const Field9 (&a2)[K][2], int64_t (&acc)[K], int32_t (&m)[K][9], Field9 (&r)[K]) {
+        constexpr int lo = k > 8 ? k - 8 : 0, hi = k < 8 ? k : 8, N = hi - lo + 1;
+        // symmetric terms: cross products i < k - i once against 2a, the diagonal i == k - i once
+        constexpr int half = (k - 1) / 2, chi = k == 0 ? -1 : (hi < half ? hi : half);
+        constexpr int NC = chi >= lo ? chi - lo + 1 : 0, ND = (k % 2 == 0 && k / 2 >= lo && k / 2 <= hi) ? 1 : 0, NS = NC + ND;
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+                if (t >= np[j]) continue;
+                const Term &T = tm[j][t];
+                if (!T.sym) {
+                    int32_t xa[N], xb[N];
+#pragma unroll
+                    for (int i = lo; i <= hi; i++) { xa[i - lo] = T.a->l[i]; xb[i - lo] = T.b->l[k - i]; }
+                    macn<N>(acc[j], xa, xb);
+                } else {
+                    int32_t xa[NS], xb[NS];
+#pragma unroll
+                    for (int q = 0; q < NC; q++) { xa[q] = a2[j][t].l[lo + q]; xb[q] = T.b->l[k - lo - q]; }
+                    if (ND) { xa[NS - 1] = T.a->l[k / 2]; xb[NS - 1] = T.b->l[k / 2]; }
+                    macn<NS>(acc[j], xa, xb);
+                }
+            }
+        if constexpr (k < 9) {
+            if constexpr (k > 0) {
+#pragma unroll
+                for (int j = 0; j < K; j++) {
+                    int32_t xm[k], xM[k];
+#pragma unroll
+                    for (int i = 0; i < k; i++) { xm[i] = m[j][i]; xM[i] = Q::M[k - i]; }
+                    macn_const<k>(acc[j], xm, xM);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < K; j++) m[j][k] = (int32_t)(((uint32_t)acc[j] * Q::PINV) & MASK);
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+                const int32_t xm[1] = {m[j][k]}, xM[1] = {Q::M[0]};
+                macn_const<1>(acc[j], xm, xM);
+                acc[j] >>= 29;
+            }
+        } else {
+            constexpr int NR = 17 - k;
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+                int32_t xm[NR], xM[NR];
+#pragma unroll
+                for (int i = k - 8; i < 9; i++) { xm[i - (k - 8)] = m[j][i]; xM[i - (k - 8)] = Q::M[k - i]; }
+                macn_const<NR>(acc[j], xm, xM);
+            }
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+                r[j].l[k - 9] = (int32_t)((uint32_t)acc[j] & MASK);
+                acc[j] >>= 29;
+            }
+        }
+    }
+    template <int K, int... Ks>
+    static ZK_HD void lockstep_columns(const Term (&tm)[K][2], const int (&np)[K], const Field9 (&a2)[K][2], int64_t (&acc)[K], int32_t (&m)[K][9], Field9 (&r)[K],
+                                       std::integer_sequence<int, Ks...>) {
+        (lockstep_column<K, Ks>(tm, np, a2, acc, m, r), ...);
+    }
     template <int K>
     static ZK_HD void mont_lockstep(const Term (&tm)[K][2], const int (&np)[K], Field9 (&r)[K]) {
         int64_t acc[K];
@@ -94,47 +191,7 @@ struct Field9 {
             for (int t = 0; t < 2; t++)
                 if (t < np[j] && tm[j][t].sym) a2[j][t] = add(*tm[j][t].a, *tm[j][t].a);
         }
-#pragma unroll
-        for (int k = 0; k < 17; k++) {
-            const int lo = k > 8 ? k - 8 : 0, hi = k < 8 ? k : 8;
-#pragma unroll
-            for (int i = lo; i <= hi; i++) {
-                const int jj = k - i;
-#pragma unroll
-                for (int t = 0; t < 2; t++)
-#pragma unroll
-                    for (int j = 0; j < K; j++) {
-                        if (t >= np[j]) continue;
-                        const Term &T = tm[j][t];
-                        if (!T.sym) mac(acc[j], T.a->l[i], T.b->l[jj]);
-                        else if (i < jj) mac(acc[j], a2[j][t].l[i], T.b->l[jj]);
-                        else if (i == jj) mac(acc[j], T.a->l[i], T.b->l[i]);
-                    }
-            }
-            if (k < 9) {
-#pragma unroll
-                for (int i = 0; i < k; i++)
-#pragma unroll
-                    for (int j = 0; j < K; j++) mac_const(acc[j], m[j][i], Q::M[k - i]);
-#pragma unroll
-                for (int j = 0; j < K; j++) m[j][k] = (int32_t)(((uint32_t)acc[j] * Q::PINV) & MASK);
-#pragma unroll
-                for (int j = 0; j < K; j++) {
-                    mac_const(acc[j], m[j][k], Q::M[0]);
-                    acc[j] >>= 29;
-                }
-            } else {
-#pragma unroll
-                for (int i = k - 8; i < 9; i++)
-#pragma unroll
-                    for (int j = 0; j < K; j++) mac_const(acc[j], m[j][i], Q::M[k - i]);
-#pragma unroll
-                for (int j = 0; j < K; j++) {
-                    r[j].l[k - 9] = (int32_t)((uint32_t)acc[j] & MASK);
-                    acc[j] >>= 29;
-                }
-            }
-        }
+        lockstep_columns<K>(tm, np, a2, acc, m, r, std::make_integer_sequence<int, 17>());
 #pragma unroll
         for (int j = 0; j < K; j++) r[j].l[8] = (int32_t)acc[j];
     }
