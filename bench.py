@@ -154,7 +154,7 @@ def roofline_objects(alg, B, mean, value_per_gpu, manifest, zinfo, ntt_alone_ms=
     adds = zinfo[4] * B / (zdur_ms * 1e-3)
     traffic, traffic_src = None, None
     pm = manifest.get("pmc_traffic", {}).get(str(alg))
-    if pm and B == 1024 and bool(pm.get("comb")) == comb:
+    if pm and B == 1024 and bool(pm.get("comb")) == comb and pm.get("k", zinfo[1]) == zinfo[1]:      # same path AND same clump size as this run
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", pm["file"])))
             v = d["kernels"][pm["kernel"]]
