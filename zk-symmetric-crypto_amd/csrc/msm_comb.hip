@@ -510,6 +510,12 @@ static void comb_fold_impl(const CombBasesT<F> &cb, size_t B, CombScratch &sc, X
     const int groups = fold_groups(cb.T);
     const size_t tiles = (B + 63) / 64;
     X9 *acc = reinterpret_cast<X9 *>(sc.acc.p), *r1 = reinterpret_cast<X9 *>(sc.r1.p);
+#ifdef ZK_EXPERIMENTS
+    // timing diagnostic (WRONG proofs): the folds of the WIRE combs (out_stride != 1) are skipped -- an upper bound on what batching
+    // the 15 latency-bound fold chains of an AES step into one launch could buy (VERDICT r3 task 2)
+    static const bool skip_wire_folds = [] { const char *e = getenv("ZKPROVE_DIAG_SKIP_WIRE_FOLDS"); return e && e[0] == '1'; }();
+    if (skip_wire_folds && out_stride != 1) return;
+#endif
     if (cb.T <= 32) {
         hipLaunchKernelGGL(k_comb_fold_narrow<F>, dim3((unsigned)tiles), dim3(64), 0, s, acc, B, cb.T, Q, cb.corr.p, out, out_stride);
         ZK_HIP(hipGetLastError());
