@@ -28,7 +28,8 @@ def build():
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(HERE, "liboracle.so")
+        # ORACLE_LIB: another build of the same file (tests/test_sanitizers.py loads liboracle_asan.so, `make -C oracle asan`)
+        so = os.environ.get("ORACLE_LIB") or os.path.join(HERE, "liboracle.so")
         if not os.path.exists(so):
             build()
         L = C.CDLL(so)

@@ -194,3 +194,46 @@ def test_hypothesis_json_shapes(driver, v, kind, cut):
 @given(b=st.binary(max_size=300), kind=st.sampled_from([REQUEST_WITNESS, PROVE_BATCH, VERIFY, INIT_VERIFIER, R1CS_STATS, PROVE_WITNESS]))
 def test_hypothesis_raw_bytes(driver, b, kind):
     driver.send(kind, b)
+
+
+_ORACLE_UNDER_ASAN = r"""
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np
+import helpers as H
+from oracle import ref, pairing, gnark_format as gf
+ref.lib(); ref.set_threads(2)
+rng = np.random.default_rng(5)
+# field / hash / transforms / MSM entry points on small inputs, then the whole pipeline: solve -> setup -> prove -> verify (AES-128:
+# lookups, countHints, the BSB22 commitment) and a violated witness
+v = np.frombuffer(b"".join((int.from_bytes(rng.bytes(32), "little") % H.R).to_bytes(32, "little") for _ in range(64)), np.uint8).reshape(64, 32).copy()
+assert np.array_equal(ref.ntt(ref.ntt(v), inverse=True), v)
+alg = 1
+inst = H.make_instance(alg, H.SplitMix64(3))
+proof, out, prf, wit = H.oracle_proof_bytes(alg, inst)
+vk = gf.vk_from_pk(H.oracle_pk(alg))
+npub = H.circuit(alg).r1cs.nb_public - 1
+assert pairing.groth16_verify(vk, gf.proof_parse(proof), wit[:npub])
+bad = list(wit); bad[100] ^= 1
+try:
+    H.circuit(alg).solve([int(x) for x in bad]); raise SystemExit("violated witness solved")
+except ValueError:
+    pass
+print("oracle under asan ok")
+"""
+
+
+def test_oracle_restatement_under_sanitizers():
+    """the CPU restatement (oracle/oracle.c) under AddressSanitizer + UBSan: transforms, the gnark solver with lookups /
+    countHints / BSB22, setup, a whole AES-128 proof and its verification, a violated witness -- no report"""
+    import sys
+    odir = os.path.join(H.ROOT, "oracle")
+    subprocess.run(["make", "-s", "-C", odir, "asan"], check=True, capture_output=True, timeout=600)
+    libasan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(libasan):
+        pytest.skip("gcc's libasan.so not found")
+    env = dict(os.environ, ORACLE_LIB=os.path.join(odir, "liboracle_asan.so"), LD_PRELOAD=libasan,
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=99", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    res = subprocess.run([sys.executable, "-c", _ORACLE_UNDER_ASAN.format(root=H.ROOT)], capture_output=True, text=True, timeout=1500, env=env)
+    bad = [l for l in res.stderr.splitlines() if "AddressSanitizer" in l or "runtime error" in l]
+    assert res.returncode == 0 and "oracle under asan ok" in res.stdout and not bad, res.stdout[-2000:] + res.stderr[-4000:]
