@@ -257,7 +257,9 @@ def test_scheduling_switches_do_not_change_a_byte(switches):
     kernel's register budget and the packing of short instructions four to a workgroup are scheduling choices: the pipelined-steps test
     (every working set, both pattern copies, byte-identical to the single step and the oracle) passes under each of them.  Own process:
     the switches are read once."""
-    env = dict(os.environ, **switches)
+    exp = os.path.join(H.ROOT, "zk-symmetric-crypto_amd", "libzkprove_exp.so")      # the A/B switches are read by the experiments build only
+    assert os.path.exists(exp), "libzkprove_exp.so missing: run `make -C zk-symmetric-crypto_amd experiments`"
+    env = dict(os.environ, ZKPROVE_LIB=exp, **switches)
     res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k", "pipelined_steps_rotate", "-p", "no:cacheprovider"],
                          env=env, capture_output=True, text=True, timeout=1200, cwd=H.ROOT)
     assert res.returncode == 0 and " passed" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]

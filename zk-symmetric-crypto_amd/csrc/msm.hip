@@ -38,7 +38,7 @@ namespace zk {
 // (one Prove() call) is pure latency of dependent additions, and 4x more threads cut it 4x
 static constexpr int SEG_LOG = 6, SEG_LOG_SMALL = 4;
 static inline uint32_t seg_len(uint32_t nb, size_t B) {
-    static const size_t min_threads = [] { const char *e = getenv("ZKPROVE_SEG_THREADS"); return e ? (size_t)atol(e) : (size_t)32768; }();
+    static const size_t min_threads = [] { const char *e = ZK_AB_ENV("ZKPROVE_SEG_THREADS"); return e ? (size_t)atol(e) : (size_t)32768; }();
     uint32_t L = nb < (1u << SEG_LOG) ? nb : (1u << SEG_LOG);
     if ((size_t)(nb / L) * B < min_threads && nb > (1u << SEG_LOG_SMALL)) L = 1u << SEG_LOG_SMALL;
     return L;
@@ -188,7 +188,7 @@ static uint32_t accumulate_lanes(size_t max_entries, size_t B) {
     size_t piece = 2048;
     while (piece > 64 && (max_entries * B) / piece < 262144) piece >>= 1;
     // parity tests force the production cut (many buckets and several inversion chunks per thread) at batch sizes the CPU oracle can follow
-    static const size_t forced = [] { const char *e = getenv("ZKPROVE_MSM_PIECE"); return e ? (size_t)atol(e) : (size_t)0; }();
+    static const size_t forced = [] { const char *e = ZK_AB_ENV("ZKPROVE_MSM_PIECE"); return e ? (size_t)atol(e) : (size_t)0; }();
     if (forced >= 16) piece = forced;
     const uint32_t nlanes = (uint32_t)((max_entries + piece - 1) / piece);
     return nlanes < 1 ? 1 : nlanes;

@@ -445,7 +445,7 @@ __global__ __launch_bounds__(64, ZK_COMB_BOUNDS(F)) void k_comb_fold_narrow(cons
 }
 
 static uint32_t comb_ranges(size_t B, size_t nclumps, int T) {
-    static const uint32_t forced = [] { const char *e = getenv("ZKPROVE_COMB_Q"); return e ? (uint32_t)atoi(e) : 0u; }();
+    static const uint32_t forced = [] { const char *e = ZK_AB_ENV("ZKPROVE_COMB_Q"); return e ? (uint32_t)atoi(e) : 0u; }();
     uint32_t Q = forced ? forced : 8;
     while (!forced && (size_t)Q * T * B < (1u << 20) && Q < 256) Q *= 2;
     const uint32_t cap = (uint32_t)(nclumps / 24);
@@ -461,7 +461,7 @@ void CombScratch::reserve(const CombBases &cb, size_t B, int nslots) {
     r1.ensure(comb_r1_bytes(cb, B, sizeof(G1X9)));
 }
 void comb_patterns(const CombBases &cb, const Fr *x, const Fr *y, size_t B, uint32_t *pat, hipStream_t s) {
-    static const bool reg_form = [] { const char *e = getenv("ZKPROVE_COMB_PAT_REG"); return !(e && e[0] == '0'); }();
+    static const bool reg_form = [] { const char *e = ZK_AB_ENV("ZKPROVE_COMB_PAT_REG"); return !(e && e[0] == '0'); }();
     if (y && reg_form && cb.k >= 16 && cb.k <= 20) {
         const dim3 grid(ceil_div(B, 64), (unsigned)cb.nclumps);
         switch (cb.k) {

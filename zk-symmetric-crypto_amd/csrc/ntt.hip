@@ -658,7 +658,7 @@ static void launch_dif_lds(Fr *data, size_t B, int logn, int loglen, const Fr *t
     dim3 grid(ceil_div(B, T::TI), (unsigned)(((size_t)1 << logn) >> T::K));
     if constexpr (T::E / (1 << K1) == T::THREADS / T::TI) {
         constexpr int TPW = ZK_NTT_TPW;
-        static const bool pipe = [] { const char *e = getenv("ZKPROVE_NTT_PIPE"); return !(e && e[0] == '0'); }();
+        static const bool pipe = [] { const char *e = ZK_AB_ENV("ZKPROVE_NTT_PIPE"); return !(e && e[0] == '0'); }();
         if (pipe && grid.y % TPW == 0 && grid.y >= (unsigned)TPW) {
             static PerDeviceOnce attr2;
             attr2.run([] { ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_dif_lds_pipe<P, K1, K2, TPW>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES)); });
@@ -677,7 +677,7 @@ static void launch_dit_lds(Fr *data, size_t B, int logn, int logS, const Fr *tw,
     dim3 grid(ceil_div(B, T::TI), (unsigned)(((size_t)1 << logn) >> T::K));
     if constexpr (T::E / (1 << K1) == T::THREADS / T::TI) {
         constexpr int TPW = ZK_NTT_TPW;
-        static const bool pipe = [] { const char *e = getenv("ZKPROVE_NTT_PIPE"); return !(e && e[0] == '0'); }();
+        static const bool pipe = [] { const char *e = ZK_AB_ENV("ZKPROVE_NTT_PIPE"); return !(e && e[0] == '0'); }();
         if (pipe && grid.y % TPW == 0 && grid.y >= (unsigned)TPW) {
             static PerDeviceOnce attr2;
             attr2.run([] { ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_dit_lds_pipe<P, K1, K2, TPW>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES)); });

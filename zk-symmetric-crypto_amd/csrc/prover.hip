@@ -623,7 +623,7 @@ void Algorithm::resident_reserve(size_t B) {
         // quotient walk ends and the transforms of ITS batch start late: AES-256 218.5 ms per step with the copy stream low, 232.2 high.
         // A short one (ChaCha20: 163 levels) finishes anyway and only delays the transforms, which are the critical chain there:
         // 88.1 ms high, 88.9 low.  ZKPROVE_COPY_PRIO=hi|lo overrides.
-        static const int copy_prio = [] { const char *e = getenv("ZKPROVE_COPY_PRIO"); return !e ? -1 : !strcmp(e, "hi") ? 1 : 0; }();
+        static const int copy_prio = [] { const char *e = ZK_AB_ENV("ZKPROVE_COPY_PRIO"); return !e ? -1 : !strcmp(e, "hi") ? 1 : 0; }();
         const bool copy_hi = copy_prio < 0 ? prog.levels.size() <= 256 : copy_prio == 1;
         ZK_HIP(hipStreamCreateWithPriority(&res->copy_stream, hipStreamNonBlocking, copy_hi ? prio_hi : prio_lo));
         for (auto &e : res->ev) ZK_HIP(hipEventCreate(&e));
@@ -663,7 +663,7 @@ void Algorithm::resident_reserve_buffers(size_t B) {
         if (has_commit) acc(pk.ped.n, pk.ped.c, pk.ped.W);
         R.ms.reserve(B, max_entries, max_nb, max_part);
         R.ms.reserve_compact(B, std::max({pk.A.n, pk.B1.n, pk.K.n, pk.B2.n, has_commit ? pk.ped.n : (size_t)1}));
-        static const bool g2_side_on = [] { const char *e = getenv("ZKPROVE_G2_SIDE"); return e && e[0] == '1'; }();
+        static const bool g2_side_on = [] { const char *e = ZK_AB_ENV("ZKPROVE_G2_SIDE"); return e && e[0] == '1'; }();
         if (g2_side_on && B > SIDE_G2_MAX_B && split_world == 1) {          // opt-in: the G2 MSM of large batches beside the G1 MSMs (enqueue_main)
             R.ms_b2.reserve(B, pk.B2.n * (size_t)pk.B2.W, (size_t)1 << (pk.B2.c - 1), msm_part_stride(pk.B2.n, pk.B2.c));
             R.ms_b2.reserve_compact(B, pk.B2.n);
@@ -795,7 +795,7 @@ void Algorithm::enqueue_solve(SolveSet &S, MsmScratch &commit_scratch, hipStream
 // stands on the critical path between the wire MSMs and the walk; the sorted list is double-buffered (slot = batch
 // parity).  ZKPROVE_SORT_AHEAD=0 keeps everything in enqueue_main.
 bool Algorithm::ahead_eligible() const {
-    static const bool on = [] { const char *e = getenv("ZKPROVE_SORT_AHEAD"); return !(e && e[0] == '0'); }();
+    static const bool on = [] { const char *e = ZK_AB_ENV("ZKPROVE_SORT_AHEAD"); return !(e && e[0] == '0'); }();
     const Resident &R = *res;
     const size_t max_entries = pk.Z.n * (size_t)pk.Z.W, nb = (size_t)1 << (pk.Z.c - 1);
     if (!(on && R.B > SIDE_G2_MAX_B && split_world == 1)) return false;
@@ -810,7 +810,7 @@ bool Algorithm::ahead_eligible() const {
 // every wave slot for its whole duration, the solve stage ended up alone on the device between the walk and the transforms:
 // 10.6 ms of 96 per ChaCha20 step, 28 of 239 for AES-256 -- scripts/debug/timeline_step.py.)  ZKPROVE_NTT_STREAM=solve: the old order.
 hipStream_t Algorithm::side_chain_stream(hipStream_t solve_stream, SolveSet &S) {
-    static const bool on_solve = [] { const char *e = getenv("ZKPROVE_NTT_STREAM"); return e && !strcmp(e, "solve"); }();
+    static const bool on_solve = [] { const char *e = ZK_AB_ENV("ZKPROVE_NTT_STREAM"); return e && !strcmp(e, "solve"); }();
     if (on_solve) return solve_stream;
     ZK_HIP(hipStreamWaitEvent(res->copy_stream, S.solved, 0));
     return res->copy_stream;
@@ -861,7 +861,7 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm,
         // four folds): it CAN run on the copy stream with scratch of its own, beside the G1 chain of the main stream.
         // (Measured, same box: AES-256 4 113 proofs/s with it, 4 199 without -- the step is bound by VALU work, not by the main stream's
         // length, and the extra stream only adds contention.  Kept as an opt-in: ZKPROVE_G2_SIDE=1.)
-        static const bool g2_side = [] { const char *e = getenv("ZKPROVE_G2_SIDE"); return e && e[0] == '1'; }();
+        static const bool g2_side = [] { const char *e = ZK_AB_ENV("ZKPROVE_G2_SIDE"); return e && e[0] == '1'; }();
         const bool b2_side = g2_side && R.ms_b2.entries.n != 0;
         R.last_g2_side = b2_side;
         hipStream_t g2s = b2_side ? R.copy_stream : st;
@@ -880,7 +880,7 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm,
         if (S.comb) {
             // the walk here; its fold (a latency-bound chain of doublings per proof) on the tail stream, in front of the tail's last
             // stage, which is its only reader -- the main stream goes straight on to the next batch's MSMs
-            static const bool fold_on_tail = [] { const char *e = getenv("ZKPROVE_COMB_FOLD_TAIL"); return !(e && e[0] == '0'); }();
+            static const bool fold_on_tail = [] { const char *e = ZK_AB_ENV("ZKPROVE_COMB_FOLD_TAIL"); return !(e && e[0] == '0'); }();
             comb_walk(pk.Zcomb, R.comb.pat[S.zslot].p, B, R.comb, st, &R.ev[8]);
             if (fold_on_tail) {
                 ZK_HIP(hipEventRecord(S.zdone, st));

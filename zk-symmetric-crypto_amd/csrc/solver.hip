@@ -868,8 +868,8 @@ void solver_run_levels(const SolverProgram &p, SolverBuffers &buf, size_t first_
         const SolverLevel &lv = p.levels[l];
         if (!lv.count) continue;
         const uint32_t packed_rows = lv.wide + (lv.count - lv.wide + 3) / 4;
-        static const bool pack = [] { const char *e = getenv("ZKPROVE_SOLVER_PACK"); return !(e && e[0] == '0'); }();
-        static const int occ_env = [] { const char *e = getenv("ZKPROVE_SOLVER_OCC"); return e ? atoi(e) : 0; }();
+        static const bool pack = [] { const char *e = ZK_AB_ENV("ZKPROVE_SOLVER_PACK"); return !(e && e[0] == '0'); }();
+        static const int occ_env = [] { const char *e = ZK_AB_ENV("ZKPROVE_SOLVER_OCC"); return e ? atoi(e) : 0; }();
         const bool four = occ_env ? occ_env >= 4 : p.levels.size() <= 256;
         if (pack && buf.B > 16 && packed_rows <= 65535) {
             if (four) hipLaunchKernelGGL((k_solve_level<64, 4, 4>), dim3(ceil_div(buf.B, 64), packed_rows), dim3(64, 4), 0, s, cx, p.instr_off.p, p.level_instr.p + lv.first, lv.count, lv.wide);
