@@ -10,7 +10,7 @@
 
 // A/B switches of past scheduling / tiling experiments (ZKPROVE_SORT_AHEAD, ZKPROVE_NTT_STREAM, ZKPROVE_COPY_PRIO, ZKPROVE_SOLVER_PACK,
 // ZKPROVE_SOLVER_OCC, ZKPROVE_SEG_THREADS, ZKPROVE_G2_SIDE, ZKPROVE_NTT_PIPE, ZKPROVE_COMB_Q, ZKPROVE_COMB_PAT_REG, ZKPROVE_COMB_FOLD_TAIL,
-// ZKPROVE_MSM_PIECE) are read by the experiments build only; the product library runs the measured winner and keeps the operational
+// ZKPROVE_MSM_PIECE, ZKPROVE_SOLVER_RUNS, ZKPROVE_SOLVER_RUN_WAVES) are read by the experiments build only; the product library runs the measured winner and keeps the operational
 // knobs (ZKPROVE_COMB, ZKPROVE_COMB_K, ZKPROVE_COMB_MIN_BATCH, ZKPROVE_WCOMB_K, ZKPROVE_PIPE_DEPTH, ZKPROVE_DEVICES, ZKPROVE_VK_DIR,
 // ZKPROVE_MEMLOG, ZKPROVE_TIMELINE, ZKPROVE_ALLOW_UNPINNED_PK).
 #ifdef ZK_EXPERIMENTS

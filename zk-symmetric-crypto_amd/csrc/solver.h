@@ -19,6 +19,7 @@ struct SolverLevel {
     uint32_t first = 0, count = 0;   // range in level_instr
     uint32_t wide = 0;               // the first `wide` of them need a whole workgroup (k_solve_level); the rest are packed four to one
     bool has_commit = false;         // a BSB22 hint sits in this level: commitment must be ready before launch
+    bool narrow = false;             // at most 16 instructions, no countHint, no commitment: runs of such levels are one launch (k_solve_narrow_run)
     uint32_t div_first = 0, div_count = 0;   // deferred divisions of this level (records in div_list)
 };
 
@@ -28,7 +29,7 @@ struct SolverProgram {
     int log_domain = 0;
     std::vector<SolverLevel> levels;
     DevBuf<uint32_t> prog, instr_off, level_instr;
-    DevBuf<uint32_t> level_desc;                    // (first, count, wide) per level: what k_solve_persistent reads on the device
+    DevBuf<uint32_t> level_desc;                    // (first, count, wide, div_first, div_count) per level: what k_solve_narrow_run reads on the device
     DevBuf<Fr> coeffs, coeff_inv, lookup_tables, count_tables;   // lookup_tables: [table][256]
     DevBuf<uint32_t> div_list;                      // (constraint, loc, wire, coeff) x deferred divisions, grouped by level
     size_t n_count_rows = 0, n_count_slots = 0;     // countHint scratch sizing: [slot][row][B]

@@ -21,6 +21,8 @@ namespace zk {
 
 // linear expressions of at least this many terms are evaluated by all slices of a workgroup (eval_terms_coop)
 static constexpr int COOP_MIN_TERMS = 16;
+// levels of at most this many instructions are "narrow": runs of them are walked by one launch (k_solve_narrow_run)
+static constexpr uint32_t NARROW_MAX = 16;
 
 // ------------------------------------------------------------------------------------- build
 namespace {
@@ -283,6 +285,9 @@ void SolverProgram::build(const R1cs &cs, hipStream_t s) {
             }
         }
         lv.div_count = (uint32_t)(defer.size() / 4) - lv.div_first;
+        lv.narrow = lv.count <= NARROW_MAX && !lv.has_commit;
+        for (uint32_t i : ordered)
+            if (prg[off[i]] == OP_COUNT) lv.narrow = false;      // a countHint wants the whole device
         levels.push_back(lv);
     }
     prog.upload(prg.data(), prg.size(), s);
@@ -291,7 +296,7 @@ void SolverProgram::build(const R1cs &cs, hipStream_t s) {
     {
         std::vector<uint32_t> desc;
         size_t max_counts = 0;
-        for (auto &lv : levels) desc.insert(desc.end(), {lv.first, lv.count, lv.wide});
+        for (auto &lv : levels) desc.insert(desc.end(), {lv.first, lv.count, lv.wide, lv.div_first, lv.div_count});
         (void)max_counts;
         level_desc.upload(desc.data(), desc.size(), s);
     }
@@ -643,7 +648,7 @@ __global__ __launch_bounds__(NT) void k_solve_persistent(SolveCtx cx, const uint
     const int tid = threadIdx.x, grp = tid / G, gl = tid % G;
     const size_t b = blockIdx.x, B = cx.B;
     for (uint32_t l = l0; l < l1; l++) {
-        const uint32_t first = level_desc[3 * l], count = level_desc[3 * l + 1], wide = level_desc[3 * l + 2];
+        const uint32_t first = level_desc[5 * l], count = level_desc[5 * l + 1], wide = level_desc[5 * l + 2];
         const uint32_t *li = level_instr + first;
         if (tid == 0) n_counts = 0;
         if (wide) __syncthreads();
@@ -726,11 +731,8 @@ __global__ __launch_bounds__(NT) void k_solve_persistent(SolveCtx cx, const uint
 // 2 for the batches of single Prove() calls, where a thread's 16 members are a sequential chain on an otherwise idle device
 // (AES-256, one proof: the 11 division launches of a call 1.5 ms -> 0.6 ms)
 template <int DIV_GROUP>
-__global__ __launch_bounds__(256) void k_solve_divisions(SolveCtx cx, const uint32_t *__restrict__ recs, uint32_t count) {
+__device__ __forceinline__ void solve_division_group(const SolveCtx &cx, const uint32_t *__restrict__ recs, uint32_t count, uint32_t g0, size_t b) {
     const size_t B = cx.B;
-    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    const uint32_t g0 = blockIdx.y * DIV_GROUP;
     const uint32_t g1 = g0 + DIV_GROUP < count ? g0 + DIV_GROUP : count;
     Fr pref[DIV_GROUP];
     Fr acc = Fr::one();
@@ -763,6 +765,46 @@ __global__ __launch_bounds__(256) void k_solve_divisions(SolveCtx cx, const uint
             if (sc == 3) x = x.neg();
             else if (sc != 1) x = x * cx.coeff_inv[sc];
             cx.wires[(size_t)sw * B + b] = x;
+        }
+    }
+}
+template <int DIV_GROUP>
+__global__ __launch_bounds__(256) void k_solve_divisions(SolveCtx cx, const uint32_t *__restrict__ recs, uint32_t count) {
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= cx.B) return;
+    solve_division_group<DIV_GROUP>(cx, recs, count, blockIdx.y * DIV_GROUP, b);
+}
+
+// A RUN of consecutive narrow levels (at most NARROW_MAX instructions each, no countHint, no commitment) in ONE launch.  The AES
+// programs end in such a run: 321 of the 457 levels of aes-256 hold 1-16 instructions (the running sums of the log-derivative
+// arguments), i.e. 321 dependent launches of a handful of workgroups each -- 2.3 ms of a single Prove() call, and the long tail that
+// made the solve stage of a 1 024-batch 28 ms.  Proofs are independent, so a workgroup that owns a tile of instances can walk all
+// levels of the run by itself with __syncthreads() between them; unlike the persistent-solver experiment above the lanes stay the
+// INSTANCES (program words are scalar loads, every branch on them is uniform): same instruction code, same division code, same
+// results.  grid = tiles of 64 instances, block = (64 instances, SL wavefronts): every wavefront takes one instruction of the level
+// (SL = 16: a narrow level is ONE round, also for a single proof, where 15 more workgroups used to run beside the first).
+template <int LX, int SL>
+__global__ __launch_bounds__(LX * SL) void k_solve_narrow_run(SolveCtx cx, const uint32_t *__restrict__ instr_off, const uint32_t *__restrict__ level_instr,
+                                                        const uint32_t *__restrict__ level_desc, const uint32_t *__restrict__ div_list, uint32_t l0, uint32_t l1) {
+    static_assert(LX == 64, "a wavefront per slice");
+    __shared__ Fr red[SL * LX];
+    const size_t b_raw = (size_t)blockIdx.x * LX + threadIdx.x;
+    const bool live = b_raw < cx.B;
+    const size_t b = live ? b_raw : cx.B - 1;
+    const uint32_t slice = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    for (uint32_t l = l0; l < l1; l++) {
+        const uint32_t first = level_desc[5 * l], count = level_desc[5 * l + 1], wide = level_desc[5 * l + 2], div_first = level_desc[5 * l + 3],
+                       div_count = level_desc[5 * l + 4];
+        const uint32_t *li = level_instr + first;
+        // long expressions: the slices share them, one instruction at a time (barriers inside: every thread takes part)
+        for (uint32_t i = 0; i < wide; i++) solve_instruction<LX, SL, true>(cx, instr_off, li[i], b, live, threadIdx.y == 0 && live, red);
+        for (uint32_t i = wide + slice; i < count; i += SL) solve_instruction<LX, SL, false>(cx, instr_off, li[i], b, live, live, red);
+        __syncthreads();
+        if (div_count) {
+            constexpr int G = 2;                               // at most 16 divisions per level: a wavefront per pair
+            for (uint32_t g = threadIdx.y; g * G < div_count; g += SL)
+                if (live) solve_division_group<G>(cx, div_list + 4 * (size_t)div_first, div_count, g * G, b);
+            __syncthreads();
         }
     }
 }
@@ -864,12 +906,29 @@ void solver_run_levels(const SolverProgram &p, SolverBuffers &buf, size_t first_
         return;
     }
 #endif
+    static const bool pack = [] { const char *e = ZK_AB_ENV("ZKPROVE_SOLVER_PACK"); return !(e && e[0] == '0'); }();
+    static const int occ_env = [] { const char *e = ZK_AB_ENV("ZKPROVE_SOLVER_OCC"); return e ? atoi(e) : 0; }();
+    static const bool fuse_runs = [] { const char *e = ZK_AB_ENV("ZKPROVE_SOLVER_RUNS"); return !(e && e[0] == '0'); }();
     for (size_t l = first_level; l < last_level && l < p.levels.size(); l++) {
         const SolverLevel &lv = p.levels[l];
         if (!lv.count) continue;
+        if (fuse_runs && lv.narrow) {
+            // a run of narrow levels: one launch (a single narrow level takes the ordinary launch)
+            size_t e = l;
+            while (e < last_level && e < p.levels.size() && p.levels[e].narrow) e++;
+            if (e - l >= 2) {
+                static const int sl_env = [] { const char *e2 = ZK_AB_ENV("ZKPROVE_SOLVER_RUN_WAVES"); return e2 ? atoi(e2) : 16; }();
+                if (sl_env == 4)
+                    hipLaunchKernelGGL((k_solve_narrow_run<64, 4>), dim3(ceil_div(buf.B, 64)), dim3(64, 4), 0, s, cx, p.instr_off.p, p.level_instr.p, p.level_desc.p, p.div_list.p,
+                                       (uint32_t)l, (uint32_t)e);
+                else
+                    hipLaunchKernelGGL((k_solve_narrow_run<64, 16>), dim3(ceil_div(buf.B, 64)), dim3(64, 16), 0, s, cx, p.instr_off.p, p.level_instr.p, p.level_desc.p, p.div_list.p,
+                                       (uint32_t)l, (uint32_t)e);
+                l = e - 1;
+                continue;
+            }
+        }
         const uint32_t packed_rows = lv.wide + (lv.count - lv.wide + 3) / 4;
-        static const bool pack = [] { const char *e = ZK_AB_ENV("ZKPROVE_SOLVER_PACK"); return !(e && e[0] == '0'); }();
-        static const int occ_env = [] { const char *e = ZK_AB_ENV("ZKPROVE_SOLVER_OCC"); return e ? atoi(e) : 0; }();
         const bool four = occ_env ? occ_env >= 4 : p.levels.size() <= 256;
         if (pack && buf.B > 16 && packed_rows <= 65535) {
             if (four) hipLaunchKernelGGL((k_solve_level<64, 4, 4>), dim3(ceil_div(buf.B, 64), packed_rows), dim3(64, 4), 0, s, cx, p.instr_off.p, p.level_instr.p + lv.first, lv.count, lv.wide);
