@@ -6,6 +6,6 @@ for alg in 0 2; do
   rocprofv3 --kernel-trace --output-format csv -d $O -o t -- python3 scripts/debug/b1_trace.py $alg > $O/out.txt 2> $O/log.txt
   cat $O/out.txt | grep single
   F=$(find $O -name "*kernel_trace.csv" | head -1)
-  python3 scripts/debug/timeline_call.py "$F" 0.03 $( [ $alg = 0 ] && echo 7 || echo 19 ) > $O/timeline.txt
+  python3 scripts/debug/timeline_call.py "$F" 0.03 $( [ $alg = 0 ] && echo 7 || echo 40 ) > $O/timeline.txt
   find $O -name "*kernel_trace.csv" -delete; find $O -name "*.db" -delete
 done

@@ -23,7 +23,7 @@ namespace glv {
 // a1 = b2 = 9931322734385697763, -b1 = 147946756881789319000765030803803410728, a2 = 147946756881789319010696353538189108491
 // G1 = floor(b2 2^320 / r), G2 = floor(-b1 2^320 / r)
 // out[0 .. na+nb) = a * b (little-endian 32-bit words)
-ZK_HD inline void mul_words(const uint32_t *a, int na, const uint32_t *b, int nb, uint32_t *out) {
+ZK_HD void mul_words(const uint32_t *a, int na, const uint32_t *b, int nb, uint32_t *out) {
     for (int i = 0; i < na + nb; i++) out[i] = 0;
     for (int i = 0; i < na; i++) {
         uint64_t carry = 0;
@@ -36,7 +36,7 @@ ZK_HD inline void mul_words(const uint32_t *a, int na, const uint32_t *b, int nb
     }
 }
 // x -= y over n words (two's complement wrap-around)
-ZK_HD inline void sub_words(uint32_t *x, const uint32_t *y, int n) {
+ZK_HD void sub_words(uint32_t *x, const uint32_t *y, int n) {
     uint64_t borrow = 0;
     for (int i = 0; i < n; i++) {
         const uint64_t t = (uint64_t)x[i] - y[i] - borrow;
@@ -45,7 +45,7 @@ ZK_HD inline void sub_words(uint32_t *x, const uint32_t *y, int n) {
     }
 }
 // |x| of an n-word two's complement value; returns its sign
-ZK_HD inline bool abs_words(uint32_t *x, int n) {
+ZK_HD bool abs_words(uint32_t *x, int n) {
     const bool neg = (x[n - 1] >> 31) != 0;
     if (neg) {
         uint64_t carry = 1;
@@ -58,7 +58,7 @@ ZK_HD inline bool abs_words(uint32_t *x, int n) {
     return neg;
 }
 // k (8 words, any value < 2^256) -> |k1|, |k2| (4 words each) and their signs; false if a part does not fit 127 bits (cannot happen)
-ZK_HD inline bool decompose(const uint32_t *k, uint32_t *k1, bool &neg1, uint32_t *k2, bool &neg2) {
+ZK_HD bool decompose(const uint32_t *k, uint32_t *k1, bool &neg1, uint32_t *k2, bool &neg2) {
     const uint32_t G1[5] = {0x773a6ef2u, 0x6eb9c714u, 0xc7e0b3d7u, 0xd91d232eu, 0x2u};
     const uint32_t G2[7] = {0x5eaa26d9u, 0xa5e38cfbu, 0x391eb18du, 0x7a7bd9d4u, 0xa773d2cfu, 0x4ccef014u, 0x2u};
     const uint32_t A1[2] = {0x94d213e3u, 0x89d32568u};                                  // = b2
@@ -99,7 +99,7 @@ ZK_HD inline bool decompose(const uint32_t *k, uint32_t *k1, bool &neg1, uint32_
 }  // namespace glv
 
 // k * p for k < 2^256 (8 LE words): same point as scalar_mul(p, k, 256)
-ZK_HD inline XYZZ<Fp> scalar_mul_glv(const Affine<Fp> &p, const uint32_t *k) {
+ZK_HD XYZZ<Fp> scalar_mul_glv(const Affine<Fp> &p, const uint32_t *k) {
     if (p.is_inf()) return XYZZ<Fp>::inf();
     uint32_t k1[4], k2[4];
     bool n1, n2;

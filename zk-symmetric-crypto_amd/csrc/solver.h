@@ -32,6 +32,9 @@ struct SolverProgram {
     DevBuf<uint32_t> level_desc;                    // (first, count, wide, div_first, div_count) per level: what k_solve_narrow_run reads on the device
     DevBuf<Fr> coeffs, coeff_inv, lookup_tables, count_tables;   // lookup_tables: [table][256]
     DevBuf<uint32_t> div_list;                      // (constraint, loc, wire, coeff) x deferred divisions, grouped by level
+    // "lane program" of the small-batch kernel (k_solve_lanes; see there): per level a list of wavefront tasks -- 64 instructions of
+    // ONE shape with their wire / constraint numbers as structure-of-arrays columns, or one long instruction for the lanes to share
+    DevBuf<uint32_t> lp_shapes, lp_tasks, lp_soa, lp_level;
     size_t n_count_rows = 0, n_count_slots = 0;     // countHint scratch sizing: [slot][row][B]
     bool has_commit = false;
     uint32_t commit_wire = 0;

@@ -15,6 +15,8 @@
 #include "solver.h"
 #include <string.h>
 #include <algorithm>
+#include <array>
+#include <map>
 #include <string>
 
 namespace zk {
@@ -23,6 +25,10 @@ namespace zk {
 static constexpr int COOP_MIN_TERMS = 16;
 // levels of at most this many instructions are "narrow": runs of them are walked by one launch (k_solve_narrow_run)
 static constexpr uint32_t NARROW_MAX = 16;
+// lane program (k_solve_lanes): instructions with a linear expression of at least this many terms are shared by the lanes of a wavefront
+static constexpr uint32_t LP_WIDE_TERMS = 32;
+enum : uint32_t { LP_TASK_LANES = 0, LP_TASK_WIDE = 1, LP_TASK_COUNT = 2 };
+static constexpr size_t LP_MAX_B = 4;
 
 // ------------------------------------------------------------------------------------- build
 namespace {
@@ -299,6 +305,89 @@ void SolverProgram::build(const R1cs &cs, hipStream_t s) {
         for (auto &lv : levels) desc.insert(desc.end(), {lv.first, lv.count, lv.wide, lv.div_first, lv.div_count});
         (void)max_counts;
         level_desc.upload(desc.data(), desc.size(), s);
+    }
+    // ---- lane program (k_solve_lanes): the same instructions, regrouped per level by SHAPE -- everything of an instruction but its
+    // wire / constraint numbers.  A shape is stored once (opcode, term counts, (coefficient id, is-constant) per term); the
+    // instructions of one shape in one level become columns of numbers (field f of instruction j at base + f * count + j), so that
+    // 64 lanes read 64 instructions' numbers with one coalesced load per field and run the shape's code with uniform control flow.
+    // Every term owns a field (a constant term's field names wire 0, loaded and ignored): field index = position in the term list.
+    // Instructions with a linear expression of >= LP_WIDE_TERMS terms stay in the encoding above and are shared by the lanes of a
+    // wavefront (a task of their own); countHints are worked on by the whole workgroup.
+    {
+        std::vector<uint32_t> shapes, tasks, soa, lvl;
+        std::map<std::vector<uint32_t>, uint32_t> shape_at;
+        for (const auto &lv : levels) {
+            std::vector<std::array<uint32_t, 4>> wide_t, count_t, lane_t;
+            std::map<uint32_t, std::vector<std::vector<uint32_t>>> groups;      // shape offset -> field rows
+            std::vector<uint32_t> group_order;
+            for (uint32_t q = 0; q < lv.count; q++) {
+                const uint32_t i = li[lv.first + q];
+                const uint32_t *rec = prg.data() + off[i];
+                const uint32_t op = rec[0];
+                std::vector<uint32_t> shp, fld;
+                bool is_wide = false;
+                auto terms = [&](const uint32_t *t, uint32_t n) {
+                    if (n >= LP_WIDE_TERMS) is_wide = true;
+                    for (uint32_t k = 0; k < n; k++) {
+                        const bool c = t[2 * k + 1] == WIRE_CONST;
+                        shp.push_back(t[2 * k]); shp.push_back(c ? 1u : 0u);
+                        fld.push_back(c ? 0u : t[2 * k + 1]);
+                    }
+                };
+                if (op == OP_COUNT) { count_t.push_back({LP_TASK_COUNT, off[i], i, 0u}); continue; }
+                if (op == OP_R1C) {
+                    shp = {OP_R1C, rec[2], rec[3], rec[4], rec[5], rec[7]};
+                    fld = {rec[1], rec[6]};
+                    const uint32_t *t = rec + 8;
+                    terms(t, rec[2]); t += 2 * rec[2];
+                    terms(t, rec[3]); t += 2 * rec[3];
+                    terms(t, rec[4]);
+                } else if (op == OP_NBITS) {
+                    shp = {OP_NBITS, rec[1], rec[3]};
+                    fld = {rec[2]};
+                    terms(rec + 4, rec[3]);
+                } else if (op == OP_LOOKUP) {
+                    shp = {OP_LOOKUP, rec[1], rec[2], rec[4]};
+                    fld = {rec[3], i};                               // the instruction number: detail of a range error
+                    const uint32_t *t = rec + 5;
+                    for (uint32_t k = 0; k < rec[2]; k++) {
+                        const uint32_t n = *t++;
+                        shp.push_back(n);
+                        terms(t, n);
+                        t += 2 * n;
+                    }
+                } else {       // OP_RANDOMIZE, OP_BSB22
+                    shp = {op};
+                    fld = {rec[1]};
+                }
+                if (is_wide) { wide_t.push_back({LP_TASK_WIDE, off[i], i, 0u}); continue; }
+                auto it = shape_at.find(shp);
+                if (it == shape_at.end()) {
+                    it = shape_at.emplace(shp, (uint32_t)shapes.size()).first;
+                    shapes.insert(shapes.end(), shp.begin(), shp.end());
+                }
+                if (!groups.count(it->second)) group_order.push_back(it->second);
+                groups[it->second].push_back(std::move(fld));
+            }
+            for (uint32_t so : group_order) {
+                const auto &rows = groups[so];
+                const uint32_t gc = (uint32_t)rows.size(), nf = (uint32_t)rows[0].size();
+                const uint32_t base = (uint32_t)soa.size();
+                for (uint32_t f = 0; f < nf; f++)
+                    for (uint32_t j = 0; j < gc; j++) soa.push_back(rows[j][f]);
+                for (uint32_t j0 = 0; j0 < gc; j0 += 64) lane_t.push_back({LP_TASK_LANES, so, base + j0, (gc - j0 < 64 ? gc - j0 : 64u) | (gc << 7)});
+            }
+            lvl.insert(lvl.end(), {(uint32_t)(tasks.size() / 4), (uint32_t)(wide_t.size() + lane_t.size()), (uint32_t)count_t.size()});
+            for (const auto *v : {&wide_t, &lane_t, &count_t})          // long instructions first, countHints after the wavefront tasks
+                for (const auto &t : *v) tasks.insert(tasks.end(), t.begin(), t.end());
+        }
+        if (shapes.empty()) shapes.push_back(0);
+        if (tasks.empty()) tasks.push_back(0);
+        if (soa.empty()) soa.push_back(0);
+        lp_shapes.upload(shapes.data(), shapes.size(), s);
+        lp_tasks.upload(tasks.data(), tasks.size(), s);
+        lp_soa.upload(soa.data(), soa.size(), s);
+        lp_level.upload(lvl.data(), lvl.size(), s);
     }
     coeffs.alloc(cs.coeffs.size());
     ZK_HIP(hipMemcpyAsync(coeffs.p, cs.coeffs.data(), cs.coeffs.size() * 32, hipMemcpyHostToDevice, s));
@@ -809,6 +898,171 @@ __global__ __launch_bounds__(LX * SL) void k_solve_narrow_run(SolveCtx cx, const
     }
 }
 
+// ---------------------------------------------------------------------------------------- small batches: the lane program
+// A single Prove() call -- what the reference's own harness and the unchanged JS operator issue (gnark/libraries/core_test.go:121-150) --
+// is latency: one launch per level costs 163 (ChaCha20) / 137 (AES-256, after the narrow runs) dependent launches of ~15 us, 2.5 / 5 ms
+// for one proof, and inside each the chain  instruction number -> program offset -> header -> terms -> wires  of dependent loads.
+// Here ONE workgroup owns one instance and walks all levels with __syncthreads() between them (proofs are independent: no device-wide
+// barrier), and the lanes are INSTRUCTIONS OF ONE SHAPE: SolverProgram::build regroups every level by shape and stores the numbers of
+// the instructions of a shape as columns, so a wavefront loads 64 instructions' wire numbers with one coalesced load per term, then
+// all their wire values, and runs the shape's arithmetic with control flow that is uniform across the wavefront (the shape words are
+// scalar loads).  Two dependent memory round trips per 8 terms instead of one per program word.  (The first persistent kernel --
+// k_solve_persistent, experiments build -- had the instructions on the lanes too, but each lane interpreted its own program record:
+// vector loads of every program word, every branch of the interpreter taken by some lane; it lost to the level launches.)
+// Long expressions (>= LP_WIDE_TERMS terms: the 96-term add32 / FromBinary rows) are a task of their own, the wavefront's lanes
+// taking the TERMS and a butterfly of wave shuffles summing them; countHints are worked on by the whole workgroup; an unknown in L or R
+// is divided out after the level's tasks, a lane per division.  Same arithmetic and case analysis as k_solve_level + k_solve_divisions, and field addition is exact and
+// commutative, so wires and a / b / c rows are the same bits.
+template <int CH>
+__device__ __forceinline__ void lp_eval(const SolveCtx &cx, const uint32_t *__restrict__ tw, uint32_t T, uint32_t nL, uint32_t nLR, const uint32_t *__restrict__ f,
+                                        uint32_t gc, size_t b, Fr &vL, Fr &vR, Fr &vO) {
+    vL = Fr::zero(); vR = Fr::zero(); vO = Fr::zero();
+    for (uint32_t t0 = 0; t0 < T; t0 += CH) {
+        uint32_t idx[CH];
+        Fr v[CH];
+#pragma unroll
+        for (int q = 0; q < CH; q++) idx[q] = t0 + q < T ? f[(size_t)(t0 + q) * gc] : 0u;
+#pragma unroll
+        for (int q = 0; q < CH; q++) v[q] = cx.wires[(size_t)idx[q] * cx.B + b];
+#pragma unroll
+        for (int q = 0; q < CH; q++) {
+            const uint32_t t = t0 + q;
+            if (t >= T) break;
+            const Fr val = term_apply(cx, tw[2 * t], tw[2 * t + 1] ? WIRE_CONST : 0u, v[q]);
+            if (t < nL) vL = vL + val;
+            else if (t < nLR) vR = vR + val;
+            else vO = vO + val;
+        }
+    }
+}
+// sum over the wavefront of the terms t = lane, lane + 64, ... of a linear expression in the program encoding; every lane gets it
+__device__ __forceinline__ Fr lp_wave_sum(const SolveCtx &cx, const uint32_t *__restrict__ p, uint32_t n, size_t b, int lane) {
+    Fr acc = Fr::zero();
+    for (uint32_t t = lane; t < n; t += 64) acc = acc + term_val(cx, p[2 * t], p[2 * t + 1], b);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        Fr other;
+#pragma unroll
+        for (int i = 0; i < 8; i++) other.l[i] = __shfl_xor(acc.l[i], o);
+        acc = acc + other;
+    }
+    return acc;
+}
+template <int NT, int CH>
+__global__ __launch_bounds__(NT) void k_solve_lanes(SolveCtx cx, const uint32_t *__restrict__ shapes, const uint32_t *__restrict__ tasks, const uint32_t *__restrict__ soa,
+                                                   const uint32_t *__restrict__ lvl, const uint32_t *__restrict__ level_desc, const uint32_t *__restrict__ div_list,
+                                                   uint32_t l0, uint32_t l1) {
+    constexpr int NW = NT / 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t b = blockIdx.x, B = cx.B;
+    for (uint32_t l = l0; l < l1; l++) {
+        const uint32_t t_first = lvl[3 * l], n_tasks = lvl[3 * l + 1], n_count = lvl[3 * l + 2];
+        for (uint32_t t = wave; t < n_tasks; t += NW) {
+            const uint32_t *tk = tasks + 4 * (size_t)(t_first + t);
+            const uint32_t kind = tk[0], w1 = tk[1], w2 = tk[2], w3 = tk[3];
+            if (kind == LP_TASK_LANES) {
+                const uint32_t n = w3 & 127u, gc = w3 >> 7;
+                if ((uint32_t)lane >= n) continue;
+                const uint32_t *sh = shapes + w1, *f = soa + w2 + lane;
+                const uint32_t op = sh[0];
+                Fr vL, vR, vO;
+                if (op == OP_R1C) {
+                    const uint32_t nL = sh[1], nR = sh[2], nO = sh[3], loc = sh[4], sc = sh[5];
+                    const uint32_t cons = f[0], sw = f[gc];
+                    lp_eval<CH>(cx, sh + 6, nL + nR + nO, nL, nL + nR, f + 2 * (size_t)gc, gc, b, vL, vR, vO);
+                    finish_r1c<false>(cx, b, cons, loc, sw, sc, vL, vR, vO);
+                } else if (op == OP_NBITS) {
+                    const uint32_t nout = sh[1], T = sh[2], out0 = f[0];
+                    lp_eval<CH>(cx, sh + 3, T, T, T, f + gc, gc, b, vL, vR, vO);
+                    finish_nbits(cx, b, nout, out0, vL);
+                } else if (op == OP_LOOKUP) {
+                    const uint32_t tb = sh[1], nq = sh[2], nent = sh[3], w0 = f[0], instr = f[gc];
+                    const uint32_t *q = sh + 4, *ff = f + 2 * (size_t)gc;
+                    for (uint32_t k = 0; k < nq; k++) {
+                        const uint32_t T = q[0];
+                        lp_eval<CH>(cx, q + 1, T, T, T, ff, gc, b, vL, vR, vO);
+                        q += 1 + 2 * T;
+                        ff += (size_t)T * gc;
+                        uint32_t idx;
+                        if (!small_index(vL, nent, idx)) { report(cx, b, SERR_LOOKUP_RANGE, instr); idx = 0; }
+                        cx.wires[(size_t)(w0 + k) * B + b] = cx.tables[(size_t)tb * nent + idx];
+                    }
+                } else if (op == OP_RANDOMIZE) {
+                    cx.wires[(size_t)f[0] * B + b] = cx.randomize[b];
+                } else if (op == OP_BSB22) {
+                    cx.wires[(size_t)f[0] * B + b] = cx.challenge[b];
+                }
+            } else {       // LP_TASK_WIDE: one instruction, the lanes take its terms
+                const uint32_t *p = cx.prog + w1;
+                const uint32_t op = p[0];
+                if (op == OP_R1C) {
+                    const uint32_t cons = p[1], nL = p[2], nR = p[3], nO = p[4], loc = p[5], sw = p[6], sc = p[7];
+                    p += 8;
+                    const Fr vL = lp_wave_sum(cx, p, nL, b, lane); p += 2 * nL;
+                    const Fr vR = lp_wave_sum(cx, p, nR, b, lane); p += 2 * nR;
+                    const Fr vO = lp_wave_sum(cx, p, nO, b, lane);
+                    if (lane == 0) finish_r1c<false>(cx, b, cons, loc, sw, sc, vL, vR, vO);
+                } else if (op == OP_NBITS) {
+                    const uint32_t nout = p[1], out0 = p[2];
+                    const Fr v = lp_wave_sum(cx, p + 4, p[3], b, lane).from_mont();
+                    const Fr one = Fr::one(), zero = Fr::zero();
+                    for (uint32_t k = lane; k < nout; k += 64) {
+                        const bool bit = k < 256 && ((v.l[k >> 5] >> (k & 31)) & 1);
+                        cx.wires[(size_t)(out0 + k) * B + b] = bit ? one : zero;
+                    }
+                } else if (op == OP_LOOKUP) {
+                    const uint32_t tb = p[1], nq = p[2], w0 = p[3], nent = p[4];
+                    p += 5;
+                    for (uint32_t k = 0; k < nq; k++) {
+                        const uint32_t n = *p++;
+                        const Fr v = lp_wave_sum(cx, p, n, b, lane);
+                        p += 2 * n;
+                        if (lane == 0) {
+                            uint32_t idx;
+                            if (!small_index(v, nent, idx)) { report(cx, b, SERR_LOOKUP_RANGE, w2); idx = 0; }
+                            cx.wires[(size_t)(w0 + k) * B + b] = cx.tables[(size_t)tb * nent + idx];
+                        }
+                    }
+                }
+            }
+        }
+        // countHints of this level: the whole workgroup on each (same code as the slices of k_solve_level)
+        for (uint32_t c = 0; c < n_count; c++) {
+            const uint32_t *p = cx.prog + tasks[4 * (size_t)(t_first + n_tasks + c) + 1], instr = tasks[4 * (size_t)(t_first + n_tasks + c) + 2];
+            const uint32_t ntab = p[1], ncol = p[2], nq = p[3], out0 = p[4], slot = p[5], toff = p[6];
+            const uint32_t *row_start = p + 8 + p[7];
+            p += 8;
+            uint32_t *cnt = cx.count_scratch + (size_t)slot * cx.count_rows * B;
+            for (uint32_t r = tid; r < ntab; r += NT) cnt[(size_t)r * B + b] = 0;
+            __syncthreads();
+            const Fr *tab = cx.count_tables + toff;
+            for (uint32_t j = tid; j < nq; j += NT) {
+                const uint32_t *pq = p + row_start[j];
+                uint32_t row = 0;
+                bool ok = true;
+                for (uint32_t col = 0; col < ncol; col++) {
+                    const Fr qv = eval_linexp(cx, pq, b);
+                    if (col == 0) ok = small_index(qv, ntab, row);
+                    if (ok && tab[(size_t)row * ncol + col] != qv) ok = false;
+                }
+                if (ok) atomicAdd(&cnt[(size_t)row * B + b], 1u);
+                else report(cx, b, SERR_COUNT_QUERY, instr);
+            }
+            __syncthreads();
+            for (uint32_t r = tid; r < ntab; r += NT) cx.wires[(size_t)(out0 + r) * B + b] = Fr::from_u32(cnt[(size_t)r * B + b]);
+        }
+        // the level's divisions (an unknown in L or R; the instruction left its partial sums in the a / b / c rows): a lane each --
+        // up to 515 in a level of the AES programs, and an inversion is a long dependent chain whoever else waits for it
+        const uint32_t div_first = level_desc[5 * l + 3], div_count = level_desc[5 * l + 4];
+        if (div_count) {
+            __syncthreads();
+            for (uint32_t g = tid; g < div_count; g += NT) solve_division_group<1>(cx, div_list + 4 * (size_t)div_first, div_count, g, b);
+        }
+        __syncthreads();                                   // the level's wires are written: the next level may read them
+    }
+}
+
 __global__ __launch_bounds__(256) void k_assign_inputs(const uint32_t *__restrict__ in, Fr *__restrict__ wires, size_t n_inputs, size_t B) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (n_inputs + 1) * B) return;
@@ -906,6 +1160,22 @@ void solver_run_levels(const SolverProgram &p, SolverBuffers &buf, size_t first_
         return;
     }
 #endif
+    // batches of at most LP_MAX_B proofs (single Prove() calls): one workgroup per instance walks the levels by itself (k_solve_lanes)
+    static const size_t lanes_max_b = [] { const char *e = ZK_AB_ENV("ZKPROVE_SOLVER_LANES"); return e ? (size_t)atol(e) : LP_MAX_B; }();
+    // (the AES programs keep the level launches for now: their wide levels -- up to 100 wavefront tasks -- want the whole device, and
+    // the lane program measured 15.5 against 13.4 ms per call there; ZKPROVE_SOLVER_LANES_ALL=1 in the experiments build forces it)
+    static const bool lanes_all = [] { const char *e = ZK_AB_ENV("ZKPROVE_SOLVER_LANES_ALL"); return e && e[0] == '1'; }();
+    if (buf.B <= lanes_max_b && first_level < last_level && (lanes_all || p.levels.size() <= 256)) {
+        static const int nt_env = [] { const char *e = ZK_AB_ENV("ZKPROVE_SOLVER_LANES_NT"); return e ? atoi(e) : 1024; }();
+        if (nt_env == 512)
+            hipLaunchKernelGGL((k_solve_lanes<512, 8>), dim3((unsigned)buf.B), dim3(512), 0, s, cx, p.lp_shapes.p, p.lp_tasks.p, p.lp_soa.p, p.lp_level.p, p.level_desc.p,
+                               p.div_list.p, (uint32_t)first_level, (uint32_t)last_level);
+        else
+            hipLaunchKernelGGL((k_solve_lanes<1024, 4>), dim3((unsigned)buf.B), dim3(1024), 0, s, cx, p.lp_shapes.p, p.lp_tasks.p, p.lp_soa.p, p.lp_level.p, p.level_desc.p,
+                               p.div_list.p, (uint32_t)first_level, (uint32_t)last_level);
+        ZK_HIP(hipGetLastError());
+        return;
+    }
     static const bool pack = [] { const char *e = ZK_AB_ENV("ZKPROVE_SOLVER_PACK"); return !(e && e[0] == '0'); }();
     static const int occ_env = [] { const char *e = ZK_AB_ENV("ZKPROVE_SOLVER_OCC"); return e ? atoi(e) : 0; }();
     static const bool fuse_runs = [] { const char *e = ZK_AB_ENV("ZKPROVE_SOLVER_RUNS"); return !(e && e[0] == '0'); }();
