@@ -25,4 +25,27 @@ __device__ __forceinline__ XYZZ<F> fixed_mul(const Affine<F> *__restrict__ tab, 
     return acc;
 }
 
+// The same product by 16 lanes of one workgroup (small batches: the 32 dependent mixed additions above are latency of every Prove()
+// call): lane i takes windows i and i + 16, four rounds through LDS join the 16 partial sums.  Result valid in lane 0; every lane of
+// the workgroup must call (barriers).  Same group element as fixed_mul.
+template <class F>
+__device__ __forceinline__ XYZZ<F> fixed_mul_tree(const Affine<F> *__restrict__ tab, const uint32_t *k, int lane, XYZZ<F> *lds) {
+    XYZZ<F> acc = XYZZ<F>::inf();
+    if (lane < 16) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int w = lane + 16 * h;
+            const uint32_t d = (k[w >> 2] >> ((w & 3) * 8)) & 0xff;
+            if (d) acc.madd(tab[w * 255 + d - 1]);
+        }
+    }
+    for (int step = 8; step >= 1; step >>= 1) {
+        if (lane >= step && lane < 2 * step) lds[lane] = acc;
+        __syncthreads();
+        if (lane < step) acc.add(lds[lane + step]);
+        __syncthreads();
+    }
+    return acc;
+}
+
 }  // namespace zk

@@ -329,6 +329,45 @@ __global__ __launch_bounds__(64) void k_finalize_stage1(const G1XYZZ *__restrict
         t_out[b] = fixed_mul(dtab, kr.l);
     }
 }
+// Stage 1 for small batches: one 16-lane workgroup per (instance, task), the fixed-base product as a tree (fixedbase.cuh)
+__global__ __launch_bounds__(16) void k_finalize_stage1_small(const G1XYZZ *__restrict__ m_ar, const G1XYZZ *__restrict__ m_bs1, const G1Affine *__restrict__ misc,
+                                                              const G1Affine *__restrict__ dtab, const U256 *__restrict__ r, const U256 *__restrict__ s,
+                                                              G1Affine *__restrict__ ar_aff, G1Affine *__restrict__ bs1_aff, G1XYZZ *__restrict__ t_out, size_t B) {
+    __shared__ G1XYZZ lds[16];
+    const size_t b = blockIdx.x;
+    const int task = blockIdx.y, lane = threadIdx.x;
+    Fr rm, sm;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { rm.l[k] = r[b].l[k]; sm.l[k] = s[b].l[k]; }
+    Fr kk = task == 0 ? rm : sm;
+    if (task == 2) kk = (rm.to_mont() * sm.to_mont()).neg().from_mont();
+    const G1XYZZ f = fixed_mul_tree(dtab, kk.l, lane, lds);
+    if (lane != 0) return;
+    if (task == 2) { t_out[b] = f; return; }
+    G1XYZZ acc = task == 0 ? m_ar[b] : m_bs1[b];
+    acc.madd(misc[task]);
+    acc.add(f);
+    if (task == 0) ar_aff[b] = acc.to_affine();
+    else bs1_aff[b] = acc.to_affine();
+}
+// Bs for small batches (the tail of the G2 chain, the longest chain of a one-proof AES call)
+__global__ __launch_bounds__(16) void k_finalize_g2_small(const G2XYZZ *__restrict__ m_bs2, const G2Affine *__restrict__ misc, const G2Affine *__restrict__ dtab,
+                                                          const U256 *__restrict__ s, ProofPoints *__restrict__ out, size_t B) {
+    __shared__ G2XYZZ lds[16];
+    const size_t b = blockIdx.x;
+    const int lane = threadIdx.x;
+    uint32_t sl[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) sl[k] = s[b].l[k];
+    const G2XYZZ f = fixed_mul_tree(dtab, sl, lane, lds);
+    if (lane != 0) return;
+    G2XYZZ bs = m_bs2[b];
+    bs.madd(misc[0]);
+    bs.add(f);
+    const G2Affine a = bs.to_affine();
+    store_fp(out[b].bs[0], a.x.a0.from_mont()); store_fp(out[b].bs[1], a.x.a1.from_mont());
+    store_fp(out[b].bs[2], a.y.a0.from_mont()); store_fp(out[b].bs[3], a.y.a1.from_mont());
+}
 // Stage 2 (blockIdx.y = task): 0: U = s*Ar   1: V = r*Bs1   (variable base)
 __global__ __launch_bounds__(64) void k_finalize_stage2(const G1Affine *__restrict__ ar_aff, const G1Affine *__restrict__ bs1_aff, const U256 *__restrict__ r,
                                                         const U256 *__restrict__ s, G1XYZZ *__restrict__ u_out, G1XYZZ *__restrict__ v_out, size_t B) {
@@ -345,6 +384,86 @@ __global__ __launch_bounds__(64) void k_finalize_stage2(const G1Affine *__restri
 #pragma unroll
         for (int i = 0; i < 8; i++) k[i] = r[b].l[i];
         v_out[b] = scalar_mul_glv(bs1_aff[b], k);
+    }
+}
+// The same two multiplications for batches of at most 32 proofs (single Prove() calls: this chain IS the end of the call's critical
+// path), as a pipeline inside one workgroup per multiplication.  k P = k1 P + k2 phi(P) right to left: wavefront 0 runs the ONE chain
+// that cannot be shortened -- the doublings D_i = 2^i P, i < 128 -- and hands every D_i over through a ring in LDS; four more wavefronts
+// add the D_i whose bit is set (two per half-scalar, even and odd positions: an addition takes ~1.5 doublings and half the bits are
+// set, so each keeps up with the doubler), and three additions join the four partial sums with the endomorphism and the signs at the
+// end.  128 doublings + 2 additions on the critical path instead of 128 doublings + ~96 additions.  Lanes = instances (lockstep).
+// Same group element as scalar_mul_glv, hence the same proof bytes.
+template <int RING>
+__global__ __launch_bounds__(320) void k_finalize_stage2_pipe(const G1Affine *__restrict__ ar_aff, const G1Affine *__restrict__ bs1_aff, const U256 *__restrict__ r,
+                                                             const U256 *__restrict__ s, G1XYZZ *__restrict__ u_out, G1XYZZ *__restrict__ v_out, size_t B) {
+    static_assert(RING % 2 == 0, "even and odd positions keep their slots");
+    __shared__ G1XYZZ ring[RING][32];      // lanes 0..31 hold instances (64 KB of static LDS would not fit both arrays at 64)
+    __shared__ G1XYZZ part[4][32];
+    __shared__ volatile int produced, consumed[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t b_raw = (size_t)blockIdx.x * 32 + lane;
+    const bool live = lane < 32 && b_raw < B;
+    const size_t b = live ? b_raw : B - 1;
+    const int ll = lane & 31;
+    if (threadIdx.x < 4) consumed[threadIdx.x] = 0;
+    if (threadIdx.x == 4) produced = 0;
+    __syncthreads();
+    const G1Affine P = blockIdx.y == 0 ? ar_aff[b] : bs1_aff[b];
+    uint32_t k[8], k1[4], k2[4];
+#pragma unroll
+    for (int i = 0; i < 8; i++) k[i] = blockIdx.y == 0 ? s[b].l[i] : r[b].l[i];
+    bool n1, n2;
+    const bool split = glv::decompose(k, k1, n1, k2, n2);      // (always true; an instance it failed for takes the plain ladder below)
+    if (wave == 0) {
+        G1XYZZ D = G1XYZZ::from_affine(P);
+        for (int i = 0; i < 128; i++) {
+            if (i >= RING) {
+                const int a0 = i & 1;                          // the adders of this slot's parity
+                while (consumed[a0] < i - RING + 1 || consumed[2 + a0] < i - RING + 1) __builtin_amdgcn_s_sleep(1);
+            }
+            if (live) ring[i % RING][ll] = D;
+            __threadfence_block();
+            if (lane == 0) produced = i + 1;
+            D = D.dbl();
+        }
+    } else {
+        const int a = wave - 1, half = a >> 1, par = a & 1;    // consumed[] index: half * 2 + parity -> match the doubler's view
+        const int slot = par + 2 * half;
+        G1XYZZ acc = G1XYZZ::inf();
+        for (int i = par; i < 128; i += 2) {
+            while (produced <= i) __builtin_amdgcn_s_sleep(1);
+            const uint32_t bit = ((half ? k2[i >> 5] : k1[i >> 5]) >> (i & 31)) & 1u;
+            if (bit && live && split) {
+                const G1XYZZ D = ring[i % RING][ll];
+                acc.add(D);
+            }
+            __threadfence_block();
+            if (lane == 0) consumed[slot] = i + 1;
+        }
+        if (live) part[slot][ll] = acc;
+    }
+    __syncthreads();
+    // R1 = +-(even + odd of k1), R2 = +-phi(even + odd of k2)
+    if (wave < 2 && live) {
+        G1XYZZ t = part[2 * wave][ll];
+        t.add(part[2 * wave + 1][ll]);
+        if (wave == 1) {
+            Fp beta;
+            const uint32_t BETA[8] = {0x77fffffeu, 0x57634731u, 0xacdb5c4fu, 0xd4f263f1u, 0xa0d48bacu, 0x59e26bceu, 0x0u, 0x0u};
+#pragma unroll
+            for (int i = 0; i < 8; i++) beta.l[i] = BETA[i];
+            t.X = t.X * beta.to_mont();
+        }
+        if (wave == 0 ? n1 : n2) t = t.neg();
+        part[2 * wave][ll] = t;
+    }
+    __syncthreads();
+    if (wave == 0 && live) {
+        G1XYZZ t = part[0][ll];
+        t.add(part[2][ll]);
+        if (!split) t = scalar_mul(P, k, 256);
+        if (blockIdx.y == 0) u_out[b] = t;
+        else v_out[b] = t;
     }
 }
 // Stage 3: Krs = K + Z + T + U + V ; canonical outputs
@@ -388,6 +507,12 @@ __global__ void k_store_commit(const G1Affine *com, const G1Affine *pok, ProofPo
     }
 }
 
+
+static constexpr size_t TAIL_TREE_MAX_B = 8;      // batches up to this size: fixed-base products as 16-lane trees
+static void launch_finalize_g2(const G2XYZZ *m_bs2, const G2Affine *misc, const G2Affine *dtab, const U256 *s, ProofPoints *out, size_t B, hipStream_t st) {
+    if (B <= TAIL_TREE_MAX_B) hipLaunchKernelGGL(k_finalize_g2_small, dim3((unsigned)B), dim3(16), 0, st, m_bs2, misc, dtab, s, out, B);
+    else hipLaunchKernelGGL(k_finalize_g2, dim3(ceil_div(B, 64)), dim3(64), 0, st, m_bs2, misc, dtab, s, out, B);
+}
 
 // ------------------------------------------------------------------------- BSB22 challenge on the device
 // challenge = fr.Hash(commitment.Marshal(), "bsb22-commitment", 1)[0]  (gnark backend/groth16/bn254/prove.go; gnark-crypto
@@ -873,7 +998,7 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm,
         msm_batch(pk.B2, S.sb.wires.p, B, b2_side ? R.ms_b2 : R.ms, R.m_bs2.p, g2s);
         ZK_HIP(hipEventRecord(R.ev[6], g2s));
         ZK_HIP(hipStreamWaitEvent(tail, R.ev[6], 0));
-        hipLaunchKernelGGL(k_finalize_g2, dim3(ceil_div(B, 64)), dim3(64), 0, tail, R.m_bs2.p, pk.g2_misc.p, pk.delta2_tab.p, S.s.p, S.out.p, B);
+        launch_finalize_g2(R.m_bs2.p, pk.g2_misc.p, pk.delta2_tab.p, S.s.p, S.out.p, B, tail);
         msm_batch(pk.K, S.sb.wires.p, B, R.ms, R.m_k.p, st);
         ZK_HIP(hipStreamWaitEvent(st, S.sorted, 0));
         R.used_comb = S.comb;
@@ -911,7 +1036,7 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm,
             ZK_HIP(hipEventRecord(R.ev[5], g2s));
             msm_batch(pk.B2, S.sb.wires.p, B, R.ms_g2, R.m_bs2.p, g2s);
             if (split_world == 1)
-                hipLaunchKernelGGL(k_finalize_g2, dim3(ceil_div(B, 64)), dim3(64), 0, g2s, R.m_bs2.p, pk.g2_misc.p, pk.delta2_tab.p, S.s.p, S.out.p, B);
+                launch_finalize_g2(R.m_bs2.p, pk.g2_misc.p, pk.delta2_tab.p, S.s.p, S.out.p, B, g2s);
             ZK_HIP(hipEventRecord(R.ev[6], g2s));               // (the tail stream joins it below, behind its own chain)
             R.last_g2_side = true;                // phase times: msm_g1 = the main stream from its first MSM to the end (collect_times)
         }
@@ -967,7 +1092,7 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm,
         ZK_HIP(hipEventRecord(R.ev[6], st));
         ZK_HIP(hipStreamWaitEvent(tail, R.ev[6], 0));
         if (split_world == 1)
-            hipLaunchKernelGGL(k_finalize_g2, dim3(ceil_div(B, 64)), dim3(64), 0, tail, R.m_bs2.p, pk.g2_misc.p, pk.delta2_tab.p, S.s.p, S.out.p, B);
+            launch_finalize_g2(R.m_bs2.p, pk.g2_misc.p, pk.delta2_tab.p, S.s.p, S.out.p, B, tail);
     } else {
         ZK_HIP(hipStreamWaitEvent(tail, R.ev[6], 0));
     }
@@ -994,9 +1119,17 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm,
 void Algorithm::enqueue_tail_early(SolveSet &S, hipStream_t st) {
     Resident &R = *res;
     const size_t B = R.B;
-    hipLaunchKernelGGL(k_finalize_stage1, dim3(ceil_div(B, 64), 3), dim3(64), 0, st, R.m_ar.p, R.m_bs1.p, pk.g1_misc.p, pk.delta_tab.p, S.r.p, S.s.p,
-                       R.ar_aff.p, R.bs1_aff.p, R.f_t.p, B);
-    hipLaunchKernelGGL(k_finalize_stage2, dim3(ceil_div(B, 64), 2), dim3(64), 0, st, R.ar_aff.p, R.bs1_aff.p, S.r.p, S.s.p, R.f_u.p, R.f_v.p, B);
+    if (B <= TAIL_TREE_MAX_B)
+        hipLaunchKernelGGL(k_finalize_stage1_small, dim3((unsigned)B, 3), dim3(16), 0, st, R.m_ar.p, R.m_bs1.p, pk.g1_misc.p, pk.delta_tab.p, S.r.p, S.s.p, R.ar_aff.p,
+                           R.bs1_aff.p, R.f_t.p, B);
+    else
+        hipLaunchKernelGGL(k_finalize_stage1, dim3(ceil_div(B, 64), 3), dim3(64), 0, st, R.m_ar.p, R.m_bs1.p, pk.g1_misc.p, pk.delta_tab.p, S.r.p, S.s.p,
+                           R.ar_aff.p, R.bs1_aff.p, R.f_t.p, B);
+    static const bool stage2_pipe = [] { const char *e = ZK_AB_ENV("ZKPROVE_STAGE2_PIPE"); return !(e && e[0] == '0'); }();
+    if (B <= 32 && stage2_pipe)
+        hipLaunchKernelGGL(k_finalize_stage2_pipe<4>, dim3(1, 2), dim3(320), 0, st, R.ar_aff.p, R.bs1_aff.p, S.r.p, S.s.p, R.f_u.p, R.f_v.p, B);
+    else
+        hipLaunchKernelGGL(k_finalize_stage2, dim3(ceil_div(B, 64), 2), dim3(64), 0, st, R.ar_aff.p, R.bs1_aff.p, S.r.p, S.s.p, R.f_u.p, R.f_v.p, B);
     ZK_HIP(hipGetLastError());
 }
 // last part, once every sum of the batch is complete: Krs, canonical outputs
@@ -1262,7 +1395,7 @@ void Algorithm::split_finish(int world, const uint8_t *gathered) {
     hipLaunchKernelGGL(k_split_sum, dim3(ceil_div(B, 64), 5), dim3(64), 0, st, rec.p, world, R.m_ar.p, R.m_bs1.p, R.m_k.p, R.m_z.p, R.m_bs2.p, B);
     SolveSet &S = R.set[0];
     enqueue_tail_early(S, st);
-    hipLaunchKernelGGL(k_finalize_g2, dim3(ceil_div(B, 64)), dim3(64), 0, st, R.m_bs2.p, pk.g2_misc.p, pk.delta2_tab.p, S.s.p, S.out.p, B);
+    launch_finalize_g2(R.m_bs2.p, pk.g2_misc.p, pk.delta2_tab.p, S.s.p, S.out.p, B, st);
     enqueue_finalize(S, st);
     ZK_HIP(hipStreamSynchronize(st));
 }

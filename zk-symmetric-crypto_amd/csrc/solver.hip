@@ -420,6 +420,7 @@ struct SolveCtx {
     const Fr *randomize, *challenge;
     uint32_t *err, *count_scratch;
     size_t B, count_rows;
+    unsigned long long *dbg;      // experiments build: per (level, wavefront) time stamps of k_solve_lanes (ZKPROVE_SOLVER_DBG=1), else null
 };
 
 // Almost every wire of these circuits is a bit, so coefficient * wire and <L,w> * <R,w> are mostly products with
@@ -935,6 +936,21 @@ __device__ __forceinline__ void lp_eval(const SolveCtx &cx, const uint32_t *__re
         }
     }
 }
+// butterfly sums over the wavefront, three values at a time (independent chains: the shuffles of one overlap the additions of another)
+__device__ __forceinline__ void lp_wave_reduce3(Fr &x, Fr &y, Fr &z, bool all) {
+#pragma unroll 1
+    for (int o = 32; o >= 1; o >>= 1) {
+        Fr ox, oy, oz;
+#pragma unroll
+        for (int i = 0; i < 8; i++) ox.l[i] = __shfl_xor(x.l[i], o);
+        if (all) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) { oy.l[i] = __shfl_xor(y.l[i], o); oz.l[i] = __shfl_xor(z.l[i], o); }
+        }
+        x = x + ox;
+        if (all) { y = y + oy; z = z + oz; }
+    }
+}
 // sum over the wavefront of the terms t = lane, lane + 64, ... of a linear expression in the program encoding; every lane gets it
 __device__ __forceinline__ Fr lp_wave_sum(const SolveCtx &cx, const uint32_t *__restrict__ p, uint32_t n, size_t b, int lane) {
     Fr acc = Fr::zero();
@@ -957,6 +973,9 @@ __global__ __launch_bounds__(NT) void k_solve_lanes(SolveCtx cx, const uint32_t 
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const size_t b = blockIdx.x, B = cx.B;
     for (uint32_t l = l0; l < l1; l++) {
+#ifdef ZK_EXPERIMENTS
+        if (cx.dbg && lane == 0 && b == 0) cx.dbg[((size_t)l * NW + wave) * 4] = wall_clock64();
+#endif
         const uint32_t t_first = lvl[3 * l], n_tasks = lvl[3 * l + 1], n_count = lvl[3 * l + 2];
         for (uint32_t t = wave; t < n_tasks; t += NW) {
             const uint32_t *tk = tasks + 4 * (size_t)(t_first + t);
@@ -996,20 +1015,51 @@ __global__ __launch_bounds__(NT) void k_solve_lanes(SolveCtx cx, const uint32_t 
             } else {       // LP_TASK_WIDE: one instruction, the lanes take its terms
                 const uint32_t *p = cx.prog + w1;
                 const uint32_t op = p[0];
-                if (op == OP_R1C) {
-                    const uint32_t cons = p[1], nL = p[2], nR = p[3], nO = p[4], loc = p[5], sw = p[6], sc = p[7];
-                    p += 8;
-                    const Fr vL = lp_wave_sum(cx, p, nL, b, lane); p += 2 * nL;
-                    const Fr vR = lp_wave_sum(cx, p, nR, b, lane); p += 2 * nR;
-                    const Fr vO = lp_wave_sum(cx, p, nO, b, lane);
-                    if (lane == 0) finish_r1c<false>(cx, b, cons, loc, sw, sc, vL, vR, vO);
-                } else if (op == OP_NBITS) {
-                    const uint32_t nout = p[1], out0 = p[2];
-                    const Fr v = lp_wave_sum(cx, p + 4, p[3], b, lane).from_mont();
-                    const Fr one = Fr::one(), zero = Fr::zero();
-                    for (uint32_t k = lane; k < nout; k += 64) {
-                        const bool bit = k < 256 && ((v.l[k >> 5] >> (k & 31)) & 1);
-                        cx.wires[(size_t)(out0 + k) * B + b] = bit ? one : zero;
+                if (op == OP_R1C || op == OP_NBITS) {
+                    // the three expressions as ONE list of terms: all (coefficient, wire) words of this lane's terms are requested together,
+                    // then all their wire values, then the three sums run as one butterfly -- two memory round trips and one reduction
+                    // where three loops of  words -> wires -> reduce  followed each other (11.5 us per 130-term add32 row; 7 per nBits)
+                    const bool r1c = op == OP_R1C;
+                    const uint32_t nL = r1c ? p[2] : p[3], nLR = r1c ? p[2] + p[3] : nL, T = r1c ? nLR + p[4] : nL;
+                    const uint32_t *pt = p + (r1c ? 8 : 4);
+                    uint32_t cw[3][2];
+                    Fr wv[3];
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        const uint32_t tt = lane + 64 * k;
+                        cw[k][0] = tt < T ? pt[2 * tt] : 0u;
+                        cw[k][1] = tt < T ? pt[2 * tt + 1] : 0u;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 3; k++) wv[k] = cx.wires[(size_t)(cw[k][1] == WIRE_CONST ? 0u : cw[k][1]) * B + b];
+                    Fr vL = Fr::zero(), vR = Fr::zero(), vO = Fr::zero();
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        const uint32_t tt = lane + 64 * k;
+                        if (tt < T) {
+                            const Fr val = term_apply(cx, cw[k][0], cw[k][1], wv[k]);
+                            if (tt < nL) vL = vL + val;
+                            else if (tt < nLR) vR = vR + val;
+                            else vO = vO + val;
+                        }
+                    }
+                    for (uint32_t tt = lane + 192; tt < T; tt += 64) {
+                        const Fr val = term_val(cx, pt[2 * tt], pt[2 * tt + 1], b);
+                        if (tt < nL) vL = vL + val;
+                        else if (tt < nLR) vR = vR + val;
+                        else vO = vO + val;
+                    }
+                    lp_wave_reduce3(vL, vR, vO, r1c);
+                    if (r1c) {
+                        if (lane == 0) finish_r1c<false>(cx, b, p[1], p[5], p[6], p[7], vL, vR, vO);
+                    } else {
+                        const uint32_t nout = p[1], out0 = p[2];
+                        const Fr v = vL.from_mont();
+                        const Fr one = Fr::one(), zero = Fr::zero();
+                        for (uint32_t k = lane; k < nout; k += 64) {
+                            const bool bit = k < 256 && ((v.l[k >> 5] >> (k & 31)) & 1);
+                            cx.wires[(size_t)(out0 + k) * B + b] = bit ? one : zero;
+                        }
                     }
                 } else if (op == OP_LOOKUP) {
                     const uint32_t tb = p[1], nq = p[2], w0 = p[3], nent = p[4];
@@ -1027,6 +1077,9 @@ __global__ __launch_bounds__(NT) void k_solve_lanes(SolveCtx cx, const uint32_t 
                 }
             }
         }
+#ifdef ZK_EXPERIMENTS
+        if (cx.dbg && lane == 0 && b == 0) cx.dbg[((size_t)l * NW + wave) * 4 + 1] = wall_clock64();
+#endif
         // countHints of this level: the whole workgroup on each (same code as the slices of k_solve_level)
         for (uint32_t c = 0; c < n_count; c++) {
             const uint32_t *p = cx.prog + tasks[4 * (size_t)(t_first + n_tasks + c) + 1], instr = tasks[4 * (size_t)(t_first + n_tasks + c) + 2];
@@ -1059,7 +1112,13 @@ __global__ __launch_bounds__(NT) void k_solve_lanes(SolveCtx cx, const uint32_t 
             __syncthreads();
             for (uint32_t g = tid; g < div_count; g += NT) solve_division_group<1>(cx, div_list + 4 * (size_t)div_first, div_count, g, b);
         }
+#ifdef ZK_EXPERIMENTS
+        if (cx.dbg && lane == 0 && b == 0) cx.dbg[((size_t)l * NW + wave) * 4 + 2] = wall_clock64();
+#endif
         __syncthreads();                                   // the level's wires are written: the next level may read them
+#ifdef ZK_EXPERIMENTS
+        if (cx.dbg && lane == 0 && b == 0) cx.dbg[((size_t)l * NW + wave) * 4 + 3] = wall_clock64();
+#endif
     }
 }
 
@@ -1136,7 +1195,7 @@ static size_t persist_max_b() {
 #endif
 void solver_run_levels(const SolverProgram &p, SolverBuffers &buf, size_t first_level, size_t last_level, hipStream_t s) {
     SolveCtx cx{p.prog.p, p.coeffs.p, p.coeff_inv.p, p.lookup_tables.p, p.count_tables.p, buf.wires.p, buf.a.p, buf.b.p, buf.c.p,
-                buf.randomize.p, buf.challenge.p, buf.err.p, buf.count_scratch.p, buf.B, p.n_count_rows};
+                buf.randomize.p, buf.challenge.p, buf.err.p, buf.count_scratch.p, buf.B, p.n_count_rows, nullptr};
     if (last_level > p.levels.size()) last_level = p.levels.size();
 #ifdef ZK_EXPERIMENTS
     if (buf.B <= persist_max_b() && first_level < last_level) {
@@ -1166,6 +1225,16 @@ void solver_run_levels(const SolverProgram &p, SolverBuffers &buf, size_t first_
     // the lane program measured 15.5 against 13.4 ms per call there; ZKPROVE_SOLVER_LANES_ALL=1 in the experiments build forces it)
     static const bool lanes_all = [] { const char *e = ZK_AB_ENV("ZKPROVE_SOLVER_LANES_ALL"); return e && e[0] == '1'; }();
     if (buf.B <= lanes_max_b && first_level < last_level && (lanes_all || p.levels.size() <= 256)) {
+#ifdef ZK_EXPERIMENTS
+        static const bool dbg_on = [] { const char *e = getenv("ZKPROVE_SOLVER_DBG"); return e && e[0] == '1'; }();
+        static DevBuf<unsigned long long> dbg_buf;
+        static int dbg_calls = 0;
+        if (dbg_on) {
+            dbg_buf.ensure(p.levels.size() * 16 * 4);
+            ZK_HIP(hipMemsetAsync(dbg_buf.p, 0, p.levels.size() * 16 * 4 * 8, s));
+            cx.dbg = dbg_buf.p;
+        }
+#endif
         static const int nt_env = [] { const char *e = ZK_AB_ENV("ZKPROVE_SOLVER_LANES_NT"); return e ? atoi(e) : 1024; }();
         if (nt_env == 512)
             hipLaunchKernelGGL((k_solve_lanes<512, 8>), dim3((unsigned)buf.B), dim3(512), 0, s, cx, p.lp_shapes.p, p.lp_tasks.p, p.lp_soa.p, p.lp_level.p, p.level_desc.p,
@@ -1174,6 +1243,23 @@ void solver_run_levels(const SolverProgram &p, SolverBuffers &buf, size_t first_
             hipLaunchKernelGGL((k_solve_lanes<1024, 4>), dim3((unsigned)buf.B), dim3(1024), 0, s, cx, p.lp_shapes.p, p.lp_tasks.p, p.lp_soa.p, p.lp_level.p, p.level_desc.p,
                                p.div_list.p, (uint32_t)first_level, (uint32_t)last_level);
         ZK_HIP(hipGetLastError());
+#ifdef ZK_EXPERIMENTS
+        if (dbg_on && ++dbg_calls == 8) {       // the 8th call: warm; one line per level (how long its fastest / slowest wavefront worked)
+            ZK_HIP(hipStreamSynchronize(s));
+            std::vector<unsigned long long> h(p.levels.size() * 64);
+            ZK_HIP(hipMemcpy(h.data(), dbg_buf.p, h.size() * 8, hipMemcpyDeviceToHost));
+            for (size_t l = first_level; l < last_level; l++) {
+                unsigned long long t0 = ~0ull, t1max = 0, t2max = 0, t3 = 0, t1min = ~0ull;
+                for (int w = 0; w < 16; w++) {
+                    const unsigned long long *q = &h[(l * 16 + w) * 4];
+                    if (!q[0]) continue;
+                    t0 = std::min(t0, q[0]); t1max = std::max(t1max, q[1]); t1min = std::min(t1min, q[1]); t2max = std::max(t2max, q[2]); t3 = std::max(t3, q[3]);
+                }
+                fprintf(stderr, "lvl %zu n %u wide %u: tasks first done %.2f last done %.2f, barrier reached %.2f, left %.2f us\n", l, p.levels[l].count, p.levels[l].wide,
+                        (t1min - t0) * 0.01, (t1max - t0) * 0.01, (t2max - t0) * 0.01, (t3 - t0) * 0.01);
+            }
+        }
+#endif
         return;
     }
     static const bool pack = [] { const char *e = ZK_AB_ENV("ZKPROVE_SOLVER_PACK"); return !(e && e[0] == '0'); }();
