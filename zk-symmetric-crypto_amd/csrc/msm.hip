@@ -36,11 +36,18 @@ namespace zk {
 
 // buckets per bucket-reduction thread: 64 when that still gives >= 32k threads (any MSM at batch 1024), else 16 -- a small batch
 // (one Prove() call) is pure latency of dependent additions, and 4x more threads cut it 4x
-static constexpr int SEG_LOG = 6, SEG_LOG_SMALL = 4;
+// -- and 8 for the batches of single Prove() calls (at most TINY_BATCH proofs), whose every chain of dependent additions is call latency
+static constexpr int SEG_LOG = 6, SEG_LOG_SMALL = 4, SEG_LOG_TINY = 3;
+static constexpr size_t TINY_BATCH = 8;
+static inline bool tiny_batch(size_t B) {
+    static const bool on = [] { const char *e = ZK_AB_ENV("ZKPROVE_MSM_TINY"); return !(e && e[0] == '0'); }();
+    return on && B <= TINY_BATCH;
+}
 static inline uint32_t seg_len(uint32_t nb, size_t B) {
     static const size_t min_threads = [] { const char *e = ZK_AB_ENV("ZKPROVE_SEG_THREADS"); return e ? (size_t)atol(e) : (size_t)32768; }();
     uint32_t L = nb < (1u << SEG_LOG) ? nb : (1u << SEG_LOG);
     if ((size_t)(nb / L) * B < min_threads && nb > (1u << SEG_LOG_SMALL)) L = 1u << SEG_LOG_SMALL;
+    if (tiny_batch(B) && nb > (1u << SEG_LOG_TINY)) L = 1u << SEG_LOG_TINY;
     return L;
 }
 static constexpr size_t FOLD_GROUP = 8;      // partial sums are folded 8 at a time, level by level
@@ -186,7 +193,8 @@ void MsmScratch::reserve_dense_second(size_t B_, size_t max_dense_entries, size_
 // at B = 1024 (among 512..4096); small batches (a single Prove() call) cut the list finer so that the launch still has ~256k threads
 static uint32_t accumulate_lanes(size_t max_entries, size_t B) {
     size_t piece = 2048;
-    while (piece > 64 && (max_entries * B) / piece < 262144) piece >>= 1;
+    const size_t floor_piece = tiny_batch(B) ? 32 : 64;      // (a lane takes whole buckets: below the bucket size a finer cut changes nothing)
+    while (piece > floor_piece && (max_entries * B) / piece < 262144) piece >>= 1;
     // parity tests force the production cut (many buckets and several inversion chunks per thread) at batch sizes the CPU oracle can follow
     static const size_t forced = [] { const char *e = ZK_AB_ENV("ZKPROVE_MSM_PIECE"); return e ? (size_t)atol(e) : (size_t)0; }();
     if (forced >= 16) piece = forced;
@@ -1092,9 +1100,35 @@ bool msm_dense_presort(const MsmBasesG1 &mb, const Fr *scalars, size_t B, MsmScr
     return true;
 }
 
+// The same sum for the batches of single Prove() calls as ONE launch: a workgroup per instance, thread t first adds the partial sums
+// t, t + 256, ..., then eight rounds through LDS halve the 256 running sums -- 3 + 8 dependent additions for the ~860 partial sums of
+// the AES G2 MSM where the four levels of k_sum_groups were 4 launches of 7 (1.0 ms of a one-proof call).  Same group element.
+template <class F>
+__global__ __launch_bounds__(256) void k_fold_parts_tree(const XYZZ<F> *__restrict__ part, size_t stride, size_t npart, XYZZ<F> *__restrict__ out) {
+    extern __shared__ uint4 fold_lds_raw[];
+    XYZZ<F> *lds = reinterpret_cast<XYZZ<F> *>(fold_lds_raw);
+    const size_t b = blockIdx.x;
+    const int t = threadIdx.x;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (size_t i = t; i < npart; i += 256) acc.add(part[b * stride + i]);
+    for (int step = 128; step >= 1; step >>= 1) {
+        if (t >= step && t < 2 * step) lds[t - step] = acc;
+        __syncthreads();
+        if (t < step) acc.add(lds[t]);
+        __syncthreads();
+    }
+    if (t == 0) out[b] = acc;
+}
 // fold the npart partial sums of every instance, FOLD_GROUP at a time; the last level writes out[b]
 template <class F>
 static void msm_fold_parts(XYZZ<F> *part, size_t stride, size_t npart, XYZZ<F> *out, size_t B, hipStream_t s) {
+    if (tiny_batch(B) && npart > FOLD_GROUP) {
+        static PerDeviceOnce attr;
+        attr.run([] { ZK_HIP(hipFuncSetAttribute((const void *)k_fold_parts_tree<F>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * (int)sizeof(XYZZ<F>))); });
+        hipLaunchKernelGGL(k_fold_parts_tree<F>, dim3((unsigned)B), dim3(256), 128 * sizeof(XYZZ<F>), s, part, stride, npart, out);
+        ZK_HIP(hipGetLastError());
+        return;
+    }
     size_t off = 0, cnt = npart;
     do {
         const size_t groups = (cnt + FOLD_GROUP - 1) / FOLD_GROUP;
@@ -1261,7 +1295,7 @@ void msm_batch(const MsmBasesG2 &mb, const Fr *sc, size_t B, MsmScratch &scr, G2
 
 size_t msm_part_stride(size_t n, int c) {
     const uint32_t nb = 1u << (c - 1);
-    const uint32_t L = nb > (1u << SEG_LOG_SMALL) ? (1u << SEG_LOG_SMALL) : nb;     // the small-batch segment length gives the most partials
+    const uint32_t L = nb > (1u << SEG_LOG_TINY) ? (1u << SEG_LOG_TINY) : nb;     // the shortest segment length (one-proof batches) gives the most partials
     size_t npart = (n + ONES_CHUNK - 1) / ONES_CHUNK + nb / L + WCOMB_CLASSES, total = 0;      // + one slot per wire-comb class
     for (size_t cnt = npart; cnt > 1; cnt = (cnt + FOLD_GROUP - 1) / FOLD_GROUP) total += cnt;
     return total + 2;
