@@ -1,0 +1,23 @@
+"""wall time of one ProveBatch(JSON array of n requests) call for small n (median of 9), ChaCha20 or AES-256:
+python3 scripts/debug/small_batch_latency.py <alg> [n ...]"""
+import importlib, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+zk = importlib.import_module("zk-symmetric-crypto_amd")
+alg = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+ns = [int(x) for x in sys.argv[2:]] or [1, 2, 4, 8, 16, 32, 64]
+zk.lib.ZkpAllowUnpinnedKeys(1)
+r1cs = zk.synth.r1cs_bytes(alg)
+pk, _ = zk.setup(r1cs, zk.synth.toxic_from_seed(1), raw=True)
+assert zk.init_algorithm(alg, pk, r1cs)
+rng = zk.synth.SplitMix64(5)
+reqs = [json.loads(zk.synth.request_json(alg, zk.synth.make_instance(alg, rng))) for _ in range(max(ns))]
+for n in ns:
+    body = json.dumps(reqs[:n]).encode()
+    lat = []
+    for _ in range(10):
+        t0 = time.perf_counter(); out = zk.prove_batch_raw(body); lat.append((time.perf_counter() - t0) * 1e3)
+    res = json.loads(out)
+    assert len(res) == n and all("proof" in r for r in res)
+    lat = sorted(lat[1:])
+    print("alg %d n %3d: %.2f ms per call (min %.2f) = %.0f proofs/s" % (alg, n, lat[len(lat) // 2], lat[0], n / lat[len(lat) // 2] * 1e3))

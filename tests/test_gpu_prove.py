@@ -51,7 +51,7 @@ def test_prove_matches_oracle_bit_exact(zk, oracle, algs, alg):
     assert not pairing.groth16_verify(vk, pp, bad)
 
 
-# 64x4, 16x16 and 8x32 solver workgroup shapes; batches of up to four take the lane program (k_solve_lanes: a workgroup per instance)
+# 64x4, 16x16 and 8x32 solver workgroup shapes; ChaCha20 batches of up to 128 take the lane program (k_solve_lanes: a workgroup per instance); AES keeps the level launches
 @pytest.mark.parametrize("alg,batch", [(0, 70), (2, 66), (1, 12), (0, 7), (0, 3), (2, 4), (1, 3)])
 def test_batch_wires_quotient_and_proofs(zk, oracle, algs, alg, batch):
     algs(alg)

@@ -51,6 +51,7 @@ static inline uint32_t seg_len(uint32_t nb, size_t B) {
     return L;
 }
 static constexpr size_t FOLD_GROUP = 8;      // partial sums are folded 8 at a time, level by level
+static size_t part_stride_for(size_t n, int c, size_t B);
 // Conditional-sum path (scalars 0 / +1 / -1): bases are taken TERN_G at a time and every signed subset sum of a group is
 // precomputed, so a group costs one mixed addition whatever its +-1 pattern is.  Index of a pattern: sum (t_i + 1) 3^i,
 // t_i in {-1, 0, +1}; the patterns above the centre (all zero) are stored, the ones below are their negatives.
@@ -238,7 +239,7 @@ void MsmScratch::reserve(size_t B_, size_t max_entries, size_t max_nb, size_t ma
     const size_t Bm = B > VIRT_MIN ? B : VIRT_MIN;
     bucket_start.ensure(Bm * (max_nb + 1));
     part1.ensure(Bm * max_part + 1);
-    part2.ensure(B * max_part + 1);
+    part2.ensure((B <= TINY_BATCH ? 2 * B : B) * max_part + 1);      // (one-proof batches: part_stride_for)
 }
 
 // --------------------------------------------------------------------------------- digit helpers
@@ -1017,7 +1018,7 @@ static void msm_dense_split(const MsmBases<F> &mb, const Fr *scalars, size_t B, 
         const size_t Bv = B * split, nv = mb.n / split, max_entries = nv * W;
         const uint32_t L = seg_len(nb, Bv);
         const size_t nseg = nb / L, npart = nseg;
-        const size_t stride = msm_part_stride(mb.n, c);
+        const size_t stride = part_stride_for(mb.n, c, Bv);
         XYZZ<F> *part = PartSel<F>::get(sc), *sums = SumsSel<F>::get(sc);
         if (sc.entries.n < Bv * max_entries + 1 || sc.entries2.n < Bv * max_entries + 1 || sc.bucket_start.n < Bv * (nb + 1) ||
             PartSel<F>::cap(sc) < Bv * stride + 1 || SumsSel<F>::cap(sc) < Bv * (size_t)nb || sc.coarse_base.n < Bv * (MAX_COARSE + 1) || sc.vout1.n < Bv)
@@ -1213,7 +1214,7 @@ static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, M
     }
     const size_t nw = wcomb ? mb.wcomb.size() : 0;
     const size_t npart = nchunks + nseg + nw;
-    const size_t stride = msm_part_stride(n, c);      // level-0 partials followed by the fold levels
+    const size_t stride = part_stride_for(n, c, B);      // level-0 partials followed by the fold levels
     if (sc.entries.n < B * max_entries + 1 || sc.bucket_start.n < B * (nb + 1) || PartSel<F>::cap(sc) < B * stride + 1)
         throw ZkError("msm scratch too small");
     XYZZ<F> *part = PartSel<F>::get(sc);
@@ -1293,9 +1294,19 @@ static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, M
 void msm_batch(const MsmBasesG1 &mb, const Fr *sc, size_t B, MsmScratch &scr, G1XYZZ *out, hipStream_t s, hipEvent_t *ev) { msm_batch_impl<Fp>(mb, sc, B, scr, out, s, ev); }
 void msm_batch(const MsmBasesG2 &mb, const Fr *sc, size_t B, MsmScratch &scr, G2XYZZ *out, hipStream_t s) { msm_batch_impl<Fp2>(mb, sc, B, scr, out, s, nullptr); }
 
+// the stride a batch of B uses: one-proof batches cut the bucket reduction finer (seg_len) and need about twice the room per instance,
+// which the reservations give them (part1 is sized for at least VIRT_MIN instances, part2 for twice the instances up to TINY_BATCH)
+static size_t part_stride_for(size_t n, int c, size_t B) {
+    if (!tiny_batch(B)) return msm_part_stride(n, c);
+    const uint32_t nb = 1u << (c - 1);
+    const uint32_t L = seg_len(nb, B);
+    size_t npart = (n + ONES_CHUNK - 1) / ONES_CHUNK + nb / L + WCOMB_CLASSES, total = 0;
+    for (size_t cnt = npart; cnt > 1; cnt = (cnt + FOLD_GROUP - 1) / FOLD_GROUP) total += cnt;
+    return total + 2;
+}
 size_t msm_part_stride(size_t n, int c) {
     const uint32_t nb = 1u << (c - 1);
-    const uint32_t L = nb > (1u << SEG_LOG_TINY) ? (1u << SEG_LOG_TINY) : nb;     // the shortest segment length (one-proof batches) gives the most partials
+    const uint32_t L = nb > (1u << SEG_LOG_SMALL) ? (1u << SEG_LOG_SMALL) : nb;     // the small-batch segment length gives the most partials
     size_t npart = (n + ONES_CHUNK - 1) / ONES_CHUNK + nb / L + WCOMB_CLASSES, total = 0;      // + one slot per wire-comb class
     for (size_t cnt = npart; cnt > 1; cnt = (cnt + FOLD_GROUP - 1) / FOLD_GROUP) total += cnt;
     return total + 2;

@@ -28,7 +28,10 @@ static constexpr uint32_t NARROW_MAX = 16;
 // lane program (k_solve_lanes): instructions with a linear expression of at least this many terms are shared by the lanes of a wavefront
 static constexpr uint32_t LP_WIDE_TERMS = 32;
 enum : uint32_t { LP_TASK_LANES = 0, LP_TASK_WIDE = 1, LP_TASK_COUNT = 2 };
-static constexpr size_t LP_MAX_B = 4;
+// up to this many proofs: a workgroup each.  (Measured through ProveBatch, same box, level launches vs lane program: 8 proofs 7.3 -> 5.7 ms
+// per call, 32: 13.9 -> 9.3, 128: 25.4 -> 21.5, 256: 36.1 -> 32.4 -- but a workgroup per proof spends ~5 x the instructions of the
+// instance-per-lane kernels, which a full 1 024-batch, bound by instruction issue, cannot afford.)
+static constexpr size_t LP_MAX_B = 128;
 
 // ------------------------------------------------------------------------------------- build
 namespace {
@@ -1219,7 +1222,7 @@ void solver_run_levels(const SolverProgram &p, SolverBuffers &buf, size_t first_
         return;
     }
 #endif
-    // batches of at most LP_MAX_B proofs (single Prove() calls): one workgroup per instance walks the levels by itself (k_solve_lanes)
+    // batches of at most LP_MAX_B proofs (single Prove() calls, small ProveBatch arrays): one workgroup per instance walks the levels by itself (k_solve_lanes)
     static const size_t lanes_max_b = [] { const char *e = ZK_AB_ENV("ZKPROVE_SOLVER_LANES"); return e ? (size_t)atol(e) : LP_MAX_B; }();
     // (the AES programs keep the level launches for now: their wide levels -- up to 100 wavefront tasks -- want the whole device, and
     // the lane program measured 15.5 against 13.4 ms per call there; ZKPROVE_SOLVER_LANES_ALL=1 in the experiments build forces it)
