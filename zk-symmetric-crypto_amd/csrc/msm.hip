@@ -39,6 +39,7 @@ namespace zk {
 // -- and 8 for the batches of single Prove() calls (at most TINY_BATCH proofs), whose every chain of dependent additions is call latency
 static constexpr int SEG_LOG = 6, SEG_LOG_SMALL = 4, SEG_LOG_TINY = 3;
 static constexpr size_t TINY_BATCH = 8;
+static constexpr size_t FOLD_TREE_MAX_B = 128;      // batches up to this size fold their partial sums in one tree launch (k_fold_parts_tree)
 static inline bool tiny_batch(size_t B) {
     static const bool on = [] { const char *e = ZK_AB_ENV("ZKPROVE_MSM_TINY"); return !(e && e[0] == '0'); }();
     return on && B <= TINY_BATCH;
@@ -1101,7 +1102,7 @@ bool msm_dense_presort(const MsmBasesG1 &mb, const Fr *scalars, size_t B, MsmScr
     return true;
 }
 
-// The same sum for the batches of single Prove() calls as ONE launch: a workgroup per instance, thread t first adds the partial sums
+// The same sum for batches of at most FOLD_TREE_MAX_B proofs as ONE launch: a workgroup per instance, thread t first adds the partial sums
 // t, t + 256, ..., then eight rounds through LDS halve the 256 running sums -- 3 + 8 dependent additions for the ~860 partial sums of
 // the AES G2 MSM where the four levels of k_sum_groups were 4 launches of 7 (1.0 ms of a one-proof call).  Same group element.
 template <class F>
@@ -1123,7 +1124,7 @@ __global__ __launch_bounds__(256) void k_fold_parts_tree(const XYZZ<F> *__restri
 // fold the npart partial sums of every instance, FOLD_GROUP at a time; the last level writes out[b]
 template <class F>
 static void msm_fold_parts(XYZZ<F> *part, size_t stride, size_t npart, XYZZ<F> *out, size_t B, hipStream_t s) {
-    if (tiny_batch(B) && npart > FOLD_GROUP) {
+    if (B <= FOLD_TREE_MAX_B && tiny_batch(1) && npart > FOLD_GROUP) {
         static PerDeviceOnce attr;
         attr.run([] { ZK_HIP(hipFuncSetAttribute((const void *)k_fold_parts_tree<F>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * (int)sizeof(XYZZ<F>))); });
         hipLaunchKernelGGL(k_fold_parts_tree<F>, dim3((unsigned)B), dim3(256), 128 * sizeof(XYZZ<F>), s, part, stride, npart, out);

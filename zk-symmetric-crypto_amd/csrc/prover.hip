@@ -386,7 +386,7 @@ __global__ __launch_bounds__(64) void k_finalize_stage2(const G1Affine *__restri
         v_out[b] = scalar_mul_glv(bs1_aff[b], k);
     }
 }
-// The same two multiplications for batches of at most 32 proofs (single Prove() calls: this chain IS the end of the call's critical
+// The same two multiplications for batches of at most 128 proofs, 32 to a workgroup (single Prove() calls: this chain IS the end of the call's critical
 // path), as a pipeline inside one workgroup per multiplication.  k P = k1 P + k2 phi(P) right to left: wavefront 0 runs the ONE chain
 // that cannot be shortened -- the doublings D_i = 2^i P, i < 128 -- and hands every D_i over through a ring in LDS; four more wavefronts
 // add the D_i whose bit is set (two per half-scalar, even and odd positions: an addition takes ~1.5 doublings and half the bits are
@@ -508,7 +508,7 @@ __global__ void k_store_commit(const G1Affine *com, const G1Affine *pok, ProofPo
 }
 
 
-static constexpr size_t TAIL_TREE_MAX_B = 8;      // batches up to this size: fixed-base products as 16-lane trees
+static constexpr size_t TAIL_TREE_MAX_B = 128;      // batches up to this size: fixed-base products as 16-lane trees
 static void launch_finalize_g2(const G2XYZZ *m_bs2, const G2Affine *misc, const G2Affine *dtab, const U256 *s, ProofPoints *out, size_t B, hipStream_t st) {
     if (B <= TAIL_TREE_MAX_B) hipLaunchKernelGGL(k_finalize_g2_small, dim3((unsigned)B), dim3(16), 0, st, m_bs2, misc, dtab, s, out, B);
     else hipLaunchKernelGGL(k_finalize_g2, dim3(ceil_div(B, 64)), dim3(64), 0, st, m_bs2, misc, dtab, s, out, B);
@@ -1126,8 +1126,8 @@ void Algorithm::enqueue_tail_early(SolveSet &S, hipStream_t st) {
         hipLaunchKernelGGL(k_finalize_stage1, dim3(ceil_div(B, 64), 3), dim3(64), 0, st, R.m_ar.p, R.m_bs1.p, pk.g1_misc.p, pk.delta_tab.p, S.r.p, S.s.p,
                            R.ar_aff.p, R.bs1_aff.p, R.f_t.p, B);
     static const bool stage2_pipe = [] { const char *e = ZK_AB_ENV("ZKPROVE_STAGE2_PIPE"); return !(e && e[0] == '0'); }();
-    if (B <= 32 && stage2_pipe)
-        hipLaunchKernelGGL(k_finalize_stage2_pipe<4>, dim3(1, 2), dim3(320), 0, st, R.ar_aff.p, R.bs1_aff.p, S.r.p, S.s.p, R.f_u.p, R.f_v.p, B);
+    if (B <= 128 && stage2_pipe)
+        hipLaunchKernelGGL(k_finalize_stage2_pipe<4>, dim3(ceil_div(B, 32), 2), dim3(320), 0, st, R.ar_aff.p, R.bs1_aff.p, S.r.p, S.s.p, R.f_u.p, R.f_v.p, B);
     else
         hipLaunchKernelGGL(k_finalize_stage2, dim3(ceil_div(B, 64), 2), dim3(64), 0, st, R.ar_aff.p, R.bs1_aff.p, S.r.p, S.s.p, R.f_u.p, R.f_v.p, B);
     ZK_HIP(hipGetLastError());
