@@ -1264,7 +1264,7 @@ void Algorithm::ensure_second_set_once(int nsets) {
         ZK_HIP(hipMemcpy(b.s.p, a.s.p, R.B * sizeof(U256), hipMemcpyDeviceToDevice));
         ZK_HIP(hipMemcpy(b.rnd.p, a.rnd.p, R.B * sizeof(U256), hipMemcpyDeviceToDevice));
     }
-    if (has_commit && R.ms2.entries.n == 0) {
+    if (has_commit && (R.ms2.entries.n == 0 || R.ms2.B < R.cap)) {      // (again when the capacity grew: a small batch may come first)
         R.ms2.reserve(R.cap, pk.ped.n * (size_t)pk.ped.W, (size_t)1 << (pk.ped.c - 1), msm_part_stride(pk.ped.n, pk.ped.c));
         R.ms2.reserve_compact(R.cap, pk.ped.n);
         R.ms2.reserve_sums(R.cap, (size_t)1 << (pk.ped.c - 1), 1);
