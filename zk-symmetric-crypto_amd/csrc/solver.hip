@@ -319,8 +319,16 @@ void SolverProgram::build(const R1cs &cs, hipStream_t s) {
     {
         std::vector<uint32_t> shapes, tasks, soa, lvl;
         std::map<std::vector<uint32_t>, uint32_t> shape_at;
-        for (const auto &lv : levels) {
-            std::vector<std::array<uint32_t, 4>> wide_t, count_t, lane_t;
+        // A long CHECK (an R1C instruction that defines no wire: the 130-term add32 recompositions) is the slowest task of its level
+        // and nobody waits for its result: it moves to the NEXT level, where it runs beside that level's own tasks (ChaCha20: beside
+        // the eight nBits hints, on the eight wavefronts that had nothing to do) -- its a / b / c rows and its verdict arrive a level
+        // later, before the kernel ends.  (Not across a commitment level: the caller cuts the level range there.)
+        std::vector<std::array<uint32_t, 4>> deferred;
+        for (size_t lidx = 0; lidx < levels.size(); lidx++) {
+            const auto &lv = levels[lidx];
+            const bool may_defer = lidx + 1 < levels.size() && !levels[lidx + 1].has_commit && !lv.has_commit;
+            std::vector<std::array<uint32_t, 4>> wide_t, count_t, lane_t, incoming;
+            incoming.swap(deferred);
             std::map<uint32_t, std::vector<std::vector<uint32_t>>> groups;      // shape offset -> field rows
             std::vector<uint32_t> group_order;
             for (uint32_t q = 0; q < lv.count; q++) {
@@ -363,7 +371,11 @@ void SolverProgram::build(const R1cs &cs, hipStream_t s) {
                     shp = {op};
                     fld = {rec[1]};
                 }
-                if (is_wide) { wide_t.push_back({LP_TASK_WIDE, off[i], i, 0u}); continue; }
+                if (is_wide) {
+                    if (op == OP_R1C && rec[5] == 0 && may_defer) deferred.push_back({LP_TASK_WIDE, off[i], i, 0u});
+                    else wide_t.push_back({LP_TASK_WIDE, off[i], i, 0u});
+                    continue;
+                }
                 auto it = shape_at.find(shp);
                 if (it == shape_at.end()) {
                     it = shape_at.emplace(shp, (uint32_t)shapes.size()).first;
@@ -380,8 +392,8 @@ void SolverProgram::build(const R1cs &cs, hipStream_t s) {
                     for (uint32_t j = 0; j < gc; j++) soa.push_back(rows[j][f]);
                 for (uint32_t j0 = 0; j0 < gc; j0 += 64) lane_t.push_back({LP_TASK_LANES, so, base + j0, (gc - j0 < 64 ? gc - j0 : 64u) | (gc << 7)});
             }
-            lvl.insert(lvl.end(), {(uint32_t)(tasks.size() / 4), (uint32_t)(wide_t.size() + lane_t.size()), (uint32_t)count_t.size()});
-            for (const auto *v : {&wide_t, &lane_t, &count_t})          // long instructions first, countHints after the wavefront tasks
+            lvl.insert(lvl.end(), {(uint32_t)(tasks.size() / 4), (uint32_t)(wide_t.size() + lane_t.size() + incoming.size()), (uint32_t)count_t.size()});
+            for (const auto *v : {&wide_t, &lane_t, &incoming, &count_t})          // long instructions first, the previous level's checks behind the level's own tasks, countHints last
                 for (const auto &t : *v) tasks.insert(tasks.end(), t.begin(), t.end());
         }
         if (shapes.empty()) shapes.push_back(0);
@@ -939,19 +951,27 @@ __device__ __forceinline__ void lp_eval(const SolveCtx &cx, const uint32_t *__re
         }
     }
 }
-// butterfly sums over the wavefront, three values at a time (independent chains: the shuffles of one overlap the additions of another)
-__device__ __forceinline__ void lp_wave_reduce3(Fr &x, Fr &y, Fr &z, bool all) {
+// butterfly sums over the wavefront, up to three values at a time (independent chains: the shuffles of one overlap the additions of
+// another); which = bit 0: x, bit 1: y, bit 2: z (wavefront-uniform)
+__device__ __forceinline__ void lp_wave_reduce3(Fr &x, Fr &y, Fr &z, uint32_t which) {
 #pragma unroll 1
     for (int o = 32; o >= 1; o >>= 1) {
         Fr ox, oy, oz;
+        if (which & 1u) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) ox.l[i] = __shfl_xor(x.l[i], o);
-        if (all) {
-#pragma unroll
-            for (int i = 0; i < 8; i++) { oy.l[i] = __shfl_xor(y.l[i], o); oz.l[i] = __shfl_xor(z.l[i], o); }
+            for (int i = 0; i < 8; i++) ox.l[i] = __shfl_xor(x.l[i], o);
         }
-        x = x + ox;
-        if (all) { y = y + oy; z = z + oz; }
+        if (which & 2u) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) oy.l[i] = __shfl_xor(y.l[i], o);
+        }
+        if (which & 4u) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) oz.l[i] = __shfl_xor(z.l[i], o);
+        }
+        if (which & 1u) x = x + ox;
+        if (which & 2u) y = y + oy;
+        if (which & 4u) z = z + oz;
     }
 }
 // sum over the wavefront of the terms t = lane, lane + 64, ... of a linear expression in the program encoding; every lane gets it
@@ -1052,7 +1072,8 @@ __global__ __launch_bounds__(NT) void k_solve_lanes(SolveCtx cx, const uint32_t 
                         else if (tt < nLR) vR = vR + val;
                         else vO = vO + val;
                     }
-                    lp_wave_reduce3(vL, vR, vO, r1c);
+                    // (an R1C row is finished by lane 0, which already holds a one-term L: t = 0 is its own term)
+                    lp_wave_reduce3(vL, vR, vO, r1c ? ((nL > 1 ? 1u : 0u) | 2u | 4u) : 1u);
                     if (r1c) {
                         if (lane == 0) finish_r1c<false>(cx, b, p[1], p[5], p[6], p[7], vL, vR, vO);
                     } else {
