@@ -477,6 +477,18 @@ __device__ __forceinline__ Fr term_apply(const SolveCtx &cx, uint32_t cid, uint3
         default: return mul_fast(w, cx.coeffs[cid]);
     }
 }
+// the same with the coefficient's value already in registers
+__device__ __forceinline__ Fr term_apply_pre(uint32_t cid, uint32_t wid, const Fr &w, const Fr &cval) {
+    if (wid == WIRE_CONST) return cval;
+    switch (cid) {
+        case 0: return Fr::zero();
+        case 1: return w;
+        case 2: return w.dbl();
+        case 3: return w.neg();
+        case 4: return w.dbl().neg();
+        default: return mul_fast(w, cval);
+    }
+}
 __device__ __forceinline__ Fr eval_terms(const SolveCtx &cx, const uint32_t *&p, uint32_t n, size_t b) {
     Fr acc = Fr::zero();
     uint32_t k = 0;
@@ -1053,14 +1065,18 @@ __global__ __launch_bounds__(NT) void k_solve_lanes(SolveCtx cx, const uint32_t 
                         cw[k][0] = tt < T ? pt[2 * tt] : 0u;
                         cw[k][1] = tt < T ? pt[2 * tt + 1] : 0u;
                     }
+                    Fr cv[3];                               // the coefficient values too: fetched behind a branch of term_apply they are a third round trip
 #pragma unroll
-                    for (int k = 0; k < 3; k++) wv[k] = cx.wires[(size_t)(cw[k][1] == WIRE_CONST ? 0u : cw[k][1]) * B + b];
+                    for (int k = 0; k < 3; k++) {
+                        wv[k] = cx.wires[(size_t)(cw[k][1] == WIRE_CONST ? 0u : cw[k][1]) * B + b];
+                        cv[k] = cx.coeffs[cw[k][0]];
+                    }
                     Fr vL = Fr::zero(), vR = Fr::zero(), vO = Fr::zero();
 #pragma unroll
                     for (int k = 0; k < 3; k++) {
                         const uint32_t tt = lane + 64 * k;
                         if (tt < T) {
-                            const Fr val = term_apply(cx, cw[k][0], cw[k][1], wv[k]);
+                            const Fr val = term_apply_pre(cw[k][0], cw[k][1], wv[k], cv[k]);
                             if (tt < nL) vL = vL + val;
                             else if (tt < nLR) vR = vR + val;
                             else vO = vO + val;
