@@ -331,6 +331,15 @@ def test_extreme_inputs(zk, oracle, algs, alg):
         res = json.loads(zk.prove_deterministic_raw(H.request_json(alg, inst), inst["r"], inst["s"], inst["randomize"]))
         exp, out, *_ = H.oracle_proof_bytes(alg, inst)
         assert base64.b64decode(res["ciphertext"]) == out and base64.b64decode(res["proof"]) == exp
+    # blinding scalars at the edges of the tail's scalar multiplications (the doubling chain + adder wavefronts of small batches, the
+    # 16-lane fixed-base trees): zero (nothing is added anywhere), one, the endomorphism's eigenvalue (k1 = 0, k2 = 1), 2^127 and 2^128 - 1
+    # (the top of a half-scalar), r - 1
+    LAMBDA = 0xb3c4d79d41a917585bfc41088d8daaa78b17ea66b99c90dd
+    for k, (r, s) in enumerate([(0, 0), (1, 0), (0, 1), (LAMBDA, LAMBDA + 1), (1 << 127, (1 << 128) - 1), (R_TEST - 1, R_TEST - 1)]):
+        inst = dict(cases[k % 3], r=r, s=s, randomize=k)
+        res = json.loads(zk.prove_deterministic_raw(H.request_json(alg, inst), inst["r"], inst["s"], inst["randomize"]))
+        exp, out, *_ = H.oracle_proof_bytes(alg, inst)
+        assert base64.b64decode(res["proof"]) == exp, "blinding scalars r = %x, s = %x" % (r, s)
 
 
 R_TEST = rf.R_MOD
