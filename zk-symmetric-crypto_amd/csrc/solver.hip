@@ -939,8 +939,12 @@ __global__ __launch_bounds__(LX * SL) void k_solve_narrow_run(SolveCtx cx, const
 // vector loads of every program word, every branch of the interpreter taken by some lane; it lost to the level launches.)
 // Long expressions (>= LP_WIDE_TERMS terms: the 96-term add32 / FromBinary rows) are a task of their own, the wavefront's lanes
 // taking the TERMS and a butterfly of wave shuffles summing them; countHints are worked on by the whole workgroup; an unknown in L or R
-// is divided out after the level's tasks, a lane per division.  Same arithmetic and case analysis as k_solve_level + k_solve_divisions, and field addition is exact and
-// commutative, so wires and a / b / c rows are the same bits.
+// is divided out after the level's tasks, a lane per division.  Same arithmetic and case analysis as k_solve_level + k_solve_divisions,
+// and field addition is exact and commutative, so wires and a / b / c rows are the same bits.
+// Measured from inside (ZKPROVE_SOLVER_DBG=1, experiments build): a dependent load costs ~0.7 us, a long row ~10 us of which three
+// quarters are the lone wavefront's arithmetic; with all 16 wavefronts busy a level is bound by the CU's instruction issue.  Fetching
+// the wire-independent words one or two levels ahead was built twice and lost to its register bill; the kernel
+// used for ChaCha20-sized programs (AES: a level of up to 100 tasks wants the whole device, and the level launches win there).
 template <int CH>
 __device__ __forceinline__ void lp_eval(const SolveCtx &cx, const uint32_t *__restrict__ tw, uint32_t T, uint32_t nL, uint32_t nLR, const uint32_t *__restrict__ f,
                                         uint32_t gc, size_t b, Fr &vL, Fr &vR, Fr &vO) {
