@@ -916,6 +916,23 @@ __global__ __launch_bounds__(LX * SL) void k_solve_narrow_run(SolveCtx cx, const
         // long expressions: the slices share them, one instruction at a time (barriers inside: every thread takes part)
         for (uint32_t i = 0; i < wide; i++) solve_instruction<LX, SL, true>(cx, instr_off, li[i], b, live, threadIdx.y == 0 && live, red);
         for (uint32_t i = wide + slice; i < count; i += SL) solve_instruction<LX, SL, false>(cx, instr_off, li[i], b, live, live, red);
+        // The last wavefront (idle in almost every level: a narrow level holds ~3 instructions) walks the NEXT level's program now --
+        // description -> instruction numbers -> offsets -> records -- so that the scalar cache holds it when the level starts: the
+        // workers' chain of five dependent scalar loads then hits the cache (a level is 7 us, ~2 of them that chain)
+        if (slice == SL - 1 && l + 1 < l1) {
+            const uint32_t f2 = level_desc[5 * (l + 1)], c2 = level_desc[5 * (l + 1) + 1];
+            uint32_t sink = level_desc[5 * (l + 1) + 2] ^ level_desc[5 * (l + 1) + 3] ^ level_desc[5 * (l + 1) + 4];
+            for (uint32_t i = 0; i < c2 && i < NARROW_MAX; i++) {
+                const uint32_t *p = cx.prog + instr_off[level_instr[f2 + i]];
+                uint32_t words = p[0] == OP_R1C ? 8 + 2 * (p[2] + p[3] + p[4]) : (p[0] == OP_NBITS ? 4 + 2 * p[3] : 16u);
+                if (words > 512) words = 512;
+                for (uint32_t k = 0; k < words; k += 16) sink ^= p[k];
+                sink ^= p[words - 1];
+            }
+            const uint32_t d2 = level_desc[5 * (l + 1) + 3], dc2 = level_desc[5 * (l + 1) + 4];
+            for (uint32_t k = 0; k < 4 * dc2 && k < 64; k += 16) sink ^= div_list[4 * (size_t)d2 + k];
+            asm volatile("" ::"s"(sink));
+        }
         __syncthreads();
         if (div_count) {
             constexpr int G = 2;                               // at most 16 divisions per level: a wavefront per pair
