@@ -1009,6 +1009,25 @@ static void partition_attr() {
     once.run([] { ZK_HIP(hipFuncSetAttribute((const void *)k_msm_partition, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)); });
 }
 
+// The same sum for batches of at most FOLD_TREE_MAX_B proofs as ONE launch: a workgroup per instance, thread t first adds the partial sums
+// t, t + 256, ..., then eight rounds through LDS halve the 256 running sums -- 3 + 8 dependent additions for the ~860 partial sums of
+// the AES G2 MSM where the four levels of k_sum_groups were 4 launches of 7 (1.0 ms of a one-proof call).  Same group element.
+template <class F>
+__global__ __launch_bounds__(256) void k_fold_parts_tree(const XYZZ<F> *__restrict__ part, size_t stride, size_t npart, XYZZ<F> *__restrict__ out) {
+    extern __shared__ uint4 fold_lds_raw[];
+    XYZZ<F> *lds = reinterpret_cast<XYZZ<F> *>(fold_lds_raw);
+    const size_t b = blockIdx.x;
+    const int t = threadIdx.x;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (size_t i = t; i < npart; i += 256) acc.add(part[b * stride + i]);
+    for (int step = 128; step >= 1; step >>= 1) {
+        if (t >= step && t < 2 * step) lds[t - step] = acc;
+        __syncthreads();
+        if (t < step) acc.add(lds[t]);
+        __syncthreads();
+    }
+    if (t == 0) out[b] = acc;
+}
 // Dense two-level path of a small batch, every instance split into `split` virtual instances (G1 only).
 template <class F>
 static void msm_dense_split(const MsmBases<F> &mb, const Fr *scalars, size_t B, MsmScratch &sc, XYZZ<F> *out, hipStream_t s, hipEvent_t *seg_events,
@@ -1040,15 +1059,22 @@ static void msm_dense_split(const MsmBases<F> &mb, const Fr *scalars, size_t B, 
             launch_accumulate_reduce<F, true>(mb, sc.bucket_start.p, sc.entries.p, max_entries, c, Bv, nlanes, sums, SumsSel<F>::cap(sc), part, stride, (size_t)0, L, s,
                                               seg_events);
         }
-        size_t off = 0, cnt = npart;
-        do {
-            const size_t groups = (cnt + FOLD_GROUP - 1) / FOLD_GROUP;
-            const bool last = groups == 1;
-            hipLaunchKernelGGL(k_sum_groups<F>, dim3(ceil_div(groups * Bv, 64)), dim3(64), 0, s, part + off, stride, cnt, FOLD_GROUP,
-                               last ? (XYZZ<F> *)sc.vout1.p : part + off + cnt, last ? (size_t)1 : stride, Bv);
-            off += cnt;
-            cnt = groups;
-        } while (cnt > 1);
+        if (Bv <= FOLD_TREE_MAX_B && tiny_batch(1) && npart > FOLD_GROUP) {
+            // (a one-proof call: the 2 048 segment totals of each of its 16 virtual instances in one tree launch instead of four levels)
+            static PerDeviceOnce attr;
+            attr.run([] { ZK_HIP(hipFuncSetAttribute((const void *)k_fold_parts_tree<F>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * (int)sizeof(XYZZ<F>))); });
+            hipLaunchKernelGGL(k_fold_parts_tree<F>, dim3((unsigned)Bv), dim3(256), 128 * sizeof(XYZZ<F>), s, part, stride, npart, (XYZZ<F> *)sc.vout1.p);
+        } else {
+            size_t off = 0, cnt = npart;
+            do {
+                const size_t groups = (cnt + FOLD_GROUP - 1) / FOLD_GROUP;
+                const bool last = groups == 1;
+                hipLaunchKernelGGL(k_sum_groups<F>, dim3(ceil_div(groups * Bv, 64)), dim3(64), 0, s, part + off, stride, cnt, FOLD_GROUP,
+                                   last ? (XYZZ<F> *)sc.vout1.p : part + off + cnt, last ? (size_t)1 : stride, Bv);
+                off += cnt;
+                cnt = groups;
+            } while (cnt > 1);
+        }
         hipLaunchKernelGGL(k_sum_groups<F>, dim3(ceil_div(B, 64)), dim3(64), 0, s, (const XYZZ<F> *)sc.vout1.p, (size_t)split, (size_t)split, (size_t)split, out,
                            (size_t)1, B);
         ZK_HIP(hipGetLastError());
@@ -1102,25 +1128,6 @@ bool msm_dense_presort(const MsmBasesG1 &mb, const Fr *scalars, size_t B, MsmScr
     return true;
 }
 
-// The same sum for batches of at most FOLD_TREE_MAX_B proofs as ONE launch: a workgroup per instance, thread t first adds the partial sums
-// t, t + 256, ..., then eight rounds through LDS halve the 256 running sums -- 3 + 8 dependent additions for the ~860 partial sums of
-// the AES G2 MSM where the four levels of k_sum_groups were 4 launches of 7 (1.0 ms of a one-proof call).  Same group element.
-template <class F>
-__global__ __launch_bounds__(256) void k_fold_parts_tree(const XYZZ<F> *__restrict__ part, size_t stride, size_t npart, XYZZ<F> *__restrict__ out) {
-    extern __shared__ uint4 fold_lds_raw[];
-    XYZZ<F> *lds = reinterpret_cast<XYZZ<F> *>(fold_lds_raw);
-    const size_t b = blockIdx.x;
-    const int t = threadIdx.x;
-    XYZZ<F> acc = XYZZ<F>::inf();
-    for (size_t i = t; i < npart; i += 256) acc.add(part[b * stride + i]);
-    for (int step = 128; step >= 1; step >>= 1) {
-        if (t >= step && t < 2 * step) lds[t - step] = acc;
-        __syncthreads();
-        if (t < step) acc.add(lds[t]);
-        __syncthreads();
-    }
-    if (t == 0) out[b] = acc;
-}
 // fold the npart partial sums of every instance, FOLD_GROUP at a time; the last level writes out[b]
 template <class F>
 static void msm_fold_parts(XYZZ<F> *part, size_t stride, size_t npart, XYZZ<F> *out, size_t B, hipStream_t s) {
