@@ -195,7 +195,9 @@ void MsmScratch::reserve_dense_second(size_t B_, size_t max_dense_entries, size_
 // at B = 1024 (among 512..4096); small batches (a single Prove() call) cut the list finer so that the launch still has ~256k threads
 static uint32_t accumulate_lanes(size_t max_entries, size_t B) {
     size_t piece = 2048;
-    const size_t floor_piece = tiny_batch(B) ? 32 : 64;      // (a lane takes whole buckets: below the bucket size a finer cut changes nothing)
+    // (a lane takes whole buckets: below the bucket size a finer cut changes nothing -- the wire MSMs' buckets hold ~28 entries, the
+    // quotient MSM's of a one-proof call two: 64 dependent additions per lane there were 0.5 ms of the call's critical chain)
+    const size_t floor_piece = tiny_batch(1) && B <= 32 ? 16 : 64;
     while (piece > floor_piece && (max_entries * B) / piece < 262144) piece >>= 1;
     // parity tests force the production cut (many buckets and several inversion chunks per thread) at batch sizes the CPU oracle can follow
     static const size_t forced = [] { const char *e = ZK_AB_ENV("ZKPROVE_MSM_PIECE"); return e ? (size_t)atol(e) : (size_t)0; }();
@@ -1075,8 +1077,11 @@ static void msm_dense_split(const MsmBases<F> &mb, const Fr *scalars, size_t B, 
                 cnt = groups;
             } while (cnt > 1);
         }
-        hipLaunchKernelGGL(k_sum_groups<F>, dim3(ceil_div(B, 64)), dim3(64), 0, s, (const XYZZ<F> *)sc.vout1.p, (size_t)split, (size_t)split, (size_t)split, out,
-                           (size_t)1, B);
+        if (Bv <= FOLD_TREE_MAX_B && tiny_batch(1) && split > 2)        // the virtual instances' totals: a tree again (15 dependent additions -> 4)
+            hipLaunchKernelGGL(k_fold_parts_tree<F>, dim3((unsigned)B), dim3(256), 128 * sizeof(XYZZ<F>), s, (const XYZZ<F> *)sc.vout1.p, (size_t)split, (size_t)split, out);
+        else
+            hipLaunchKernelGGL(k_sum_groups<F>, dim3(ceil_div(B, 64)), dim3(64), 0, s, (const XYZZ<F> *)sc.vout1.p, (size_t)split, (size_t)split, (size_t)split, out,
+                               (size_t)1, B);
         ZK_HIP(hipGetLastError());
     } else {
         (void)mb; (void)scalars; (void)B; (void)sc; (void)out; (void)s; (void)seg_events; (void)split;
