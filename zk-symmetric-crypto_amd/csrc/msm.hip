@@ -243,6 +243,7 @@ void MsmScratch::reserve(size_t B_, size_t max_entries, size_t max_nb, size_t ma
     bucket_start.ensure(Bm * (max_nb + 1));
     part1.ensure(Bm * max_part + 1);
     part2.ensure((B <= TINY_BATCH ? 2 * B : B) * max_part + 1);      // (one-proof batches: part_stride_for)
+    vout1.ensure(VIRT_MIN + 1);                                          // (msm_sparse_split)
 }
 
 // --------------------------------------------------------------------------------- digit helpers
@@ -275,20 +276,24 @@ template <bool DENSE>
 __global__ __launch_bounds__(SORT_THREADS) void k_msm_sort(const Fr *__restrict__ dense, size_t dense_stride, const uint32_t *__restrict__ gen_count,
                                                            const uint32_t *__restrict__ gen_idx, const Fr *__restrict__ gen_val, size_t n, int c,
                                                            int W, uint32_t *__restrict__ bucket_start, uint32_t *__restrict__ entries,
-                                                           size_t max_entries, const uint32_t *__restrict__ skip_if_zero) {
+                                                           size_t max_entries, const uint32_t *__restrict__ skip_if_zero, uint32_t split = 1) {
     extern __shared__ uint32_t lds[];
     const uint32_t nb = 1u << (c - 1);
     uint32_t *hist = lds;
     uint32_t *scan = lds + nb;
-    const size_t b = blockIdx.x;
+    // split > 1 (msm_sparse_split): workgroup blockIdx.x sorts the share blockIdx.x % split of instance blockIdx.x / split as an
+    // instance of its own (bucket_start / entries rows by blockIdx.x)
+    const size_t bb = blockIdx.x, b = bb / split;
+    const uint32_t vshare = (uint32_t)(bb % split);
     const int tid = threadIdx.x;
     // wire MSMs (9-limb kernels): *skip_if_zero = gen_count[B] is the batch total of the compact lists; 0 (the normal case once the wire
     // combs take the wide positions, and always for the ChaCha20 circuit) means no instance has anything for the bucket pipeline: its
     // kernels -- this one, k_msm_accumulate9 and k_msm_bucket_reduce9 -- return at once
     if (skip_if_zero && *skip_if_zero == 0) return;
-    const size_t cnt = DENSE ? n : (size_t)gen_count[b];
-    uint32_t *bs = bucket_start + b * (nb + 1);
-    if (cnt == 0) {     // nothing for the bucket pipeline: publish an empty histogram and leave
+    const size_t cnt_all = DENSE ? n : (size_t)gen_count[b];
+    const size_t k_lo = cnt_all * vshare / split, cnt = cnt_all * (vshare + 1) / split;      // this workgroup's entries of the list: [k_lo, cnt)
+    uint32_t *bs = bucket_start + bb * (nb + 1);
+    if (cnt == k_lo) {     // nothing for the bucket pipeline: publish an empty histogram and leave
         for (uint32_t i = tid; i <= nb; i += SORT_THREADS) bs[i] = 0;
         return;
     }
@@ -299,7 +304,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_msm_sort(const Fr *__restrict_
         j = gen_idx[b * n + k];
         return gen_val[b * n + k];
     };
-    for (size_t k = tid; k < cnt; k += SORT_THREADS) {
+    for (size_t k = k_lo + tid; k < cnt; k += SORT_THREADS) {
         uint32_t j;
         Fr cs = load(k, j);
         int carry = 0;
@@ -330,8 +335,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_msm_sort(const Fr *__restrict_
     }
     if (tid == SORT_THREADS - 1) bs[nb] = scan[tid];
     __syncthreads();
-    uint32_t *ent = entries + b * max_entries;
-    for (size_t k = tid; k < cnt; k += SORT_THREADS) {
+    uint32_t *ent = entries + bb * max_entries;
+    for (size_t k = k_lo + tid; k < cnt; k += SORT_THREADS) {
         uint32_t j;
         Fr cs = load(k, j);
         int carry = 0;
@@ -1209,6 +1214,50 @@ static bool attach_wire_comb(MsmBases<F> &mb, const uint8_t *cls, int k, hipStre
 bool msm_attach_wire_comb(MsmBasesG1 &mb, const uint8_t *cls, int k, hipStream_t s) { return attach_wire_comb<Fp>(mb, cls, k, s); }
 bool msm_attach_wire_comb(MsmBasesG2 &mb, const uint8_t *cls, int k, hipStream_t s) { return attach_wire_comb<Fp2>(mb, cls, k, s); }
 
+// Wire MSM of a one-proof call (G1): the scalars that are neither 0 nor +-1 -- the byte- and word-valued wires of the AES circuits -- crowd
+// into a few buckets (24 425 committed bytes into 255 of 4 096: ~96 dependent additions for the lane that owns such a bucket, 0.9-1.9 ms
+// of k_msm_accumulate9 in every chain of the call).  As for the quotient MSM of small batches (msm_dense_split) every instance becomes
+// SPARSE_SPLIT virtual instances: a sixteenth of the compact list each to its own sort / accumulate / reduce rows, the totals joined by
+// the tree launch.  The +-1 sums stay with the real instance (virtual instance 0's first slots).  Same group element.
+static constexpr uint32_t SPARSE_SPLIT = 16;
+static constexpr size_t SPARSE_SPLIT_MAX_B = 4;
+template <class F>
+static bool msm_sparse_split(const MsmBases<F> &mb, const Fr *scalars, size_t B, MsmScratch &sc, XYZZ<F> *out, hipStream_t s) {
+    if constexpr (sizeof(F) == 32) {
+        const size_t n = mb.n, Bv = B * SPARSE_SPLIT;
+        const int c = mb.c, W = mb.W;
+        const uint32_t nb = 1u << (c - 1);
+        const size_t max_entries_v = ((n + SPARSE_SPLIT - 1) / SPARSE_SPLIT + 1) * (size_t)W;
+        const uint32_t L = seg_len(nb, Bv);
+        const size_t nseg = nb / L, nchunks = (n + ONES_CHUNK - 1) / ONES_CHUNK, npart = nchunks + nseg;
+        const size_t stride = part_stride_for(n, c, Bv);
+        using X9 = typename Nine<F>::X9;
+        if (npart > stride || sc.entries.n < Bv * max_entries_v + 1 || sc.bucket_start.n < Bv * (size_t)(nb + 1) || PartSel<F>::cap(sc) < Bv * stride + 1 ||
+            SumsSel<F>::cap(sc) * sizeof(XYZZ<F>) < Bv * (size_t)nb * sizeof(X9) || sc.vout1.n < Bv || sc.gen_count.n < B + 1 || sc.gen_idx.n < B * n ||
+            sc.gen_val.n < B * n)
+            return false;                                    // scratch of another shape: the caller takes the ordinary path
+        XYZZ<F> *part = PartSel<F>::get(sc);
+        ZK_HIP(hipMemsetAsync(part, 0, Bv * stride * sizeof(XYZZ<F>), s));              // the +-1 slots of the virtual instances 1.. : the identity
+        ZK_HIP(hipMemsetAsync(sc.gen_count.p, 0, (B + 1) * sizeof(uint32_t), s));
+        hipLaunchKernelGGL(k_msm_ones9<F>, dim3(ceil_div(nchunks * B, 256)), dim3(256), 0, s, mb.tern.p, scalars, B, mb.scalar_row.p, n, part, stride * SPARSE_SPLIT,
+                           (size_t)0, sc.gen_count.p, sc.gen_idx.p, sc.gen_val.p, (const uint8_t *)nullptr);
+        const size_t lds = (size_t)(nb + SORT_THREADS) * sizeof(uint32_t);
+        const uint32_t *skip = sc.gen_count.p + B;
+        hipLaunchKernelGGL(k_msm_sort<false>, dim3((unsigned)Bv), dim3(SORT_THREADS), lds, s, (const Fr *)nullptr, (size_t)0, sc.gen_count.p, sc.gen_idx.p, sc.gen_val.p, n, c,
+                           W, sc.bucket_start.p, sc.entries.p, max_entries_v, skip, SPARSE_SPLIT);
+        launch_accumulate_reduce<F, false>(mb, sc.bucket_start.p, sc.entries.p, max_entries_v, c, Bv, accumulate_lanes(max_entries_v, Bv), SumsSel<F>::get(sc),
+                                           SumsSel<F>::cap(sc), part, stride, nchunks, L, s, nullptr, skip);
+        msm_fold_parts<F>(part, stride, npart, (XYZZ<F> *)sc.vout1.p, Bv, s);
+        hipLaunchKernelGGL(k_fold_parts_tree<F>, dim3((unsigned)B), dim3(256), 128 * sizeof(XYZZ<F>), s, (const XYZZ<F> *)sc.vout1.p, (size_t)SPARSE_SPLIT,
+                           (size_t)SPARSE_SPLIT, out);
+        ZK_HIP(hipGetLastError());
+        return true;
+    } else {
+        (void)mb; (void)scalars; (void)B; (void)sc; (void)out; (void)s;
+        return false;
+    }
+}
+
 template <class F>
 static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, MsmScratch &sc, XYZZ<F> *out, hipStream_t s, hipEvent_t *seg_events) {
     const size_t n = mb.n;
@@ -1241,6 +1290,7 @@ static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, M
         ZK_HIP(hipFuncSetAttribute((const void *)k_msm_sort<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
         ZK_HIP(hipFuncSetAttribute((const void *)k_msm_sort<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
     });
+    if (!mb.dense && mb.f9 && !wcomb && sizeof(F) == 32 && B <= SPARSE_SPLIT_MAX_B && tiny_batch(1) && msm_sparse_split(mb, scalars, B, sc, out, s)) return;
     // the sorted list of the dense MSM lives in buffers of its own when they exist (entries_z): its sort may then run on another
     // stream beside the wire MSMs (msm_dense_presort), which use entries / bucket_start
     uint32_t *ent_p = sc.entries.p, *bs_p = sc.bucket_start.p;
