@@ -238,7 +238,7 @@ void MsmScratch::reserve_sums(size_t B_, size_t nb_g1, size_t nb_g2) {
 }
 void MsmScratch::reserve(size_t B_, size_t max_entries, size_t max_nb, size_t max_part) {
     B = B_;
-    entries.ensure(B * max_entries + 1);
+    entries.ensure(B * max_entries + 1 + 4096);      // (+ the rounding of msm_sparse_split's shares: up to 15 scalars' entries per proof)
     const size_t Bm = B > VIRT_MIN ? B : VIRT_MIN;
     bucket_start.ensure(Bm * (max_nb + 1));
     part1.ensure(Bm * max_part + 1);
@@ -1227,7 +1227,7 @@ static bool msm_sparse_split(const MsmBases<F> &mb, const Fr *scalars, size_t B,
         const size_t n = mb.n, Bv = B * SPARSE_SPLIT;
         const int c = mb.c, W = mb.W;
         const uint32_t nb = 1u << (c - 1);
-        const size_t max_entries_v = ((n + SPARSE_SPLIT - 1) / SPARSE_SPLIT + 1) * (size_t)W;
+        const size_t max_entries_v = ((n + SPARSE_SPLIT - 1) / SPARSE_SPLIT) * (size_t)W;      // a share holds at most ceil(n / split) scalars
         const uint32_t L = seg_len(nb, Bv);
         const size_t nseg = nb / L, nchunks = (n + ONES_CHUNK - 1) / ONES_CHUNK, npart = nchunks + nseg;
         const size_t stride = part_stride_for(n, c, Bv);
