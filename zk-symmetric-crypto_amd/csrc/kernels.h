@@ -123,6 +123,7 @@ struct MsmScratch {
     void reserve_compact(size_t B, size_t max_sparse_n);
     DevBuf<uint32_t> entries2, coarse_base;   // dense two-level sort: partitioned entries, per-instance coarse bin offsets
     DevBuf<G1XYZZ> vout1;                     // results of the virtual instances of a split small-batch dense MSM
+    DevBuf<G2XYZZ> vout2;                     // the same for the G2 wire MSM of a one-proof call (msm_sparse_split)
     void reserve_dense(size_t B, size_t max_dense_entries, size_t nb = 0);
     DevBuf<uint32_t> entries_z, bucket_start_z;   // sorted list of the dense MSM when it is kept apart from the wire MSMs' (nb != 0 above)
     DevBuf<uint32_t> entries_zb, bucket_start_zb; // second copy (reserve_dense_second): the NEXT batch's list is sorted while this one is walked

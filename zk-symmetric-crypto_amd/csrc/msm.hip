@@ -39,6 +39,8 @@ namespace zk {
 // -- and 8 for the batches of single Prove() calls (at most TINY_BATCH proofs), whose every chain of dependent additions is call latency
 static constexpr int SEG_LOG = 6, SEG_LOG_SMALL = 4, SEG_LOG_TINY = 3;
 static constexpr size_t TINY_BATCH = 8;
+static constexpr uint32_t SPARSE_SPLIT = 16;          // virtual instances per proof of a one-proof wire MSM (msm_sparse_split)
+static constexpr size_t SPARSE_SPLIT_MAX_B = 4;
 static constexpr size_t FOLD_TREE_MAX_B = 128;      // batches up to this size fold their partial sums in one tree launch (k_fold_parts_tree)
 static inline bool tiny_batch(size_t B) {
     static const bool on = [] { const char *e = ZK_AB_ENV("ZKPROVE_MSM_TINY"); return !(e && e[0] == '0'); }();
@@ -234,7 +236,7 @@ void MsmScratch::reserve_compact(size_t B_, size_t max_sparse_n) {
 }
 void MsmScratch::reserve_sums(size_t B_, size_t nb_g1, size_t nb_g2) {
     sums1.ensure(((B_ > VIRT_MIN ? B_ : VIRT_MIN) * nb_g1 + 1) * sizeof(G1X9) / sizeof(G1XYZZ) + 1);      // G1 bucket records are G1X9 (144 bytes) on the 9-limb path
-    sums2.ensure((B_ * nb_g2 + 1) * sizeof(G2X9) / sizeof(G2XYZZ) + 1);
+    sums2.ensure(((B_ <= SPARSE_SPLIT_MAX_B ? B_ * SPARSE_SPLIT : B_) * nb_g2 + 1) * sizeof(G2X9) / sizeof(G2XYZZ) + 1);      // (msm_sparse_split: 16 virtual instances per proof)
 }
 void MsmScratch::reserve(size_t B_, size_t max_entries, size_t max_nb, size_t max_part) {
     B = B_;
@@ -242,8 +244,9 @@ void MsmScratch::reserve(size_t B_, size_t max_entries, size_t max_nb, size_t ma
     const size_t Bm = B > VIRT_MIN ? B : VIRT_MIN;
     bucket_start.ensure(Bm * (max_nb + 1));
     part1.ensure(Bm * max_part + 1);
-    part2.ensure((B <= TINY_BATCH ? 2 * B : B) * max_part + 1);      // (one-proof batches: part_stride_for)
+    part2.ensure(std::max<size_t>(B <= TINY_BATCH ? 2 * B : B, B <= SPARSE_SPLIT_MAX_B ? B * SPARSE_SPLIT : 0) * max_part + 1);      // (one-proof batches: part_stride_for, msm_sparse_split)
     vout1.ensure(VIRT_MIN + 1);                                          // (msm_sparse_split)
+    vout2.ensure(VIRT_MIN + 1);
 }
 
 // --------------------------------------------------------------------------------- digit helpers
@@ -1010,6 +1013,13 @@ struct SumsSel<Fp> { static G1XYZZ *get(MsmScratch &s) { return s.sums1.p; } sta
 template <>
 struct SumsSel<Fp2> { static G2XYZZ *get(MsmScratch &s) { return s.sums2.p; } static size_t cap(MsmScratch &s) { return s.sums2.n; } };
 
+template <class F>
+struct VoutSel;
+template <>
+struct VoutSel<Fp> { static G1XYZZ *get(MsmScratch &s) { return s.vout1.p; } static size_t cap(MsmScratch &s) { return s.vout1.n; } };
+template <>
+struct VoutSel<Fp2> { static G2XYZZ *get(MsmScratch &s) { return s.vout2.p; } static size_t cap(MsmScratch &s) { return s.vout2.n; } };
+
 // the dynamic-LDS limit of a kernel is a per-device attribute
 static void partition_attr() {
     static PerDeviceOnce once;
@@ -1219,11 +1229,9 @@ bool msm_attach_wire_comb(MsmBasesG2 &mb, const uint8_t *cls, int k, hipStream_t
 // of k_msm_accumulate9 in every chain of the call).  As for the quotient MSM of small batches (msm_dense_split) every instance becomes
 // SPARSE_SPLIT virtual instances: a sixteenth of the compact list each to its own sort / accumulate / reduce rows, the totals joined by
 // the tree launch.  The +-1 sums stay with the real instance (virtual instance 0's first slots).  Same group element.
-static constexpr uint32_t SPARSE_SPLIT = 16;
-static constexpr size_t SPARSE_SPLIT_MAX_B = 4;
 template <class F>
 static bool msm_sparse_split(const MsmBases<F> &mb, const Fr *scalars, size_t B, MsmScratch &sc, XYZZ<F> *out, hipStream_t s) {
-    if constexpr (sizeof(F) == 32) {
+    {
         const size_t n = mb.n, Bv = B * SPARSE_SPLIT;
         const int c = mb.c, W = mb.W;
         const uint32_t nb = 1u << (c - 1);
@@ -1233,7 +1241,7 @@ static bool msm_sparse_split(const MsmBases<F> &mb, const Fr *scalars, size_t B,
         const size_t stride = part_stride_for(n, c, Bv);
         using X9 = typename Nine<F>::X9;
         if (npart > stride || sc.entries.n < Bv * max_entries_v + 1 || sc.bucket_start.n < Bv * (size_t)(nb + 1) || PartSel<F>::cap(sc) < Bv * stride + 1 ||
-            SumsSel<F>::cap(sc) * sizeof(XYZZ<F>) < Bv * (size_t)nb * sizeof(X9) || sc.vout1.n < Bv || sc.gen_count.n < B + 1 || sc.gen_idx.n < B * n ||
+            SumsSel<F>::cap(sc) * sizeof(XYZZ<F>) < Bv * (size_t)nb * sizeof(X9) || VoutSel<F>::cap(sc) < Bv || sc.gen_count.n < B + 1 || sc.gen_idx.n < B * n ||
             sc.gen_val.n < B * n)
             return false;                                    // scratch of another shape: the caller takes the ordinary path
         XYZZ<F> *part = PartSel<F>::get(sc);
@@ -1247,14 +1255,11 @@ static bool msm_sparse_split(const MsmBases<F> &mb, const Fr *scalars, size_t B,
                            W, sc.bucket_start.p, sc.entries.p, max_entries_v, skip, SPARSE_SPLIT);
         launch_accumulate_reduce<F, false>(mb, sc.bucket_start.p, sc.entries.p, max_entries_v, c, Bv, accumulate_lanes(max_entries_v, Bv), SumsSel<F>::get(sc),
                                            SumsSel<F>::cap(sc), part, stride, nchunks, L, s, nullptr, skip);
-        msm_fold_parts<F>(part, stride, npart, (XYZZ<F> *)sc.vout1.p, Bv, s);
-        hipLaunchKernelGGL(k_fold_parts_tree<F>, dim3((unsigned)B), dim3(256), 128 * sizeof(XYZZ<F>), s, (const XYZZ<F> *)sc.vout1.p, (size_t)SPARSE_SPLIT,
+        msm_fold_parts<F>(part, stride, npart, VoutSel<F>::get(sc), Bv, s);
+        hipLaunchKernelGGL(k_fold_parts_tree<F>, dim3((unsigned)B), dim3(256), 128 * sizeof(XYZZ<F>), s, (const XYZZ<F> *)VoutSel<F>::get(sc), (size_t)SPARSE_SPLIT,
                            (size_t)SPARSE_SPLIT, out);
         ZK_HIP(hipGetLastError());
         return true;
-    } else {
-        (void)mb; (void)scalars; (void)B; (void)sc; (void)out; (void)s;
-        return false;
     }
 }
 
@@ -1290,7 +1295,7 @@ static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, M
         ZK_HIP(hipFuncSetAttribute((const void *)k_msm_sort<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
         ZK_HIP(hipFuncSetAttribute((const void *)k_msm_sort<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
     });
-    if (!mb.dense && mb.f9 && !wcomb && sizeof(F) == 32 && B <= SPARSE_SPLIT_MAX_B && tiny_batch(1) && msm_sparse_split(mb, scalars, B, sc, out, s)) return;
+    if (!mb.dense && mb.f9 && !wcomb && B <= SPARSE_SPLIT_MAX_B && tiny_batch(1) && msm_sparse_split(mb, scalars, B, sc, out, s)) return;
     // the sorted list of the dense MSM lives in buffers of its own when they exist (entries_z): its sort may then run on another
     // stream beside the wire MSMs (msm_dense_presort), which use entries / bucket_start
     uint32_t *ent_p = sc.entries.p, *bs_p = sc.bucket_start.p;
