@@ -104,6 +104,11 @@ ProveReturn ZkpProveWitnessDeterministic(unsigned char algorithmID, GoSlice witn
  * the only source of non-determinism in a proof; fixing them makes proofs reproducible for parity tests. */
 ProveReturn ZkpProveDeterministic(GoSlice params, const uint8_t *r32, const uint8_t *s32, const uint8_t *randomize32);
 
+/* ProveBatch with caller-supplied blinding: r32 / s32 / randomize32 = [n][32] canonical little-endian scalars, element i for request i of
+ * the array (n must equal its length; all three arrays are required).  Makes batch proofs reproducible byte for byte (parity tests of the
+ * batch-size-switched code paths against the CPU oracle); everything else is ProveBatch. */
+ProveReturn ZkpProveBatchDeterministic(GoSlice params, long n, const uint8_t *r32, const uint8_t *s32, const uint8_t *randomize32);
+
 /* Groth16 key generation on the GPU (single-party; replaces gnark/keygen/keygen.go:94-132 = groth16.Setup + pk/vk WriteTo).
  * toxic192 = alpha, beta, gamma, delta, tau, sigma as canonical little-endian 32-byte scalars.  raw != 0 writes
  * uncompressed points (ProvingKey.WriteRawTo), else compressed (WriteTo).  Buffers are malloc'd; release with Free. */
@@ -139,12 +144,6 @@ int zkp_split_finish(int algorithmID, int world, const uint8_t *gathered);
  * clumps | windows, table MiB, mixed additions per proof of its walk, 1 when the wire MSMs use wire combs for their non-0/+-1 positions,
  * such positions in G1.A, wire-comb table MiB} */
 int zkp_quotient_msm_info(int algorithmID, long *info8);
-/* after a step: {sum, max, instances with any} of the entries the last main-stream wire MSM handed to the bucket pipeline (diagnostic) */
-int zkp_debug_leftovers(int algorithmID, long *out3);
-/* after a step: copy out the solved wire vectors [batch][n_wires][32] and the quotient-stage products
- * f_i = A(g w^i) * B(g w^i) [batch][N][32] (canonical LE, natural order; the scalars of the folded quotient MSM, see
- * csrc/keyfold.hip) -- parity tests only */
-int zkp_debug_fetch(int algorithmID, uint8_t *wires, uint8_t *h);
 /* request -> witness assignment (host logic only, no GPU): fills inputs[n_inputs], output bytes; returns
  * 0, or -1 with the reference's panic text in zkp_last_error() */
 int zkp_request_witness(GoSlice params, uint32_t *inputs, long inputs_cap, uint8_t *output, long output_cap, long *n_inputs, long *n_output);

@@ -65,6 +65,13 @@ int zkp_expand_message_xmd(const uint8_t *msg, long mlen, const uint8_t *dst, lo
 int zkp_bsb22_challenge(const uint8_t *com, long n, uint8_t *out);
 /* the verifier's host path for the same: commitments as X | Y 32-byte big-endian (G1Affine.Marshal) */
 int zkp_bsb22_challenge_host(const uint8_t *com_be64, long n, uint8_t *out);
+/* ---- parity-test views of the resident batch (zkp_bench_upload / zkp_bench_step of THIS library; the drop-in does not export them) */
+/* after a step: {sum, max, instances with any} of the entries the last main-stream wire MSM handed to the bucket pipeline */
+int zkp_debug_leftovers(int algorithmID, long *out3);
+/* after a step: the solved wire vectors [n][n_wires][32] and the quotient-stage products f_i = A(g w^i) * B(g w^i) [n][N][32] (canonical LE,
+ * natural order; the scalars of the folded quotient MSM, see csrc/keyfold.hip) of the n listed instances of the batch (instances == NULL:
+ * all of them, n ignored); either output may be NULL */
+int zkp_debug_fetch(int algorithmID, const uint32_t *instances, long n, uint8_t *wires, uint8_t *h);
 /* ---- request layer */
 /* the two request decoders (single-pass scanner for the canonical shape, DOM reader with Go's encoding/json semantics) on one input:
  * 1 = the scanner took it and agrees with the DOM reader field by field, 0 = the scanner declined, -1 = they disagree */

@@ -55,10 +55,15 @@ def test_prove_matches_oracle_bit_exact(zk, oracle, algs, alg):
 @pytest.mark.parametrize("alg,batch", [(0, 70), (2, 66), (1, 12), (0, 7), (0, 3), (2, 4), (1, 3)])
 def test_batch_wires_quotient_and_proofs(zk, oracle, algs, alg, batch):
     algs(alg)
+    # solved wires and quotient-stage products are read back through the TEST library (the drop-in exports no debug entries): the same
+    # objects with a registry of their own, so the batch is uploaded and stepped there
+    tl = zk.testlib
+    tl.ZkpAllowUnpinnedKeys(1)
+    assert zk.init_algorithm(alg, H.pk_file_bytes(alg), rf.load_r1cs_bytes(H.NAMES[alg]), lib=tl)
     rng = H.SplitMix64(0xBA7C4 + alg)
     insts = [H.make_instance(alg, rng) for _ in range(batch)]
     wits = [H.oracle_witness(alg, i)[0] for i in insts]
-    rb = zk.ResidentBatch(alg, np.array(wits, np.uint32), [i["r"] for i in insts], [i["s"] for i in insts], [i["randomize"] for i in insts])
+    rb = zk.ResidentBatch(alg, np.array(wits, np.uint32), [i["r"] for i in insts], [i["s"] for i in insts], [i["randomize"] for i in insts], lib=tl)
     times = rb.step()
     proofs, errs = rb.fetch()
     assert not errs.any(), errs
@@ -87,6 +92,11 @@ def test_batch_wires_quotient_and_proofs(zk, oracle, algs, alg, batch):
         pp = gf.proof_parse(zk.proof_serialize(proofs[k], alg != 0))
         assert pairing.groth16_verify(vk, pp, wits[k][:npub])
     assert times["total"] > 0
+    # the drop-in's resident entry gives the same records
+    rb2 = zk.ResidentBatch(alg, np.array(wits, np.uint32), [i["r"] for i in insts], [i["s"] for i in insts], [i["randomize"] for i in insts])
+    rb2.step()
+    proofs2, errs2 = rb2.fetch()
+    assert not errs2.any() and np.array_equal(proofs2, proofs)
 
 
 def test_prove_random_blinding_verifies_and_differs(zk, oracle, algs):

@@ -72,6 +72,8 @@ def _load_testlib():
                 ("zkp_field_inv", _i32, [_i32, _i64, _vp, _vp]),
                 ("zkp_bench_to_coset", C.c_double, [_i32, _i64, _i32]),
                 ("zkp_debug_tree", _i32, [_i32, _i32, _i32, _i32]),
+                ("zkp_debug_fetch", _i32, [_i32, _vp, _i64, _vp, _vp]),
+                ("zkp_debug_leftovers", _i32, [_i32, _vp]),
                 ("zkp_pairing_product_check", _i32, [_vp, _vp, _i64, _i32]),
                 ("zkp_vk_pairing_identities", _i32, [_vp, _i64, _i32]),
                 ("zkp_expand_message_xmd", _i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i32]),
@@ -80,6 +82,8 @@ def _load_testlib():
                 ("zkp_request_decode_both", _i32, [_vp, _i64]),
                 ("zkp_host_stage_bench", _i32, [_vp, _i64, _i32, _vp])):
             _sig(name, res, args, of=t)
+        if t is not lib:
+            _bind_product(t)          # the test library exports include/zkprove.h too (same objects): a resident batch may live in it
         _testlib = t
     return _testlib
 
@@ -110,38 +114,45 @@ ALGORITHM_IDS = {"chacha20": 0, "aes-128-ctr": 1, "aes-256-ctr": 2}      # impl/
 FILE_EXT = {"chacha20": "chacha20", "aes-128-ctr": "aes128", "aes-256-ctr": "aes256"}   # js/src/gnark/operator.ts:6-12
 
 _u8p = C.c_void_p
-_sig("enforce_binding", None, [])
-_sig("InitAlgorithm", C.c_ubyte, [C.c_ubyte, GoSlice, GoSlice])
-_sig("Prove", ProveReturn, [GoSlice])
-_sig("ProveBatch", ProveReturn, [GoSlice])
-_sig("Free", None, [C.c_void_p])
-_sig("GenerateOPRFRequestData", ProveReturn, [GoSlice])
-_sig("TOPRFFinalize", ProveReturn, [GoSlice])
-_sig("ZkpAllowUnpinnedKeys", None, [_i32])
-_sig("ZkpSetDevice", _i32, [_i32])
-_sig("ZkpReset", None, [])
-_sig("VerifyBatch", ProveReturn, [GoSlice])
-_sig("zkp_verify_batch_timed", ProveReturn, [GoSlice, C.POINTER(C.c_double)])
-_sig("VFree", None, [C.c_void_p])
-_sig("ZkpProveDeterministic", ProveReturn, [GoSlice, _u8p, _u8p, _u8p])
-_sig("ZkpProveWitness", ProveReturn, [C.c_ubyte, GoSlice])
-_sig("ZkpProveWitnessDeterministic", ProveReturn, [C.c_ubyte, GoSlice, _u8p, _u8p, _u8p])
-_sig("ZkpSetHardwareQueues", _i32, [_i32])
-_sig("zkp_n_inputs", _i64, [_i32])
-_sig("zkp_bench_upload", _i32, [_i32, _i64, _vp, _vp, _vp, _vp])
-_sig("zkp_bench_step", _i32, [_i32, _vp])
-_sig("zkp_bench_fetch", _i32, [_i32, _vp, _vp])
-_sig("zkp_bench_steps", _i32, [_i32, _i32, _vp])
-_sig("zkp_debug_fetch", _i32, [_i32, _vp, _vp])
-_sig("zkp_quotient_msm_info", _i32, [_i32, _vp])
-_sig("ZkpSetSplit", _i32, [_i32, _i32])
-_sig("zkp_split_partials", _i32, [_i32, _vp])
-_sig("zkp_split_finish", _i32, [_i32, _i32, _vp])
-_sig("ZkpDeviceReplicas", _i32, [_i32])
-_sig("zkp_request_witness", _i32, [GoSlice, _vp, _i64, _vp, _i64, C.POINTER(C.c_long), C.POINTER(C.c_long)])
-_sig("zkp_last_panic", C.c_char_p, [])
-_sig("zkp_proof_serialize", _i64, [_vp, _i32, _vp, _i64])
-_sig("zkp_r1cs_stats", _i32, [GoSlice, _vp])
+
+
+def _bind_product(l):
+    """ctypes signatures of include/zkprove.h on library handle l (the drop-in; the test library exports the same entries)"""
+    _sig("enforce_binding", None, [], of=l)
+    _sig("InitAlgorithm", C.c_ubyte, [C.c_ubyte, GoSlice, GoSlice], of=l)
+    _sig("Prove", ProveReturn, [GoSlice], of=l)
+    _sig("ProveBatch", ProveReturn, [GoSlice], of=l)
+    _sig("Free", None, [C.c_void_p], of=l)
+    _sig("GenerateOPRFRequestData", ProveReturn, [GoSlice], of=l)
+    _sig("TOPRFFinalize", ProveReturn, [GoSlice], of=l)
+    _sig("ZkpAllowUnpinnedKeys", None, [_i32], of=l)
+    _sig("ZkpSetDevice", _i32, [_i32], of=l)
+    _sig("ZkpReset", None, [], of=l)
+    _sig("VerifyBatch", ProveReturn, [GoSlice], of=l)
+    _sig("zkp_verify_batch_timed", ProveReturn, [GoSlice, C.POINTER(C.c_double)], of=l)
+    _sig("VFree", None, [C.c_void_p], of=l)
+    _sig("ZkpProveDeterministic", ProveReturn, [GoSlice, _u8p, _u8p, _u8p], of=l)
+    _sig("ZkpProveBatchDeterministic", ProveReturn, [GoSlice, _i64, _u8p, _u8p, _u8p], of=l)
+    _sig("ZkpProveWitness", ProveReturn, [C.c_ubyte, GoSlice], of=l)
+    _sig("ZkpProveWitnessDeterministic", ProveReturn, [C.c_ubyte, GoSlice, _u8p, _u8p, _u8p], of=l)
+    _sig("ZkpSetHardwareQueues", _i32, [_i32], of=l)
+    _sig("zkp_n_inputs", _i64, [_i32], of=l)
+    _sig("zkp_bench_upload", _i32, [_i32, _i64, _vp, _vp, _vp, _vp], of=l)
+    _sig("zkp_bench_step", _i32, [_i32, _vp], of=l)
+    _sig("zkp_bench_fetch", _i32, [_i32, _vp, _vp], of=l)
+    _sig("zkp_bench_steps", _i32, [_i32, _i32, _vp], of=l)
+    _sig("zkp_quotient_msm_info", _i32, [_i32, _vp], of=l)
+    _sig("ZkpSetSplit", _i32, [_i32, _i32], of=l)
+    _sig("zkp_split_partials", _i32, [_i32, _vp], of=l)
+    _sig("zkp_split_finish", _i32, [_i32, _i32, _vp], of=l)
+    _sig("ZkpDeviceReplicas", _i32, [_i32], of=l)
+    _sig("zkp_request_witness", _i32, [GoSlice, _vp, _i64, _vp, _i64, C.POINTER(C.c_long), C.POINTER(C.c_long)], of=l)
+    _sig("zkp_last_panic", C.c_char_p, [], of=l)
+    _sig("zkp_proof_serialize", _i64, [_vp, _i32, _vp, _i64], of=l)
+    _sig("zkp_r1cs_stats", _i32, [GoSlice, _vp], of=l)
+
+
+_bind_product(lib)
 
 
 def _slice(b: bytes):
@@ -155,11 +166,11 @@ def _take(ret: ProveReturn) -> bytes:
     return out
 
 
-def init_algorithm(algorithm_id: int, proving_key: bytes, r1cs: bytes) -> bool:
-    """lib.initAlgorithm(id, pk, r1cs)  (js/src/gnark/utils.ts:111-136)"""
+def init_algorithm(algorithm_id: int, proving_key: bytes, r1cs: bytes, lib=None) -> bool:
+    """lib.initAlgorithm(id, pk, r1cs)  (js/src/gnark/utils.ts:111-136); lib: another handle of the library (zk.testlib), default the drop-in"""
     s1, k1 = _slice(proving_key)
     s2, k2 = _slice(r1cs)
-    return bool(lib.InitAlgorithm(algorithm_id, s1, s2))
+    return bool((lib or globals()["lib"]).InitAlgorithm(algorithm_id, s1, s2))
 
 
 def prove_raw(request_json: bytes) -> bytes:
@@ -212,6 +223,15 @@ def prove_batch_raw(requests_json: bytes) -> bytes:
     return _take(lib.ProveBatch(s))
 
 
+def prove_batch_deterministic_raw(requests_json: bytes, r, s, randomize) -> bytes:
+    """ZkpProveBatchDeterministic: ProveBatch with one (r, s, randomize) triple per request of the array"""
+    sl, keep = _slice(requests_json)
+    le = lambda vals: _np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in vals), _np.uint8).copy()
+    rr, ss, nn = le(r), le(s), le(randomize)
+    assert len(rr) == len(ss) == len(nn)
+    return _take(lib.ZkpProveBatchDeterministic(sl, len(rr) // 32, rr.ctypes.data, ss.ctypes.data, nn.ctypes.data))
+
+
 def request_witness(request_json: bytes):
     """-> (algorithm id, witness assignment uint32[n], output bytes); raises ValueError(panic json)"""
     s, keep = _slice(request_json)
@@ -235,7 +255,10 @@ def r1cs_stats(r1cs: bytes):
 class ResidentBatch:
     """Device-resident batch of one algorithm (bench.py / parity tests)."""
 
-    def __init__(self, algorithm_id: int, inputs, r, s, randomize):
+    def __init__(self, algorithm_id: int, inputs, r, s, randomize, lib=None):
+        """lib: the library that holds the batch -- default the drop-in; zk.testlib (same objects + the kernel-level / debug entries,
+        its own algorithm registry: InitAlgorithm there first) for the tests that read solved wires back"""
+        lib = self.lib = lib or globals()["lib"]
         self.alg = algorithm_id
         self.inputs = _np.ascontiguousarray(inputs, _np.uint32)
         self.batch = self.inputs.shape[0]
@@ -247,7 +270,7 @@ class ResidentBatch:
 
     def step(self):
         t = _np.zeros(8, _np.float32)
-        if lib.zkp_bench_step(self.alg, t.ctypes.data) != 0:
+        if self.lib.zkp_bench_step(self.alg, t.ctypes.data) != 0:
             raise RuntimeError("zkp_bench_step failed")
         return dict(zip(("solve", "commit", "ntt", "msm_g1", "msm_g2", "finalize", "total", "z_segments"), [float(x) for x in t]))
 
@@ -255,34 +278,40 @@ class ResidentBatch:
         """n passes back to back, solve(k+1) overlapped with NTT+MSM(k); returns phase times of the last pass
         ('total' = whole call / n)"""
         t = _np.zeros(8, _np.float32)
-        if lib.zkp_bench_steps(self.alg, int(n), t.ctypes.data) != 0:
+        if self.lib.zkp_bench_steps(self.alg, int(n), t.ctypes.data) != 0:
             raise RuntimeError("zkp_bench_steps failed")
         return dict(zip(("solve", "commit", "ntt", "msm_g1", "msm_g2", "finalize", "total", "z_segments"), [float(x) for x in t]))
 
     def fetch(self):
         proofs = _np.zeros((self.batch, 384), _np.uint8)
         errs = _np.zeros(self.batch, _np.uint32)
-        if lib.zkp_bench_fetch(self.alg, proofs.ctypes.data, errs.ctypes.data) != 0:
+        if self.lib.zkp_bench_fetch(self.alg, proofs.ctypes.data, errs.ctypes.data) != 0:
             raise RuntimeError("zkp_bench_fetch failed")
         return proofs, errs
 
     def split_partials(self):
         """split mode (ZkpSetSplit): this rank's partial sums, [batch][384] uint8"""
         out = _np.zeros((self.batch, 384), _np.uint8)
-        if lib.zkp_split_partials(self.alg, out.ctypes.data) != 0:
+        if self.lib.zkp_split_partials(self.alg, out.ctypes.data) != 0:
             raise RuntimeError("zkp_split_partials failed")
         return out
 
     def split_finish(self, gathered):
         g = _np.ascontiguousarray(gathered, _np.uint8)
         assert g.ndim == 3 and g.shape[1:] == (self.batch, 384)
-        if lib.zkp_split_finish(self.alg, int(g.shape[0]), g.ctypes.data) != 0:
+        if self.lib.zkp_split_finish(self.alg, int(g.shape[0]), g.ctypes.data) != 0:
             raise RuntimeError("zkp_split_finish failed")
 
-    def debug(self, n_wires, domain):
-        wires = _np.zeros((self.batch, n_wires, 32), _np.uint8)
-        h = _np.zeros((self.batch, domain, 32), _np.uint8)
-        if lib.zkp_debug_fetch(self.alg, wires.ctypes.data, h.ctypes.data) != 0:
+    def debug(self, n_wires, domain, instances=None, want_h=True):
+        """solved wires [n][n_wires][32] and quotient-stage products [n][domain][32] of the listed instances (default: all) after a
+        step -- only on a batch that lives in the test library (lib=zk.testlib): the drop-in does not export the debug entries"""
+        if not hasattr(self.lib, "zkp_debug_fetch"):
+            raise RuntimeError("ResidentBatch.debug needs lib=zk.testlib (the drop-in library exports no debug entries)")
+        inst = None if instances is None else _np.ascontiguousarray(instances, _np.uint32)
+        n = self.batch if inst is None else len(inst)
+        wires = _np.zeros((n, n_wires, 32), _np.uint8)
+        h = _np.zeros((n, domain, 32), _np.uint8) if want_h else None
+        if self.lib.zkp_debug_fetch(self.alg, None if inst is None else inst.ctypes.data, n, wires.ctypes.data, None if h is None else h.ctypes.data) != 0:
             raise RuntimeError("zkp_debug_fetch failed")
         return wires, h
 

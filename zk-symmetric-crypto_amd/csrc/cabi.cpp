@@ -433,7 +433,7 @@ struct StreamFeed : ChunkFeed {
     }
 };
 
-std::string prove_batch_json(const char *data, size_t len) {
+std::string prove_batch_json(const char *data, size_t len, const U256 *r_fix = nullptr, const U256 *s_fix = nullptr, const U256 *rnd_fix = nullptr) {
     std::string result;
     try {
         std::vector<std::pair<size_t, size_t>> el;
@@ -471,7 +471,10 @@ std::string prove_batch_json(const char *data, size_t len) {
             }
             if (!items.empty()) {
                 try {
-                    auto out = prove_prepared(alg, items, nullptr, nullptr, nullptr);
+                    // caller-supplied blinding (ZkpProveBatchDeterministic): element i of the arrays belongs to request i
+                    std::vector<U256> rf, sf, nf;
+                    if (r_fix) for (size_t i : idx) { rf.push_back(r_fix[i]); sf.push_back(s_fix[i]); nf.push_back(rnd_fix[i]); }
+                    auto out = prove_prepared(alg, items, r_fix ? rf.data() : nullptr, r_fix ? sf.data() : nullptr, r_fix ? nf.data() : nullptr);
                     for (size_t k = 0; k < idx.size(); k++) res[idx[k]] = std::move(out[k]);
                 } catch (const Panic &p) {
                     for (size_t k = 0; k < idx.size(); k++) res[idx[k]] = p.json;
@@ -523,7 +526,10 @@ std::string prove_batch_json(const char *data, size_t len) {
                         sc.buf = g_chunk_pool.take(chunk, ni);
                         const size_t m = sc.idx.size();
                         for (size_t q = 0; q < m; q++) memcpy(sc.buf.raw + q * RAW_STRIDE, sc.prep[sc.idx[q]].raw.b, RAW_STRIDE);
-                        fr_random_fill(sc.buf.r, 3 * sc.buf.cap);           // r, s and the Randomize values: one entropy read per chunk
+                        if (r_fix) {
+                            for (size_t q = 0; q < m; q++) { const size_t i = sc.lo + sc.idx[q]; sc.buf.r[q] = r_fix[i]; sc.buf.s[q] = s_fix[i]; sc.buf.rnd[q] = rnd_fix[i]; }
+                        } else
+                            fr_random_fill(sc.buf.r, 3 * sc.buf.cap);       // r, s and the Randomize values: one entropy read per chunk
                         tl.add("prepare", k, -1, "end");
                         std::lock_guard<std::mutex> lk(feed.m);
                         feed.outstanding++;
@@ -693,6 +699,17 @@ U256 u256_from_le(const uint8_t *p) {
 
 // ---- test / benchmark hooks (C wrappers in test_api.hip: exported by the test library only) -------------------------------------
 namespace zk {
+// parity-test hooks on the current resident batch of an algorithm (wrappers zkp_debug_* in test_api.hip)
+void debug_leftovers(int id, long *out3) {
+    Algorithm *a = (id >= 0 && id < 3) ? get_alg(id) : nullptr;
+    if (!a || !a->res) throw ZkError("algorithm not initialised / nothing uploaded");
+    a->debug_leftovers(out3);
+}
+void debug_fetch(int id, const uint32_t *instances, size_t n, uint8_t *wires, uint8_t *h) {
+    Algorithm *a = (id >= 0 && id < 3) ? get_alg(id) : nullptr;
+    if (!a || !a->res) throw ZkError("algorithm not initialised / nothing uploaded");
+    a->debug_fetch(instances, n, wires, h);
+}
 // the two request decoders on one input: 1 = the scanner took it and agrees with the DOM reader field by field, 0 = the scanner
 // declined (the DOM reader decides alone), -1 = they DISAGREE (a bug)
 int request_decode_both(const char *p, size_t n) {
@@ -871,6 +888,15 @@ ProveReturn ZkpProveWitnessDeterministic(unsigned char algorithmID, GoSlice witn
 }
 
 ProveReturn ProveBatch(GoSlice params) { return make_return(prove_batch_json((const char *)params.data, (size_t)params.len)); }
+ProveReturn ZkpProveBatchDeterministic(GoSlice params, long n, const uint8_t *r32, const uint8_t *s32, const uint8_t *randomize32) {
+    // the arrays must cover every element of the request array: counted with the scanner ProveBatch itself uses
+    std::vector<std::pair<size_t, size_t>> el;
+    size_t off = 0;
+    bool not_array = false;
+    if (!r32 || !s32 || !randomize32 || n < 0 || !json_split_array((const char *)params.data, (size_t)params.len, el, off, not_array) || el.size() != (size_t)n)
+        return make_return(json_quote("ZkpProveBatchDeterministic: one (r, s, randomize) triple per request"));
+    return make_return(prove_batch_json((const char *)params.data, (size_t)params.len, (const U256 *)r32, (const U256 *)s32, (const U256 *)randomize32));
+}
 
 ProveReturn GenerateOPRFRequestData(GoSlice) { return make_return(json_quote("toprf is not supported by libzkprove")); }
 ProveReturn TOPRFFinalize(GoSlice) { return make_return(json_quote("toprf is not supported by libzkprove")); }
@@ -967,22 +993,6 @@ int zkp_quotient_msm_info(int id, long *info8) {
     for (const MsmBasesG1 *mb : {&a->pk.A, &a->pk.B1, &a->pk.K, &a->pk.ped, &a->pk.ped_sigma}) for (auto &cb : mb->wcomb) bytes += cb->table.bytes();
     for (auto &cb : a->pk.B2.wcomb) bytes += cb->table.bytes();
     info8[6] = pos; info8[7] = (long)(bytes >> 20);
-    return 0;
-    CABI_CATCH
-}
-int zkp_debug_leftovers(int id, long *out3) {
-    CABI_TRY
-    Algorithm *a = (id >= 0 && id < 3) ? get_alg(id) : nullptr;
-    if (!a || !a->res) throw ZkError("algorithm not initialised / nothing uploaded");
-    a->debug_leftovers(out3);
-    return 0;
-    CABI_CATCH
-}
-int zkp_debug_fetch(int id, uint8_t *wires, uint8_t *h) {
-    CABI_TRY
-    Algorithm *a = (id >= 0 && id < 3) ? get_alg(id) : nullptr;
-    if (!a || !a->res) throw ZkError("algorithm not initialised / nothing uploaded");
-    a->debug_fetch(wires, h);
     return 0;
     CABI_CATCH
 }

@@ -236,7 +236,7 @@ void MsmScratch::reserve_compact(size_t B_, size_t max_sparse_n) {
 }
 void MsmScratch::reserve_sums(size_t B_, size_t nb_g1, size_t nb_g2) {
     sums1.ensure(((B_ > VIRT_MIN ? B_ : VIRT_MIN) * nb_g1 + 1) * sizeof(G1X9) / sizeof(G1XYZZ) + 1);      // G1 bucket records are G1X9 (144 bytes) on the 9-limb path
-    sums2.ensure(((B_ <= SPARSE_SPLIT_MAX_B ? B_ * SPARSE_SPLIT : B_) * nb_g2 + 1) * sizeof(G2X9) / sizeof(G2XYZZ) + 1);      // (msm_sparse_split: 16 virtual instances per proof)
+    sums2.ensure((std::max<size_t>(B_, SPARSE_SPLIT * std::min(B_, SPARSE_SPLIT_MAX_B)) * nb_g2 + 1) * sizeof(G2X9) / sizeof(G2XYZZ) + 1);      // (msm_sparse_split: 16 virtual instances per proof, for every batch up to B_)
 }
 void MsmScratch::reserve(size_t B_, size_t max_entries, size_t max_nb, size_t max_part) {
     B = B_;
@@ -244,7 +244,11 @@ void MsmScratch::reserve(size_t B_, size_t max_entries, size_t max_nb, size_t ma
     const size_t Bm = B > VIRT_MIN ? B : VIRT_MIN;
     bucket_start.ensure(Bm * (max_nb + 1));
     part1.ensure(Bm * max_part + 1);
-    part2.ensure(std::max<size_t>(B <= TINY_BATCH ? 2 * B : B, B <= SPARSE_SPLIT_MAX_B ? B * SPARSE_SPLIT : 0) * max_part + 1);      // (one-proof batches: part_stride_for, msm_sparse_split)
+    // Reservations only grow, and a scratch reserved for B serves every batch up to B: rows for the largest need of ANY of them -- B
+    // itself, twice the instances of a tiny batch (part_stride_for: the finer bucket reduction of batches <= TINY_BATCH needs up to
+    // twice the partial slots per instance), SPARSE_SPLIT virtual instances per proof of a split batch (msm_sparse_split).  (Sized by
+    // the reserving batch alone, a first call of 9..15 proofs left a later batch of 8 without room: "msm scratch too small".)
+    part2.ensure(std::max({B, 2 * std::min(B, TINY_BATCH), SPARSE_SPLIT * std::min(B, SPARSE_SPLIT_MAX_B)}) * max_part + 1);
     vout1.ensure(VIRT_MIN + 1);                                          // (msm_sparse_split)
     vout2.ensure(VIRT_MIN + 1);
 }

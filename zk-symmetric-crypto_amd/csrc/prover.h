@@ -145,7 +145,7 @@ class Algorithm {
     void resident_prove(PhaseTimes *times);                  // one batch, one stream
     void resident_prove_pipelined(int nsteps, PhaseTimes *times);   // timed region of bench.py: solve(k+1) under NTT+MSM(k)
     void resident_download(ProofPoints *out, uint32_t *errs);
-    void debug_fetch(uint8_t *wires_out, uint8_t *h_out);   // parity tests
+    void debug_fetch(const uint32_t *instances, size_t n, uint8_t *wires_out, uint8_t *h_out);   // parity tests (nullptr: every instance)
 
     size_t n_inputs() const { return prog.n_inputs; }
     size_t max_chunk = 1024;

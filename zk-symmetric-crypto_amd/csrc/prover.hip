@@ -420,6 +420,7 @@ __global__ __launch_bounds__(320) void k_finalize_stage2_pipe(const G1Affine *__
             if (i >= RING) {
                 const int a0 = i & 1;                          // the adders of this slot's parity
                 while (consumed[a0] < i - RING + 1 || consumed[2 + a0] < i - RING + 1) __builtin_amdgcn_s_sleep(1);
+                __threadfence_block();                         // acquire: the slot is overwritten only after the adders' reads of it
             }
             if (live) ring[i % RING][ll] = D;
             __threadfence_block();
@@ -432,6 +433,7 @@ __global__ __launch_bounds__(320) void k_finalize_stage2_pipe(const G1Affine *__
         G1XYZZ acc = G1XYZZ::inf();
         for (int i = par; i < 128; i += 2) {
             while (produced <= i) __builtin_amdgcn_s_sleep(1);
+            __threadfence_block();                             // acquire: the ring read below may not move above the poll of `produced`
             const uint32_t bit = ((half ? k2[i >> 5] : k1[i >> 5]) >> (i & 31)) & 1u;
             if (bit && live && split) {
                 const G1XYZZ D = ring[i % RING][ll];
@@ -1555,31 +1557,38 @@ void Algorithm::prove_stream(ChunkFeed &feed, PhaseTimes *times) {
 }
 
 // parity-test hook: solved wires and quotient-stage products (A*B on the coset g<w>, natural order) of the last resident
-// batch, canonical form
-void Algorithm::debug_fetch(uint8_t *wires_out, uint8_t *h_out) {
+// batch, canonical form; instances == nullptr: all B of them, else the n listed ones (wires_out [n][n_wires][32], h_out [n][N][32])
+__global__ __launch_bounds__(256) void k_debug_gather(const Fr *__restrict__ src, size_t rows, size_t B, const uint32_t *__restrict__ inst, size_t n, Fr *__restrict__ out,
+                                                      const Fr *__restrict__ mul) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * n) return;
+    const size_t k = i / rows, row = i % rows;
+    const size_t b = inst ? inst[k] : k;
+    Fr v = src[row * B + b];
+    if (mul) v = v * mul[row * B + b];
+    out[k * rows + row] = v.from_mont();
+}
+void Algorithm::debug_fetch(const uint32_t *instances, size_t n, uint8_t *wires_out, uint8_t *h_out) {
     DeviceScope on_device(device);
     Resident &R = *res;
     const size_t B = R.B, nw = prog.n_wires, N = (size_t)1 << prog.log_domain;
-    std::vector<Fr> tmp;
-    auto fetch = [&](const Fr *src, size_t rows) {
-        DevBuf<Fr> d(rows * B);
-        ZK_HIP(hipMemcpy(d.p, src, rows * B * sizeof(Fr), hipMemcpyDeviceToDevice));
-        fr_from_mont(d.p, rows * B, 0);
-        tmp.resize(rows * B);
-        ZK_HIP(hipMemcpy(tmp.data(), d.p, rows * B * sizeof(Fr), hipMemcpyDeviceToHost));
+    if (!instances) n = B;
+    DevBuf<uint32_t> dinst(n ? n : 1);
+    if (instances) {
+        for (size_t i = 0; i < n; i++) if (instances[i] >= B) throw ZkError("debug_fetch: instance out of range");
+        ZK_HIP(hipMemcpy(dinst.p, instances, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    const SolverBuffers &sb = R.set[R.last_set].sb;
+    auto fetch = [&](const Fr *src, const Fr *mul, size_t rows, uint8_t *out) {
+        DevBuf<Fr> d(rows * n);
+        hipLaunchKernelGGL(k_debug_gather, dim3(ceil_div(rows * n, 256)), dim3(256), 0, 0, src, rows, B, instances ? dinst.p : (const uint32_t *)nullptr, n, d.p, mul);
+        ZK_HIP(hipGetLastError());
+        ZK_HIP(hipMemcpy(out, d.p, rows * n * sizeof(Fr), hipMemcpyDeviceToHost));
     };
-    if (wires_out) {
-        fetch(R.set[0].sb.wires.p, nw);
-        for (size_t b = 0; b < B; b++)
-            for (size_t w = 0; w < nw; w++) memcpy(wires_out + (b * nw + w) * 32, &tmp[w * B + b], 32);
-    }
-    if (h_out) {   // instance-major products f = A*B on the coset, as left in c by enqueue_main (the comb path never forms them: done here)
-        if (R.used_comb) { fr_transpose_mul(R.set[0].sb.a.p, R.set[0].sb.b.p, R.set[0].sb.c.p, N, B, N, 0); ZK_HIP(hipDeviceSynchronize()); }
-        DevBuf<Fr> d(N * B);
-        ZK_HIP(hipMemcpy(d.p, R.set[0].sb.c.p, N * B * sizeof(Fr), hipMemcpyDeviceToDevice));
-        fr_from_mont(d.p, N * B, 0);
-        ZK_HIP(hipMemcpy(h_out, d.p, N * B * sizeof(Fr), hipMemcpyDeviceToHost));
-    }
+    if (wires_out) fetch(sb.wires.p, nullptr, nw, wires_out);
+    // the products f = A*B on the coset: a and b hold the coset evaluations after every path (the bucket path's instance-major copy in
+    // c is the same numbers transposed)
+    if (h_out) fetch(sb.a.p, sb.b.p, N, h_out);
 }
 
 // -------------------------------------------------------------------------- serialisation

@@ -299,6 +299,7 @@ void SolverProgram::build(const R1cs &cs, hipStream_t s) {
             if (prg[off[i]] == OP_COUNT) lv.narrow = false;      // a countHint wants the whole device
         levels.push_back(lv);
     }
+    prg.resize(prg.size() + 16, 0);          // k_solve_narrow_run's prefetcher reads 16-word strides of a record whatever its opcode: the last record must not end the buffer
     prog.upload(prg.data(), prg.size(), s);
     instr_off.upload(off.data(), off.size(), s);
     level_instr.upload(li.data(), li.size(), s);

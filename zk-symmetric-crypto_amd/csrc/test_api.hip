@@ -790,6 +790,21 @@ extern "C" int zkp_bsb22_challenge_host(const uint8_t *com_be64, long n, uint8_t
 namespace zk {
 int request_decode_both(const char *p, size_t n);
 int host_stage_bench(const char *data, size_t len, int iters, double *out);
+void debug_leftovers(int id, long *out3);
+void debug_fetch(int id, const uint32_t *instances, size_t n, uint8_t *wires, uint8_t *h);
+}
+// ---- parity-test views of the current resident batch (state of THIS library: the batch must have been uploaded and stepped through it)
+extern "C" int zkp_debug_leftovers(int id, long *out3) {
+    ZKP_TRY
+    zk::debug_leftovers(id, out3);
+    return 0;
+    ZKP_CATCH(-1)
+}
+extern "C" int zkp_debug_fetch(int id, const uint32_t *instances, long n, uint8_t *wires, uint8_t *h) {
+    ZKP_TRY
+    zk::debug_fetch(id, instances, (size_t)(n < 0 ? 0 : n), wires, h);
+    return 0;
+    ZKP_CATCH(-1)
 }
 // 1: the single-pass scanner took the request and agrees with the DOM reader, 0: it declined, -1: the two disagree
 extern "C" int zkp_request_decode_both(const uint8_t *json, long len) { return zk::request_decode_both((const char *)json, (size_t)(len < 0 ? 0 : len)); }
