@@ -144,10 +144,17 @@ def test_msm_g1_dense_path_matches_oracle(zk, oracle, n, batch, c):
 
 
 @pytest.mark.parametrize("n,batch,k,mode", [(1, 1, 4, 0), (5, 3, 2, 0), (37, 3, 5, 0), (300, 65, 8, 1), (1000, 2, 16, 0), (2500, 130, 11, 1), (4099, 1, 13, 0),
-                                             (1000, 3, 16, 1), (900, 66, 19, 1), (530, 2, 18, 1)])
+                                             (1000, 3, 16, 1), (900, 66, 19, 1), (530, 2, 18, 1),
+                                             # mixed tables (mode >> 8 = n1 leading clumps of k + 1 bases; CombShape::n1): both segments with a
+                                             # short last clump, every clump large, one large clump, register-form patterns at k + 1 = 17..21
+                                             (100, 3, 5, 0 | (7 << 8)), (100, 5, 5, 1 | (16 << 8)), (37, 2, 3, 0 | (1 << 8)), (2500, 70, 11, 1 | (100 << 8)),
+                                             (700, 3, 16, 1 | (20 << 8)), (400, 17, 19, 1 | (9 << 8)), (260, 2, 20, 1 | (5 << 8)),
+                                             # lanes = (plane, proof) pairs: batches that are not a multiple of 64, and clump counts large enough
+                                             # for more than 8 ranges per pair (the in-place range levels of the fold)
+                                             (9000, 1, 4, 0), (9000, 5, 5, 1), (7000, 16, 3, 1 | (900 << 8)), (5000, 33, 4, 0)])
 def test_msm_comb_matches_oracle(zk, oracle, n, batch, k, mode):
     """quotient MSM of large batches: fixed-base bit-plane comb (csrc/msm_comb.hip) -- clumps of k bases incl. a short last clump,
-    signed subset-sum tables of the halved bases, one accumulator per (proof, bit plane, clump range), Horner fold"""
+    signed subset-sum tables of the halved bases, one accumulator per (plane, proof, clump range), range levels, Horner fold"""
     rng = np.random.default_rng(8100 + n + k)
     pts = oracle.g1_fixed_base(_rand_fr(rng, n))
     sc = np.stack([_rand_fr(rng, n) for _ in range(batch)])

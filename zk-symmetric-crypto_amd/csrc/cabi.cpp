@@ -10,6 +10,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <chrono>
 #include "../../include/zkprove.h"
 #include "prover.h"
@@ -142,7 +143,23 @@ bool release_neighbours(Algorithm *self) {
 // (being initialised or reset right now) is counted as it was.
 std::atomic<int> g_loaded_on[64];
 int loaded_on_device(int device) { return g_loaded_on[device & 63].load(); }
-const bool g_hook_set = [] { Algorithm::neighbours_release = release_neighbours; Algorithm::loaded_on_device = loaded_on_device; return true; }();
+// Algorithm::peers_visit: fn(peer) for every OTHER replica the registry holds on self's device (the comb-table budget looks at what its
+// neighbours hold and will still allocate, Algorithm::comb_prepare).  False when a slot was busy (being initialised / reset): the caller
+// then knows its picture is incomplete.  The slot locks are held while fn runs, so a peer cannot be reset under it.
+bool peers_visit(Algorithm *self, const std::function<void(Algorithm *)> &fn) {
+    bool complete = true;
+    for (auto &slot : g_slots) {
+        std::unique_lock<std::mutex> lk(slot.lock, std::try_to_lock);
+        if (!lk) { complete = false; continue; }
+        for (auto &r : slot.replicas)
+            if (r.get() != self && r->device == self->device) fn(r.get());
+    }
+    return complete;
+}
+const bool g_hook_set = [] {
+    Algorithm::neighbours_release = release_neighbours; Algorithm::loaded_on_device = loaded_on_device; Algorithm::peers_visit = peers_visit;
+    return true;
+}();
 // one decoded request with its witness assignment and cipher output (or the panic value it produced)
 struct Prepared {
     int alg = -1;
@@ -981,6 +998,7 @@ int zkp_quotient_msm_info(int id, long *info8) {
     if (!a || !a->res) throw ZkError("algorithm not initialised / nothing uploaded");
     if (a->comb_active()) {
         const CombBases &cb = a->pk.Zcomb;
+        // (mixed clump sizes, CombShape::n1: [1] = the smaller size k; [2] clumps in all -- n1 = bases - clumps * k up to the last clump's slack)
         info8[0] = 1; info8[1] = cb.k; info8[2] = (long)cb.nclumps; info8[3] = (long)(cb.table.bytes() >> 20); info8[4] = (long)cb.nclumps * 254;
     } else {
         const MsmBasesG1 &z = a->pk.Z;

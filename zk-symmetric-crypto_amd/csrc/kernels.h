@@ -34,8 +34,15 @@ void fr_from_mont(Fr *a, size_t total, hipStream_t s);
 // 2^261-Montgomery words, of the HALVED bases), see msm_comb.hip.  Used for the quotient MSM of large batches (T = 254 planes, scalars
 // = products formed on the fly) and, per width class, for the wire positions of the AES circuits that are not 0 / +-1 (MsmBases::wcomb).
 struct CombShape {
-    size_t n = 0, nclumps = 0, E = 0;      // bases, clumps, entries per clump
+    size_t n = 0, nclumps = 0, E = 0;      // bases, clumps, entries per clump of size k
     int k = 0, T = 254;                    // clump size, bit planes
+    // Mixed clump sizes (quotient tables; the memory budget is filled to the last GiB, Algorithm::comb_prepare): the FIRST n1 clumps hold
+    // k + 1 bases and 2E entries each, the rest k bases and E entries.  Clump c starts at base c*k + min(c, n1) and at table entry
+    // (c + min(c, n1)) * E.  n1 == 0: one size throughout (the wire combs).
+    size_t n1 = 0;
+    size_t clump_base(size_t c) const { return c * (size_t)k + (c < n1 ? c : n1); }
+    size_t clump_entry(size_t c) const { return (c + (c < n1 ? c : n1)) * E; }
+    size_t entries() const { return (nclumps + n1) * E; }
     DevBuf<uint32_t> rows;                 // wire comb: row of base j in the [row][B] scalar matrix
     DevBuf<uint32_t> base_index;           // wire comb: index of base j in the owning MsmBases (for the bucket-pipeline hand-over)
     bool ok = false;
@@ -43,7 +50,7 @@ struct CombShape {
 };
 template <class F>
 struct CombBasesT : CombShape {
-    DevBuf<Affine<F>> table;               // [nclumps][E]
+    DevBuf<Affine<F>> table;               // [nclumps][E] (clump_entry(c): the first n1 clumps take 2E)
     DevBuf<Affine<F>> corr;                // (2^T - 1) * sum P_i / 2: the constant of the signed-bit form
 };
 using CombBases = CombBasesT<Fp>;
@@ -53,12 +60,17 @@ struct CombScratch {
     void reserve(const CombBases &cb, size_t B, int nslots);
 };
 size_t comb_table_bytes(size_t n, int k);
+// mixed sizes: n1 clumps of k + 1 bases, the rest of k (n1 * (k + 1) <= n): clumps and table bytes
+size_t comb_mixed_clumps(size_t n, int k, size_t n1);
+size_t comb_mixed_bytes(size_t n, int k, size_t n1);
+// the largest n1 whose mixed table fits `bytes` (0 when not even the pure-k table does: the caller checks comb_table_bytes first)
+size_t comb_mixed_fit(size_t n, int k, size_t bytes);
 size_t comb_pattern_words(const CombShape &cb, size_t B);
 size_t comb_acc_bytes(const CombShape &cb, size_t B, size_t x9_bytes);
 size_t comb_r1_bytes(const CombShape &cb, size_t B, size_t x9_bytes);
 // (bases at infinity and clumps whose subset sums cancel or coincide are tabulated by the complete addition rules; has_inf then makes
 // the walk skip the entries at infinity)
-bool comb_build(CombBases &cb, const G1Affine *d_points, size_t n, int k, hipStream_t s);
+bool comb_build(CombBases &cb, const G1Affine *d_points, size_t n, int k, hipStream_t s, size_t n1 = 0);
 bool comb_build_planes(CombBasesT<Fp> &cb, const G1Affine *d_points, size_t n, int k, int T, hipStream_t s);
 bool comb_build_planes(CombBasesT<Fp2> &cb, const G2Affine *d_points, size_t n, int k, int T, hipStream_t s);
 // scalars x[row][B] (y == nullptr) or the products x * y, Montgomery form -> pat

@@ -169,32 +169,54 @@ size_t comb_table_bytes(size_t n, int k) {
     const size_t nclumps = (n + k - 1) / k;
     return nclumps * ((size_t)1 << (k - 1)) * sizeof(G1Affine);
 }
+size_t comb_mixed_clumps(size_t n, int k, size_t n1) {
+    const size_t rest = n - n1 * (size_t)(k + 1);
+    return n1 + (rest + k - 1) / k;
+}
+size_t comb_mixed_bytes(size_t n, int k, size_t n1) { return (comb_mixed_clumps(n, k, n1) + n1) * ((size_t)1 << (k - 1)) * sizeof(G1Affine); }
+size_t comb_mixed_fit(size_t n, int k, size_t bytes) {
+    size_t lo = 0, hi = n / (size_t)(k + 1);           // bytes grow with n1: bisection
+    if (comb_mixed_bytes(n, k, hi) <= bytes) return hi;
+    while (lo + 1 < hi) {
+        const size_t mid = (lo + hi) / 2;
+        if (comb_mixed_bytes(n, k, mid) <= bytes) lo = mid; else hi = mid;
+    }
+    return comb_mixed_bytes(n, k, lo) <= bytes ? lo : 0;
+}
 
 template <class F>
-static bool comb_build_impl(CombBasesT<F> &cb, const Affine<F> *d_points, size_t n, int k, int T, hipStream_t s) {
+static bool comb_build_impl(CombBasesT<F> &cb, const Affine<F> *d_points, size_t n, int k, int T, hipStream_t s, size_t n1 = 0) {
     cb.ok = false;
-    if (n == 0 || k < 2 || k > COMB_KMAX || T < 1 || T > COMB_T) return false;
-    cb.n = n; cb.k = k; cb.T = T;
-    cb.nclumps = (n + k - 1) / k;
+    if (n == 0 || k < 2 || k + (n1 ? 1 : 0) > COMB_KMAX || T < 1 || T > COMB_T || n1 * (size_t)(k + 1) > n) return false;
+    cb.n = n; cb.k = k; cb.T = T; cb.n1 = n1;
+    cb.nclumps = comb_mixed_clumps(n, k, n1);
     cb.E = (size_t)1 << (k - 1);
     DevBuf<Affine<F>> half(n);
     DevBuf<uint32_t> bad(1);
     bad.zero(s);
     hipLaunchKernelGGL(k_comb_halve<F>, dim3(ceil_div(n, 64)), dim3(64), 0, s, d_points, n, half.p, bad.p);
-    cb.table.alloc(cb.nclumps * cb.E);
+    cb.table.alloc(cb.entries());
     cb.corr.alloc(1);
-    hipLaunchKernelGGL(k_comb_seed<F>, dim3(ceil_div(cb.nclumps, 256)), dim3(256), 0, s, half.p, n, k, cb.nclumps, cb.E, cb.table.p);
     constexpr int G = sizeof(F) == 32 ? 4 : 1;              // clumps per build thread (register budget)
-    const size_t ngroups = (cb.nclumps + G - 1) / G;
-    for (int j = 0; j + 1 < k; j++)
-        hipLaunchKernelGGL((k_comb_level<F, G>), dim3(ceil_div(ngroups << j, 64)), dim3(64), 0, s, cb.table.p, half.p, n, k, cb.nclumps, cb.E, j, bad.p);
+    // one segment of equally sized clumps: `nc` clumps of `kk` bases (the last may be shorter) over the `ns` points at hp, table at tp
+    auto segment = [&](Affine<F> *tp, const Affine<F> *hp, size_t ns, int kk, size_t nc) {
+        if (!nc) return;
+        const size_t Es = (size_t)1 << (kk - 1);
+        hipLaunchKernelGGL(k_comb_seed<F>, dim3(ceil_div(nc, 256)), dim3(256), 0, s, hp, ns, kk, nc, Es, tp);
+        const size_t ngroups = (nc + G - 1) / G;
+        for (int j = 0; j + 1 < kk; j++)
+            hipLaunchKernelGGL((k_comb_level<F, G>), dim3(ceil_div(ngroups << j, 64)), dim3(64), 0, s, tp, hp, ns, kk, nc, Es, j, bad.p);
+        // the last clump may be shorter: its unused entries are never indexed (zeroed so that the scaling below reads defined memory)
+        const size_t last_kc = ns - (nc - 1) * (size_t)kk;
+        if (last_kc < (size_t)kk)
+            ZK_HIP(hipMemsetAsync(tp + (nc - 1) * Es + ((size_t)1 << (last_kc - 1)), 0, (Es - ((size_t)1 << (last_kc - 1))) * sizeof(Affine<F>), s));
+    };
+    const size_t nb1 = n1 * (size_t)(k + 1);
+    segment(cb.table.p, half.p, nb1, k + 1, n1);
+    segment(cb.table.p + cb.clump_entry(n1), half.p + nb1, n - nb1, k, cb.nclumps - n1);
     hipLaunchKernelGGL(k_comb_correction<F>, dim3(1), dim3(128), 0, s, half.p, n, T, cb.corr.p);
-    // the last clump may be shorter: its unused entries are never indexed (zeroed so that the scaling below reads defined memory)
     const size_t per_point = sizeof(Affine<F>) / sizeof(Fp);
-    const size_t coords = cb.nclumps * cb.E * per_point;
-    const size_t last_kc = n - (cb.nclumps - 1) * (size_t)k;
-    if (last_kc < (size_t)k)
-        ZK_HIP(hipMemsetAsync(cb.table.p + (cb.nclumps - 1) * cb.E + ((size_t)1 << (last_kc - 1)), 0, (cb.E - ((size_t)1 << (last_kc - 1))) * sizeof(Affine<F>), s));
+    const size_t coords = cb.entries() * per_point;
     hipLaunchKernelGGL(k_comb_to_f9, dim3(ceil_div(coords, 256)), dim3(256), 0, s, (Fp *)cb.table.p, coords);
     ZK_HIP(hipGetLastError());
     uint32_t nbad = 0;
@@ -204,7 +226,7 @@ static bool comb_build_impl(CombBasesT<F> &cb, const Affine<F> *d_points, size_t
     cb.ok = true;
     return true;
 }
-bool comb_build(CombBases &cb, const G1Affine *d_points, size_t n, int k, hipStream_t s) { return comb_build_impl<Fp>(cb, d_points, n, k, COMB_T, s); }
+bool comb_build(CombBases &cb, const G1Affine *d_points, size_t n, int k, hipStream_t s, size_t n1) { return comb_build_impl<Fp>(cb, d_points, n, k, COMB_T, s, n1); }
 bool comb_build_planes(CombBasesT<Fp> &cb, const G1Affine *d_points, size_t n, int k, int T, hipStream_t s) { return comb_build_impl<Fp>(cb, d_points, n, k, T, s); }
 bool comb_build_planes(CombBasesT<Fp2> &cb, const G2Affine *d_points, size_t n, int k, int T, hipStream_t s) { return comb_build_impl<Fp2>(cb, d_points, n, k, T, s); }
 
@@ -253,8 +275,11 @@ __device__ __forceinline__ void comb_transpose32(uint32_t (&a)[32]) {
 }
 // Quotient patterns with the clump's K products held in REGISTERS (8 K words; the LDS form below parks them in 32 K bytes per lane,
 // which leaves one wavefront per SIMD) and the bit planes extracted by the transpose above.  K = compile-time clump size.
+// One segment of equally sized clumps per launch (mixed tables, CombShape::n1): blockIdx.y = clump within the segment, whose `n` bases
+// start at row base0 of the matrices and whose first clump is clump0 of the table.
 template <int K>
-__global__ __launch_bounds__(64) void k_comb_patterns_reg(const Fr *__restrict__ x, const Fr *__restrict__ y, size_t B, size_t n, uint32_t *__restrict__ pat) {
+__global__ __launch_bounds__(64) void k_comb_patterns_reg(const Fr *__restrict__ x, const Fr *__restrict__ y, size_t B, size_t n, size_t base0, size_t clump0,
+                                                          uint32_t *__restrict__ pat) {
     const size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
     const size_t c = blockIdx.y;
     const int kc = (int)zmin((size_t)K, n - c * K);
@@ -263,7 +288,7 @@ __global__ __launch_bounds__(64) void k_comb_patterns_reg(const Fr *__restrict__
 #pragma unroll
     for (int j = 0; j < K; j++) {
         if (j < kc) {
-            const size_t row = c * K + j;
+            const size_t row = base0 + c * K + j;
             const Fr s = (x[row * B + b] * y[row * B + b]).from_mont();
 #pragma unroll
             for (int w = 0; w < 8; w++) sw[j][w] = s.l[w];
@@ -273,7 +298,7 @@ __global__ __launch_bounds__(64) void k_comb_patterns_reg(const Fr *__restrict__
         }
     }
     const uint32_t low_mask = (1u << (kc - 1)) - 1u;
-    uint32_t *out = pat + (c * COMB_T) * B + b;
+    uint32_t *out = pat + ((clump0 + c) * COMB_T) * B + b;
 #pragma unroll
     for (int w = 0; w < 8; w++) {
         uint32_t a[32];
@@ -293,7 +318,8 @@ __global__ __launch_bounds__(64) void k_comb_patterns_reg(const Fr *__restrict__
     }
 }
 //   y == nullptr: scalars = x[row * B + b];  else the quotient products x[row * B + b] * y[row * B + b] (Montgomery, [row][B])
-__global__ __launch_bounds__(64) void k_comb_patterns(const Fr *__restrict__ x, const Fr *__restrict__ y, size_t B, size_t n, int k, uint32_t *__restrict__ pat) {
+__global__ __launch_bounds__(64) void k_comb_patterns(const Fr *__restrict__ x, const Fr *__restrict__ y, size_t B, size_t n, int k, size_t base0, size_t clump0,
+                                                      uint32_t *__restrict__ pat) {
     extern __shared__ uint32_t lds[];
     const size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
     const size_t c = blockIdx.y;
@@ -301,14 +327,14 @@ __global__ __launch_bounds__(64) void k_comb_patterns(const Fr *__restrict__ x, 
     const int kc = (int)zmin((size_t)k, n - c * k);
     if (b >= B) return;
     for (int j = 0; j < kc; j++) {
-        const size_t row = c * k + j;
+        const size_t row = base0 + c * k + j;
         Fr s = x[row * B + b];
         if (y) s = s * y[row * B + b];
         s = s.from_mont();
 #pragma unroll
         for (int w = 0; w < 8; w++) lds[(j * 8 + w) * 64 + lane] = s.l[w];
     }
-    comb_emit_patterns(lds, lane, kc, COMB_T, 8, B, pat + (c * COMB_T) * B + b);
+    comb_emit_patterns(lds, lane, kc, COMB_T, 8, B, pat + ((clump0 + c) * COMB_T) * B + b);
 }
 // wire scalars: base j of the comb reads row rows[j] of the [row][B] matrix.  A value that does not fit the comb's T bit planes (the
 // position was calibrated narrower than this instance's value) enters the comb as 0 and is appended to the instance's compact list
@@ -353,21 +379,24 @@ __global__ __launch_bounds__(64) void k_comb_patterns_rows(const Fr *__restrict_
 #define ZK_COMB_BOUNDS(F) (sizeof(F) == 64 ? 2 : ZK_COMB_WAVES)
 template <class F, bool MAY_INF>
 __global__ __launch_bounds__(64, ZK_COMB_BOUNDS(F)) void k_comb_walk(const Affine<F> *__restrict__ table, const uint32_t *__restrict__ pat, size_t B, size_t nclumps, size_t E,
-                                                                    int T, uint32_t Q, typename Nine<F>::X9 *__restrict__ acc_out) {
+                                                                    int T, uint32_t Q, size_t n1, typename Nine<F>::X9 *__restrict__ acc_out) {
     using F9 = typename Nine<F>::F9;
     using X9 = typename Nine<F>::X9;
-    const size_t tiles = (B + 63) / 64;
+    // lanes = 64 consecutive (plane, proof) pairs of one clump range: f = t * B + b.  With B a multiple of 64 a wavefront holds 64 proofs
+    // of one plane; a small batch fills its wavefronts with several planes (B = 16: four) instead of leaving 48 lanes idle -- the
+    // pattern words of a clump are [T][B], so the read stays one contiguous segment either way
+    const size_t TB = (size_t)T * B, tiles = (TB + 63) / 64;
     const size_t blk = blockIdx.x;
-    const size_t bt = blk % tiles, t = (blk / tiles) % T, q = blk / (tiles * T);
-    const size_t b = bt * 64 + threadIdx.x;
-    if (b >= B) return;
+    const size_t q = blk / tiles, f = (blk % tiles) * 64 + threadIdx.x;
+    if (f >= TB) return;
     const size_t c0 = nclumps * q / Q, c1 = nclumps * (q + 1) / Q;
     X9 acc = X9::inf();
     if (c0 < c1) {
-        const uint32_t *pp = pat + (c0 * T + t) * B + b;
-        const size_t pstride = (size_t)T * B;
+        const uint32_t *pp = pat + c0 * TB + f;
+        const size_t pstride = TB;
         uint32_t e = *pp;
-        Affine<F> p = table[c0 * E + (e & 0x7fffffffu)];
+        // clump c starts at entry (c + min(c, n1)) * E: the first n1 clumps hold one base more and twice the entries (wave-uniform: SALU)
+        Affine<F> p = table[(c0 + zmin(c0, n1)) * E + (e & 0x7fffffffu)];
         for (size_t c = c0;;) {
             // only the next pattern WORD is fetched ahead; the table entry is loaded just in time (a point held across the addition
             // costs 16 live registers = a wavefront per SIMD, msm.hip accumulate_body)
@@ -377,15 +406,16 @@ __global__ __launch_bounds__(64, ZK_COMB_BOUNDS(F)) void k_comb_walk(const Affin
             if (++c >= c1) break;
             pp += pstride;
             e = e_next;
-            p = table[c * E + (e & 0x7fffffffu)];
+            p = table[(c + zmin(c, n1)) * E + (e & 0x7fffffffu)];
         }
     }
-    acc_out[(q * T + t) * B + b] = acc;
+    acc_out[q * TB + f] = acc;
 }
 
 // fold, stage 1: thread (g, b): Horner over the bit planes 8g+7 .. 8g of proof b (each plane = the sum of its Q range accumulators)
 template <class F>
-__global__ __launch_bounds__(64, ZK_COMB_BOUNDS(F)) void k_comb_fold1(const typename Nine<F>::X9 *__restrict__ acc, size_t B, int T, uint32_t Q, typename Nine<F>::X9 *__restrict__ r1) {
+__global__ __launch_bounds__(64, ZK_COMB_BOUNDS(F)) void k_comb_fold1(const typename Nine<F>::X9 *__restrict__ acc, size_t B, int T, uint32_t Q, uint32_t qstride,
+                                                                     typename Nine<F>::X9 *__restrict__ r1) {
     using X9 = typename Nine<F>::X9;
     const size_t tiles = (B + 63) / 64;
     const size_t g = blockIdx.x / tiles, b = (blockIdx.x % tiles) * 64 + threadIdx.x;
@@ -396,9 +426,24 @@ __global__ __launch_bounds__(64, ZK_COMB_BOUNDS(F)) void k_comb_fold1(const type
     for (int t = t1 - 1; t >= t0; t--) {
         r = X9::dbl_of(r);
 #pragma unroll 1
-        for (uint32_t q = 0; q < Q; q++) r.add(acc[((size_t)q * T + t) * B + b]);
+        for (uint32_t q = 0; q < Q; q++) r.add(acc[((size_t)q * qstride * T + t) * B + b]);
     }
     r1[g * B + b] = r;
+}
+// fold, stage 0 (small batches: many clump ranges per plane so that the walk still fills the device): thread (f, j) sums the range
+// accumulators (8j + i) * stride, i < 8, of pair f = (plane, proof) into slot 8j * stride -- its own first slot, so the pass is in
+// place; repeated until at most 8 slots per pair are left.  7 dependent additions per level instead of Q per plane in stage 1.
+template <class F>
+__global__ __launch_bounds__(64, ZK_COMB_BOUNDS(F)) void k_comb_fold_ranges(typename Nine<F>::X9 *__restrict__ acc, size_t TB, uint32_t Q, uint32_t stride) {
+    using X9 = typename Nine<F>::X9;
+    const size_t tiles = (TB + 63) / 64;
+    const size_t j = blockIdx.x / tiles, f = (blockIdx.x % tiles) * 64 + threadIdx.x;
+    if (f >= TB) return;
+    const uint32_t q0 = (uint32_t)j * 8;
+    X9 r = acc[(size_t)q0 * stride * TB + f];
+#pragma unroll 1
+    for (uint32_t i = 1; i < 8 && q0 + i < Q; i++) r.add(acc[(size_t)(q0 + i) * stride * TB + f]);
+    acc[(size_t)q0 * stride * TB + f] = r;
 }
 // stage 2: thread b: Horner over the partial results (8 doublings apart), + the constant of the signed-bit form; out[b * out_stride]
 template <class F>
@@ -426,7 +471,7 @@ __global__ __launch_bounds__(64, ZK_COMB_BOUNDS(F)) void k_comb_fold2(const type
 // both fold stages in one launch for the narrow width classes of the wire combs (T = 8 / 32 planes: at most 32 doublings per proof):
 // thread b: Horner over ALL planes, each plane the sum of its Q range accumulators, + the constant
 template <class F>
-__global__ __launch_bounds__(64, ZK_COMB_BOUNDS(F)) void k_comb_fold_narrow(const typename Nine<F>::X9 *__restrict__ acc, size_t B, int T, uint32_t Q,
+__global__ __launch_bounds__(64, ZK_COMB_BOUNDS(F)) void k_comb_fold_narrow(const typename Nine<F>::X9 *__restrict__ acc, size_t B, int T, uint32_t Q, uint32_t qstride,
                                                                            const Affine<F> *__restrict__ corr, XYZZ<F> *__restrict__ out, size_t out_stride) {
     using F9 = typename Nine<F>::F9;
     using X9 = typename Nine<F>::X9;
@@ -437,7 +482,7 @@ __global__ __launch_bounds__(64, ZK_COMB_BOUNDS(F)) void k_comb_fold_narrow(cons
     for (int t = T - 1; t >= 0; t--) {
         r = X9::dbl_of(r);
 #pragma unroll 1
-        for (uint32_t q = 0; q < Q; q++) r.add(acc[((size_t)q * T + t) * B + b]);
+        for (uint32_t q = 0; q < Q; q++) r.add(acc[((size_t)q * qstride * T + t) * B + b]);
     }
     const Affine<F> c = corr[0];
     if (!c.is_inf()) r.madd(F9::from_words(c.x), F9::from_words(c.y));
@@ -447,7 +492,10 @@ __global__ __launch_bounds__(64, ZK_COMB_BOUNDS(F)) void k_comb_fold_narrow(cons
 static uint32_t comb_ranges(size_t B, size_t nclumps, int T) {
     static const uint32_t forced = [] { const char *e = ZK_AB_ENV("ZKPROVE_COMB_Q"); return e ? (uint32_t)atoi(e) : 0u; }();
     uint32_t Q = forced ? forced : 8;
-    while (!forced && (size_t)Q * T * B < (1u << 20) && Q < 256) Q *= 2;
+    // (batches below 512 proofs: two residency rounds instead of four -- their call is latency, and every doubling of Q is a range more
+    // for the fold to add; the 1 024-batch keeps the shape it was tuned at)
+    const size_t want = B >= 512 ? ((size_t)1 << 20) : ((size_t)1 << 19);
+    while (!forced && (size_t)Q * T * B < want && Q < 256) Q *= 2;
     const uint32_t cap = (uint32_t)(nclumps / 24);
     if (Q > cap) Q = cap;
     return Q < 1 ? 1 : Q;
@@ -462,21 +510,27 @@ void CombScratch::reserve(const CombBases &cb, size_t B, int nslots) {
 }
 void comb_patterns(const CombBases &cb, const Fr *x, const Fr *y, size_t B, uint32_t *pat, hipStream_t s) {
     static const bool reg_form = [] { const char *e = ZK_AB_ENV("ZKPROVE_COMB_PAT_REG"); return !(e && e[0] == '0'); }();
-    if (y && reg_form && cb.k >= 16 && cb.k <= 20) {
-        const dim3 grid(ceil_div(B, 64), (unsigned)cb.nclumps);
-        switch (cb.k) {
-            case 16: hipLaunchKernelGGL(k_comb_patterns_reg<16>, grid, dim3(64), 0, s, x, y, B, cb.n, pat); break;
-            case 17: hipLaunchKernelGGL(k_comb_patterns_reg<17>, grid, dim3(64), 0, s, x, y, B, cb.n, pat); break;
-            case 18: hipLaunchKernelGGL(k_comb_patterns_reg<18>, grid, dim3(64), 0, s, x, y, B, cb.n, pat); break;
-            case 19: hipLaunchKernelGGL(k_comb_patterns_reg<19>, grid, dim3(64), 0, s, x, y, B, cb.n, pat); break;
-            default: hipLaunchKernelGGL(k_comb_patterns_reg<20>, grid, dim3(64), 0, s, x, y, B, cb.n, pat); break;
-        }
-        ZK_HIP(hipGetLastError());
-        return;
-    }
     static PerDeviceOnce once;
     once.run([] { ZK_HIP(hipFuncSetAttribute((const void *)k_comb_patterns, hipFuncAttributeMaxDynamicSharedMemorySize, COMB_KMAX * 8 * 64 * 4)); });
-    hipLaunchKernelGGL(k_comb_patterns, dim3(ceil_div(B, 64), (unsigned)cb.nclumps), dim3(64), (size_t)cb.k * 8 * 64 * 4, s, x, y, B, cb.n, cb.k, pat);
+    // one launch per segment of equally sized clumps: nc clumps of kk bases over the ns bases from row base0, first table clump clump0
+    auto segment = [&](size_t ns, int kk, size_t nc, size_t base0, size_t clump0) {
+        if (!nc) return;
+        const dim3 grid(ceil_div(B, 64), (unsigned)nc);
+        if (y && reg_form && kk >= 16 && kk <= 21) {
+            switch (kk) {
+                case 16: hipLaunchKernelGGL(k_comb_patterns_reg<16>, grid, dim3(64), 0, s, x, y, B, ns, base0, clump0, pat); break;
+                case 17: hipLaunchKernelGGL(k_comb_patterns_reg<17>, grid, dim3(64), 0, s, x, y, B, ns, base0, clump0, pat); break;
+                case 18: hipLaunchKernelGGL(k_comb_patterns_reg<18>, grid, dim3(64), 0, s, x, y, B, ns, base0, clump0, pat); break;
+                case 19: hipLaunchKernelGGL(k_comb_patterns_reg<19>, grid, dim3(64), 0, s, x, y, B, ns, base0, clump0, pat); break;
+                case 20: hipLaunchKernelGGL(k_comb_patterns_reg<20>, grid, dim3(64), 0, s, x, y, B, ns, base0, clump0, pat); break;
+                default: hipLaunchKernelGGL(k_comb_patterns_reg<21>, grid, dim3(64), 0, s, x, y, B, ns, base0, clump0, pat); break;
+            }
+        } else
+            hipLaunchKernelGGL(k_comb_patterns, grid, dim3(64), (size_t)kk * 8 * 64 * 4, s, x, y, B, ns, kk, base0, clump0, pat);
+    };
+    const size_t nb1 = cb.n1 * (size_t)(cb.k + 1);
+    segment(nb1, cb.k + 1, cb.n1, 0, 0);
+    segment(cb.n - nb1, cb.k, cb.nclumps - cb.n1, nb1, cb.n1);
     ZK_HIP(hipGetLastError());
 }
 void comb_patterns_rows(const CombShape &cb, const Fr *scalars, size_t B, uint32_t *pat, uint32_t *gen_count, uint32_t *gen_idx, Fr *gen_val, size_t gen_stride,
@@ -495,11 +549,11 @@ static void comb_walk_impl(const CombBasesT<F> &cb, const uint32_t *pat, size_t 
     const uint32_t Q = comb_ranges(B, cb.nclumps, cb.T);
     const int groups = fold_groups(cb.T);
     if (sc.acc.n < (size_t)Q * cb.T * B * sizeof(X9) || sc.r1.n < (size_t)groups * B * sizeof(X9)) throw ZkError("comb MSM: scratch too small");
-    const size_t tiles = (B + 63) / 64;
+    const size_t tiles = ((size_t)cb.T * B + 63) / 64;
     X9 *acc = reinterpret_cast<X9 *>(sc.acc.p);
     if (seg_events) ZK_HIP(hipEventRecord(seg_events[0], s));
-    if (cb.has_inf) hipLaunchKernelGGL((k_comb_walk<F, true>), dim3((unsigned)(tiles * cb.T * Q)), dim3(64), 0, s, cb.table.p, pat, B, cb.nclumps, cb.E, cb.T, Q, acc);
-    else hipLaunchKernelGGL((k_comb_walk<F, false>), dim3((unsigned)(tiles * cb.T * Q)), dim3(64), 0, s, cb.table.p, pat, B, cb.nclumps, cb.E, cb.T, Q, acc);
+    if (cb.has_inf) hipLaunchKernelGGL((k_comb_walk<F, true>), dim3((unsigned)(tiles * Q)), dim3(64), 0, s, cb.table.p, pat, B, cb.nclumps, cb.E, cb.T, Q, cb.n1, acc);
+    else hipLaunchKernelGGL((k_comb_walk<F, false>), dim3((unsigned)(tiles * Q)), dim3(64), 0, s, cb.table.p, pat, B, cb.nclumps, cb.E, cb.T, Q, cb.n1, acc);
     if (seg_events) ZK_HIP(hipEventRecord(seg_events[1], s));
     ZK_HIP(hipGetLastError());
 }
@@ -516,12 +570,21 @@ static void comb_fold_impl(const CombBasesT<F> &cb, size_t B, CombScratch &sc, X
     static const bool skip_wire_folds = [] { const char *e = getenv("ZKPROVE_DIAG_SKIP_WIRE_FOLDS"); return e && e[0] == '1'; }();
     if (skip_wire_folds && out_stride != 1) return;
 #endif
+    // more than 8 ranges per (plane, proof) pair: 8-way in-place levels first (only small batches have them)
+    uint32_t Qr = Q, qstride = 1;
+    const size_t TB = (size_t)cb.T * B, tb_tiles = (TB + 63) / 64;
+    while (Qr > 8) {
+        const uint32_t groups8 = (Qr + 7) / 8;
+        hipLaunchKernelGGL(k_comb_fold_ranges<F>, dim3((unsigned)(tb_tiles * groups8)), dim3(64), 0, s, acc, TB, Qr, qstride);
+        Qr = groups8;
+        qstride *= 8;
+    }
     if (cb.T <= 32) {
-        hipLaunchKernelGGL(k_comb_fold_narrow<F>, dim3((unsigned)tiles), dim3(64), 0, s, acc, B, cb.T, Q, cb.corr.p, out, out_stride);
+        hipLaunchKernelGGL(k_comb_fold_narrow<F>, dim3((unsigned)tiles), dim3(64), 0, s, acc, B, cb.T, Qr, qstride, cb.corr.p, out, out_stride);
         ZK_HIP(hipGetLastError());
         return;
     }
-    hipLaunchKernelGGL(k_comb_fold1<F>, dim3((unsigned)(tiles * groups)), dim3(64), 0, s, acc, B, cb.T, Q, r1);
+    hipLaunchKernelGGL(k_comb_fold1<F>, dim3((unsigned)(tiles * groups)), dim3(64), 0, s, acc, B, cb.T, Qr, qstride, r1);
     hipLaunchKernelGGL(k_comb_fold2<F>, dim3((unsigned)tiles), dim3(64), 0, s, r1, B, groups, cb.corr.p, out, out_stride);
     ZK_HIP(hipGetLastError());
 }

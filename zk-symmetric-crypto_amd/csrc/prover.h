@@ -5,6 +5,7 @@
 // gnark/libraries/prover/impl/provers.go:179,269) and ProvingKey.ReadFrom (impl/library.go:104-109).
 #pragma once
 #include <atomic>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include "hostutil.h"
@@ -124,11 +125,21 @@ class Algorithm {
     void comb_prepare(size_t B);
     bool comb_drop_tables();
     void resident_reserve_buffers(size_t B);
+    size_t own_c_rows(size_t B) const;
     bool comb_release();                                    // out of memory: give the comb tables back, continue on the bucket pipeline                            // lazy table build + scratch (resident_reserve)
     // Memory pressure across algorithms: the hook (set by cabi.cpp, which owns the registry) asks every OTHER algorithm on this device
     // that is idle right now to give its comb tables back (release_comb_if_idle); true when something was freed
     static bool (*neighbours_release)(Algorithm *self);
     static int (*loaded_on_device)(int device);             // replicas of ALL algorithms the registry holds on a device (cabi.cpp): the comb budget's divisor
+    static bool (*peers_visit)(Algorithm *self, const std::function<void(Algorithm *)> &fn);      // every other replica on self's device (cabi.cpp)
+    // Filling the device (comb_prepare): once every circuit loaded on the device has reserved its working sets and built its tables, what
+    // is still free goes into the tables -- a prefix of clumps one base larger (CombShape::n1) -- shared between the circuits by relative
+    // gain per byte.  One rebuild per algorithm.
+    bool comb_topped = false;
+    struct CombPeer { bool settled = false, can_top = false; size_t pending = 0, weight = 0; };
+    CombPeer comb_peer_view();                              // caller holds this->mu (try_lock)
+    size_t pending_bytes() const;                           // what this replica will still allocate at its reserved capacity (further working sets, commitment scratch)
+    void comb_top_up();                                     // proving entries: rebuild the quotient tables larger when the device has settled
     bool release_comb_if_idle();
     size_t comb_table_bytes() const;                        // quotient + wire comb tables held right now
     std::atomic<uint64_t> last_use{0};                      // stamp of the last proving call (prove_batch / prove_stream)

@@ -121,8 +121,8 @@ struct SolveSet {
     int zslot = 0;                     // which copy of the sorted list / of the comb patterns they filled
     bool comb = false;                 // ... as comb patterns (msm_comb.hip) rather than a sorted bucket list
     bool ready = false;
-    void reserve(const SolverProgram &prog, size_t B) {
-        sb.reserve(prog, B);
+    void reserve(const SolverProgram &prog, size_t B, size_t c_B = (size_t)-1) {
+        sb.reserve(prog, B, c_B);
         m_com.ensure(B); m_pok.ensure(B); com_aff.ensure(B); pok_aff.ensure(B); chal.ensure(B);
         r.ensure(B); s.ensure(B); rnd.ensure(B); out.ensure(B);
         h_com.resize(B); h_chal.resize(B);
@@ -557,29 +557,27 @@ static size_t comb_min_batch() {
     static const size_t v = [] { const char *e = getenv("ZKPROVE_COMB_MIN_BATCH"); return e ? (size_t)atol(e) : (size_t)128; }();
     return v;
 }
-// Largest clump size whose table fits the budget.  The budget has two sides: a share of the device -- 0.42 of its memory divided by
-// the algorithm replicas LOADED on this device when the decision is made (one circuit alone: k = 20 for a 2^16 domain, 19 for 2^17 --
-// +3.1 % / +2.3 % proofs/s, profiles/r03p_k_sweep.txt; two circuits: 0.21 each = k = 19 / 18, which together with the working sets fill
-// 254 of the 288 GB; the tables are built by the first large batch, i.e. normally after the host has initialised what it serves) --
-// and what is left once the buffers this replica will still allocate (working sets, pattern copies) are set aside.  Decisions are
-// serialised per device so that each one sees the tables of the replicas before it on the same GPU.
-static std::mutex g_comb_budget_lock[64];      // per device: replicas on different GPUs decide and build in parallel
-static int comb_pick_k(size_t n, size_t still_needed, int share) {
+// The clump shape whose table fits a byte budget: the largest k <= 20 whose one-size table fits, and -- when `mixed` -- as many leading
+// clumps of k + 1 bases as the rest of the budget holds (CombShape::n1; k = 20 stays one size: a clump of 21 doubles a 100 GB table).
+struct CombPick { int k = 0; size_t n1 = 0; size_t bytes = 0; size_t clumps = 0; };
+static CombPick comb_pick_shape(size_t n, double budget, bool mixed) {
+    CombPick p;
+    for (int k = 20; k >= 12 && !p.k; k--)
+        if ((double)comb_table_bytes(n, k) <= budget) p.k = k;
+    if (!p.k) return p;
+    if (mixed && p.k < 20) p.n1 = comb_mixed_fit(n, p.k, (size_t)budget);
+    p.bytes = comb_mixed_bytes(n, p.k, p.n1);
+    p.clumps = comb_mixed_clumps(n, p.k, p.n1);
+    return p;
+}
+static int comb_forced_k() {
     static const int forced = [] { const char *e = getenv("ZKPROVE_COMB_K"); return e ? atoi(e) : 0; }();
-    if (forced) return forced;
-    size_t free_b = 0, total_b = 0;
-    ZK_HIP(hipMemGetInfo(&free_b, &total_b));
-    const double by_share = 0.42 * (double)total_b / (double)(share < 1 ? 1 : share);
-    const double by_free = free_b > still_needed ? 0.75 * (double)(free_b - still_needed) : 0.0;
-    const double budget = by_share < by_free ? by_share : by_free;
-    int pick = 0;
-    for (int k = 20; k >= 12 && !pick; k--)
-        if ((double)comb_table_bytes(n, k) <= budget) pick = k;
+    return forced;
+}
+static std::mutex g_comb_budget_lock[64];      // per device: replicas on different GPUs decide and build in parallel
+static bool comb_memlog() {
     static const bool log = getenv("ZKPROVE_MEMLOG") != nullptr;
-    if (log)
-        fprintf(stderr, "zkprove: comb budget: free %.1f GiB of %.1f, still needed %.1f, share 1/%d -> budget %.1f GiB, k = %d (%.1f GiB)\n", free_b / 1073741824.0,
-                total_b / 1073741824.0, still_needed / 1073741824.0, share, budget / 1073741824.0, pick, pick ? comb_table_bytes(n, pick) / 1073741824.0 : 0.0);
-    return pick;
+    return log;
 }
 size_t Algorithm::resident_batch() const { return res ? res->B : 0; }
 void Algorithm::debug_leftovers(long *out3) {
@@ -593,6 +591,46 @@ void Algorithm::debug_leftovers(long *out3) {
 bool Algorithm::comb_active() const {
     return pk.Zcomb.ok && res && split_world == 1 && res->B > SIDE_G2_MAX_B && res->comb_cap >= res->B;
 }
+// What this replica will still allocate at its reserved capacity: the second and third working set of the pipelined entries, the scratch
+// of the commitment MSMs on the solve stream.  (A peer's budget decision sets this aside; caller holds mu.)
+size_t Algorithm::pending_bytes() const {
+    if (!res) return 0;
+    const Resident &R = *res;
+    const size_t B = R.cap, N = (size_t)1 << prog.log_domain;
+    const size_t per_set = B * (prog.n_wires + 2 * N + (pk.Zcomb.ok ? 0 : N)) * sizeof(Fr) + ((size_t)64 << 20);      // (with comb tables the further sets keep no c rows of their own)
+    size_t need = ((R.set[1].ready ? 0 : 1) + (R.set[2].ready ? 0 : 1)) * per_set;
+    if (has_commit && R.ms2.entries.n == 0)
+        need += B * (pk.ped.n * (size_t)pk.ped.W * 4 + ((size_t)4 << (pk.ped.c - 1)) + msm_part_stride(pk.ped.n, pk.ped.c) * sizeof(G1XYZZ) + ((size_t)144 << (pk.ped.c - 1)) + pk.ped.n * 36);
+    if (has_commit && !wire_comb_tried && comb_enabled()) need += (size_t)6 << 30;      // wire-comb tables (4 GiB at clumps of 16) and their pattern / accumulator scratch
+    return need;
+}
+// A peer as this replica's budget decision sees it.  settled: it has reserved the working buffers of a large batch and decided its own
+// tables (or will never build any) -- what it still allocates is `pending`.  can_top / weight: it holds tables that may still grow; the
+// bytes a whole clump size more would cost it (the free memory is shared in proportion: equal relative gain per byte).
+Algorithm::CombPeer Algorithm::comb_peer_view() {
+    CombPeer v;
+    if (!res || res->cap < comb_min_batch() || !pk.comb_tried) return v;      // has not served a large batch yet: its needs are unknown
+    v.settled = true;
+    v.pending = pending_bytes();
+    if (pk.Zcomb.ok && !comb_topped && pk.Zcomb.k < 20) {
+        v.can_top = true;
+        v.weight = zk::comb_table_bytes(pk.Zcomb.n, pk.Zcomb.k + 1) - zk::comb_table_bytes(pk.Zcomb.n, pk.Zcomb.k);
+    }
+    return v;
+}
+// Table build is triggered by the first batch of >= comb_min_batch() proofs.  Budget, in two regimes:
+//  * some circuit loaded on this device has not served a large batch yet (its working sets and tables are still to come): a share of
+//    the device -- 0.42 of its memory divided by the replicas loaded on it -- and at most 75 % of what is free beyond this replica's own
+//    further needs; one clump size throughout (k = 19 for a 2^16 domain, 18 for 2^17 with two circuits loaded);
+//  * every loaded circuit has settled (or this one is alone): what is really free, less every replica's pending allocations and the
+//    headroom, goes into the tables -- mixed clump sizes fill it to the last GiB -- divided between the circuits whose tables can still
+//    grow in proportion to the bytes a clump size more costs each (equal relative gain per byte: a 2^17 domain at k = 18 and a 2^16
+//    domain at k = 19 both buy 5 % fewer additions for ~50 GB).  A circuit that decided under the first regime is topped up later, at
+//    its next large batch after the device settled (comb_top_up: one rebuild).
+// Decisions are serialised per device so that each one sees the tables of the replicas before it on the same GPU.
+// kept free beyond every known allocation: the 4 GiB every large allocation must leave (require_headroom, common.h) + room for what the
+// estimates do not list (verifier images, pinned-copy staging, the host application's own buffers)
+static constexpr size_t COMB_HEADROOM = (size_t)9 << 30;
 void Algorithm::comb_prepare(size_t B) {
     if (!comb_enabled() || split_world != 1 || B <= SIDE_G2_MAX_B) return;
     Resident &R = *res;
@@ -600,18 +638,52 @@ void Algorithm::comb_prepare(size_t B) {
         pk.comb_tried = true;
         std::lock_guard<std::mutex> budget(g_comb_budget_lock[device & 63]);
         // still to come for this replica: the second and third working set of the pipelined entries, the two pattern copies (~ the
-        // table's clump count x 254 x B words: bounded by the k = 12 figure), range accumulators, and slack for the allocator
-        const size_t N = (size_t)1 << prog.log_domain;
-        const size_t per_set = B * (prog.n_wires + 3 * N) * sizeof(Fr);
-        const size_t sets_to_come = (R.set[1].ready ? 0 : 1) + (R.set[2].ready ? 0 : 1);      // (a second chance after a release finds them in place)
-        const size_t still_needed = sets_to_come * per_set + 2 * ((pk.ze.n / 16 + 1) * 254 * B * sizeof(uint32_t)) + ((size_t)6 << 30);
+        // table's clump count x 254 x B words: bounded by the k = 16 figure), range accumulators, and slack for the allocator
+        const size_t still_needed = pending_bytes() + 2 * ((pk.ze.n / 16 + 1) * 254 * B * sizeof(uint32_t)) + COMB_HEADROOM;
         const int loaded = loaded_on_device ? loaded_on_device(device) : comb_share;      // algorithm replicas on this GPU right now, this one included
-        const int k = comb_pick_k(pk.ze.n, still_needed, std::max(loaded, comb_share));
+        const int share = std::max(std::max(loaded, comb_share), 1);
+        size_t free_b = 0, total_b = 0;
+        ZK_HIP(hipMemGetInfo(&free_b, &total_b));
+        // the neighbours: all settled?  what will they still allocate, and how much of the free memory is theirs to grow into?
+        bool settled = true;
+        size_t peers_pending = 0, peers_weight = 0;
+        if (peers_visit) {
+            const bool complete = peers_visit(this, [&](Algorithm *p) {
+                std::unique_lock<std::mutex> lk(p->mu, std::try_to_lock);
+                if (!lk) { settled = false; return; }                      // proving right now: ask again another time
+                const CombPeer v = p->comb_peer_view();
+                if (!v.settled) { settled = false; return; }
+                peers_pending += v.pending;
+                if (v.can_top) peers_weight += v.weight;
+            });
+            settled = settled && complete;
+        } else settled = share == 1;
+        const double by_share = 0.42 * (double)total_b / (double)share;
+        const double by_free = free_b > still_needed ? 0.75 * (double)(free_b - still_needed) : 0.0;
+        CombPick pick = comb_pick_shape(pk.ze.n, std::min(by_share, by_free), false);
+        if (comb_forced_k()) { pick = CombPick(); pick.k = comb_forced_k(); pick.bytes = zk::comb_table_bytes(pk.ze.n, pick.k); pick.clumps = (pk.ze.n + pick.k - 1) / pick.k; }
+        else if (settled && pick.k) {
+            // everything the neighbours need is known: fill the device
+            const double avail = (double)free_b - (double)still_needed - (double)peers_pending;
+            const size_t my_weight = pick.k < 20 ? zk::comb_table_bytes(pk.ze.n, pick.k + 1) - zk::comb_table_bytes(pk.ze.n, pick.k) : 0;
+            const double frac = (my_weight + peers_weight) ? (double)my_weight / (double)(my_weight + peers_weight) : 1.0;
+            const double extra = avail - (double)pick.bytes;
+            if (extra > 0) {
+                // (the patterns of a finer table are fewer, never more: still_needed stays an upper bound)
+                const CombPick full = comb_pick_shape(pk.ze.n, std::min((double)pick.bytes + 0.97 * extra * frac, 0.42 * (double)total_b), true);
+                if (full.k && full.bytes >= pick.bytes) pick = full;
+            }
+            comb_topped = true;
+        }
+        if (comb_memlog())
+            fprintf(stderr, "zkprove: comb budget: free %.1f GiB of %.1f, still needed %.1f, peers pending %.1f, share 1/%d, device %s -> k = %d, %zu clumps of %d (%zu clumps, %.1f GiB)\n",
+                    free_b / 1073741824.0, total_b / 1073741824.0, still_needed / 1073741824.0, peers_pending / 1073741824.0, share, settled ? "settled" : "not settled",
+                    pick.k, pick.n1, pick.k + 1, pick.clumps, pick.bytes / 1073741824.0);
         bool ok = false;
         std::string why = "not enough free device memory";
-        if (k) {
+        if (pick.k) {
             try {
-                ok = comb_build(pk.Zcomb, pk.ze.p, pk.ze.n, k, R.stream);
+                ok = comb_build(pk.Zcomb, pk.ze.p, pk.ze.n, pick.k, R.stream, pick.n1);
                 if (!ok) why = "degenerate bases";
             } catch (const ZkError &e) {
                 pk.Zcomb.table.release();
@@ -625,6 +697,58 @@ void Algorithm::comb_prepare(size_t B) {
         R.comb.reserve(pk.Zcomb, B, 2);
         R.comb_cap = B;
     }
+}
+// Top-up (proving entries, before anything is enqueued: nothing of this replica is in flight).  The tables were sized while a
+// neighbour's needs were unknown; now that every circuit on the device has settled, this replica's share of what is still free goes
+// into a prefix of larger clumps.  The old table is released first (both do not fit), so a failed build falls back to the old shape.
+void Algorithm::comb_top_up() {
+    if (!res || !pk.Zcomb.ok || comb_topped || comb_forced_k() || split_world != 1 || res->B < comb_min_batch() || !peers_visit) return;
+    Resident &R = *res;
+    std::lock_guard<std::mutex> budget(g_comb_budget_lock[device & 63]);
+    bool settled = true;
+    size_t peers_pending = 0, peers_weight = 0;
+    const bool complete = peers_visit(this, [&](Algorithm *p) {
+        std::unique_lock<std::mutex> lk(p->mu, std::try_to_lock);
+        if (!lk) { settled = false; return; }
+        const CombPeer v = p->comb_peer_view();
+        if (!v.settled) { settled = false; return; }
+        peers_pending += v.pending;
+        if (v.can_top) peers_weight += v.weight;
+    });
+    if (!settled || !complete) return;                      // not yet: the next large batch asks again
+    comb_topped = true;
+    const CombBases &old = pk.Zcomb;
+    if (old.k >= 20) return;
+    size_t free_b = 0, total_b = 0;
+    ZK_HIP(hipMemGetInfo(&free_b, &total_b));
+    const size_t old_bytes = old.table.bytes(), n = old.n;
+    const int old_k = old.k;
+    const size_t old_n1 = old.n1, old_clumps = old.nclumps;
+    const double avail = (double)free_b - (double)pending_bytes() - (double)peers_pending - (double)COMB_HEADROOM;
+    const size_t my_weight = zk::comb_table_bytes(n, old_k + 1) - zk::comb_table_bytes(n, old_k);
+    const double frac = (double)my_weight / (double)(my_weight + peers_weight);
+    if (avail <= 0) return;
+    const CombPick pick = comb_pick_shape(n, std::min((double)old_bytes + 0.97 * avail * frac, 0.42 * (double)total_b), true);      // (one replica's tables: at most 0.42 of the device)
+    if (comb_memlog())
+        fprintf(stderr, "zkprove: comb top-up: free %.1f GiB, own pending %.1f, peers pending %.1f, share %.2f -> k = %d, %zu clumps of %d (%zu clumps, %.1f GiB; was %zu clumps, %.1f GiB)\n",
+                free_b / 1073741824.0, pending_bytes() / 1073741824.0, peers_pending / 1073741824.0, frac, pick.k, pick.n1, pick.k + 1, pick.clumps, pick.bytes / 1073741824.0,
+                old_clumps, old_bytes / 1073741824.0);
+    if (!pick.k || (double)pick.clumps > 0.993 * (double)old_clumps) return;      // less than 0.7 % fewer additions: not worth a rebuild
+    ZK_HIP(hipDeviceSynchronize());
+    pk.Zcomb = CombBases();
+    bool ok = false;
+    try {
+        ok = comb_build(pk.Zcomb, pk.ze.p, n, pick.k, R.stream, pick.n1);
+    } catch (const ZkError &e) {
+        pk.Zcomb = CombBases();
+        (void)hipGetLastError();
+        fprintf(stderr, "zkprove: comb top-up failed (%s): rebuilding the previous tables\n", e.what());
+    }
+    if (!ok) {
+        try { ok = comb_build(pk.Zcomb, pk.ze.p, n, old_k, R.stream, old_n1); } catch (const ZkError &) { pk.Zcomb = CombBases(); (void)hipGetLastError(); }
+        if (!ok) { fprintf(stderr, "zkprove: comb tables lost: this algorithm continues on the bucket pipeline\n"); comb_release(); return; }
+    }
+    R.comb.reserve(pk.Zcomb, R.cap, 2);
 }
 
 void bsb22_challenge_device(const G1Affine *com_canonical, Fr *challenge_mont, size_t n, hipStream_t s) {
@@ -771,14 +895,21 @@ void Algorithm::resident_reserve(size_t B) {
         }
     }
 }
+// Instances the c rows of the second / third working set are sized for: with comb tables only the products buffer of the batches too
+// small for the comb (the solver writes its output column into the first set's rows, SolverBuffers::c_shared); without tables the
+// bucket pipeline keeps every batch's products there.
+size_t Algorithm::own_c_rows(size_t B) const { return pk.Zcomb.ok ? std::min(B, SIDE_G2_MAX_B) : B; }
 void Algorithm::resident_reserve_buffers(size_t B) {
     Resident &R = *res;
     R.B = B;
+    // (tables given back under memory pressure: the further sets need full c rows again)
+    for (int i = 1; i < 3; i++)
+        if (R.set[i].ready && R.cap) R.set[i].sb.c.ensure(((size_t)1 << prog.log_domain) * own_c_rows(R.cap));
     if (B > R.cap) {
         R.cap = B;
         R.set[0].reserve(prog, B);
-        if (R.set[1].ready) R.set[1].reserve(prog, B);
-        if (R.set[2].ready) R.set[2].reserve(prog, B);
+        if (R.set[1].ready) R.set[1].reserve(prog, B, own_c_rows(B));
+        if (R.set[2].ready) R.set[2].reserve(prog, B, own_c_rows(B));
         size_t max_entries = 0, max_nb = 0, max_part = 0;
         auto acc = [&](size_t n, int c, int W) {
             max_entries = std::max(max_entries, n * (size_t)W);
@@ -879,6 +1010,11 @@ void Algorithm::enqueue_solve(SolveSet &S, MsmScratch &commit_scratch, hipStream
     Resident &R = *res;
     const size_t B = R.B;
     ZK_HIP(hipEventRecord(S.t0, st));
+    {   // output column: own rows when they hold this batch, else the first set's (own_c_rows; solve stages share one stream)
+        const size_t need = ((size_t)1 << prog.log_domain) * B;
+        S.sb.c_shared = S.sb.c.n >= need ? nullptr : R.set[0].sb.c.p;
+        if (S.sb.c_shared && (R.set[0].sb.c.n < need || !comb_active())) throw ZkError("internal: working set without rows for the output column");
+    }
     hipLaunchKernelGGL(k_u256_to_mont, dim3(ceil_div(B, 64)), dim3(64), 0, st, S.rnd.p, S.sb.randomize.p, B);
     solver_begin(prog, S.sb, st);
     if (S.n_wide) hipLaunchKernelGGL(k_wide_inputs, dim3(ceil_div(S.n_wide, 64)), dim3(64), 0, st, S.wide.p, S.n_wide, S.sb.wires.p, B);
@@ -915,6 +1051,10 @@ void Algorithm::enqueue_solve(SolveSet &S, MsmScratch &commit_scratch, hipStream
     ZK_HIP(hipEventRecord(S.t3, st));
 }
 
+// the bucket pipeline keeps the instance-major products of a batch in the set's own c rows (own_c_rows sizes them for exactly the batches that take it)
+static void products_rows_check(const SolverBuffers &sb, size_t N, size_t B) {
+    if (sb.c.n < N * B) throw ZkError("internal: working set without rows for the quotient products");
+}
 // Ahead mode (pipelined entries, large batches): the transforms and the quotient MSM's bucket sort of a batch need nothing but its solved
 // wires, so they are enqueued right behind its solve stage -- on the copy stream (side_chain_stream), i.e. while the main stream is still
 // busy with an EARLIER batch.  (Nothing runs under the quotient walk itself: its single-wave workgroups hold every wave slot; the ahead
@@ -949,7 +1089,7 @@ void Algorithm::enqueue_ntt_sort(SolveSet &S, hipStream_t sn, int slot, hipEvent
     dom.to_coset(S.sb.a.p, S.sb.b.p, B, sn);
     ZK_HIP(hipEventRecord(R.ev[20], sn));
     S.comb = comb_active();
-    if (!S.comb) fr_transpose_mul(S.sb.a.p, S.sb.b.p, S.sb.c.p, N, B, N, sn);
+    if (!S.comb) { products_rows_check(S.sb, N, B); fr_transpose_mul(S.sb.a.p, S.sb.b.p, S.sb.c.p, N, B, N, sn); }
     ZK_HIP(hipEventRecord(R.ev[17], sn));
     ZK_HIP(hipStreamWaitEvent(R.copy_stream, R.ev[17], 0));
     if (slot_free) ZK_HIP(hipStreamWaitEvent(R.copy_stream, slot_free, 0));      // the quotient MSM that walked this copy of the list is done
@@ -1071,7 +1211,7 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm,
     if (!side) {
         // the quotient MSM's scalars f = A*B are complete: its bucket sort (LDS / memory bound) -- or, on the comb path, the extraction
         // of its bit-plane patterns -- runs on the copy stream beside the wire MSMs (multiplier bound) and is joined just before the walk
-        if (!comb) fr_transpose_mul(S.sb.a.p, S.sb.b.p, S.sb.c.p, N, B, N, st);
+        if (!comb) { products_rows_check(S.sb, N, B); fr_transpose_mul(S.sb.a.p, S.sb.b.p, S.sb.c.p, N, B, N, st); }
         ZK_HIP(hipEventRecord(R.ev[17], st));
         ZK_HIP(hipStreamWaitEvent(R.copy_stream, R.ev[17], 0));
         if (comb) { comb_patterns(pk.Zcomb, S.sb.a.p, S.sb.b.p, B, R.comb.pat[0].p, R.copy_stream); presorted = true; }
@@ -1103,6 +1243,7 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm,
     // instance-major products
     if (side) {
         ZK_HIP(hipStreamWaitEvent(st, R.ev[15], 0));      // b on the coset comes from the side stream
+        products_rows_check(S.sb, N, B);
         fr_transpose_mul(S.sb.a.p, S.sb.b.p, S.sb.c.p, N, B, N, st);
     }
     if (presorted) ZK_HIP(hipStreamWaitEvent(st, R.ev[18], 0));
@@ -1160,6 +1301,7 @@ void Algorithm::collect_times(SolveSet &S, PhaseTimes *times) {
 
 void Algorithm::resident_prove(PhaseTimes *times) {
     DeviceScope on_device(device);
+    comb_top_up();
     Resident &R = *res;
     hipStream_t st = R.stream;
     R.last_set = 0;
@@ -1196,13 +1338,14 @@ bool Algorithm::comb_drop_tables() {
     return true;
 }
 // Tables that went under pressure are not gone for good: when this algorithm is next asked to prove -- the pressure has passed, every
-// circuit's working sets exist -- the budget (comb_pick_k: what is free beyond this algorithm's own needs) is consulted once more and
+// circuit's working sets exist -- the budget (comb_prepare: what is free beyond this algorithm's own needs) is consulted once more and
 // builds what fits, possibly a smaller clump size.  Twice per algorithm at most.
 void Algorithm::comb_second_chance() {
     if (!comb_dropped || comb_rebuilds >= 2) return;
     comb_dropped = false;
     comb_rebuilds++;
     pk.comb_tried = false;
+    comb_topped = false;
     wire_comb_tried = false;
 }
 bool Algorithm::comb_release() {
@@ -1214,6 +1357,7 @@ bool Algorithm::comb_release() {
 // fit and it has no tables of its own to give back.  The tables of the algorithms that are idle at that moment go instead (they continue
 // on the bucket pipeline; the log line says so) -- a request must not fail for the sake of another circuit's optimisation.
 bool (*Algorithm::neighbours_release)(Algorithm *self) = nullptr;
+bool (*Algorithm::peers_visit)(Algorithm *self, const std::function<void(Algorithm *)> &fn) = nullptr;
 int (*Algorithm::loaded_on_device)(int device) = nullptr;
 bool Algorithm::release_comb_if_idle() {
     std::unique_lock<std::mutex> lk(mu, std::try_to_lock);
@@ -1256,7 +1400,7 @@ void Algorithm::ensure_second_set_once(int nsets) {
     Resident &R = *res;
     for (int i = 1; i < nsets; i++) {
         if (R.set[i].ready) continue;
-        R.set[i].reserve(prog, R.cap);
+        R.set[i].reserve(prog, R.cap, own_c_rows(R.cap));
         R.set[i].sb.B = R.B;
         SolveSet &a = R.set[0], &b = R.set[i];
         ZK_HIP(hipMemcpy(b.sb.inputs.p, a.sb.inputs.p, prog.n_inputs * R.B * sizeof(uint32_t), hipMemcpyDeviceToDevice));
@@ -1278,6 +1422,7 @@ void Algorithm::ensure_second_set_once(int nsets) {
 // with the NTT + MSM stage of batch k.  times (optional) = phase times of the LAST batch; total = whole call / nsteps.
 void Algorithm::resident_prove_pipelined(int nsteps, PhaseTimes *times) {
     DeviceScope on_device(device);
+    comb_top_up();
     Resident &R = *res;
     if (nsteps <= 0) return;
     hipStream_t M = R.stream, S = R.stream2, F = R.stream3;
@@ -1470,6 +1615,7 @@ void Algorithm::prove_stream(ChunkFeed &feed, PhaseTimes *times) {
     comb_second_chance();
     DeviceScope on_device(device);
     resident_reserve(max_chunk);
+    comb_top_up();
     Resident &R = *res;
     // two working sets; three when chunks are prepared ahead (as in resident_prove_pipelined: the side chain of chunk k then runs beside
     // the MSMs of chunks k-2 and k-1)

@@ -47,6 +47,11 @@ struct SolverBuffers {
     size_t B = 0;
     DevBuf<Fr> wires;          // [n_wires][B]
     DevBuf<Fr> a, b, c;        // [N][B]
+    // The solver writes the output column c (and reads it back for the deferred divisions) but nothing after the solve stage needs it
+    // on the comb path (everything done to c is folded into the key, keyfold.hip).  The further working sets of the pipelined entries
+    // therefore keep only a small c of their own (the products buffer of batches <= 64) and solve into the first set's rows:
+    // c_shared != nullptr replaces c.p for the solver (solve stages are serialised on one stream).
+    Fr *c_shared = nullptr;
     DevBuf<uint32_t> inputs;   // [B][n_inputs] small integers (instance-major, as the host builds them)
     // the request path's compact form (request.h, RawWitness): [B][SOLVER_RAW_STRIDE] bytes -- the request's own bytes and the cipher
     // output, 320 B per proof instead of 10 KB of bit-expanded u32 (ChaCha20) -- expanded into the input wires on the device.
@@ -57,7 +62,7 @@ struct SolverBuffers {
     DevBuf<Fr> challenge;      // [B] Montgomery (commitment challenge)
     DevBuf<uint32_t> err;      // [B] (code | constraint<<8)
     DevBuf<uint32_t> count_scratch;
-    void reserve(const SolverProgram &p, size_t B);
+    void reserve(const SolverProgram &p, size_t B, size_t c_B = (size_t)-1);      // c_B: instances the own c rows are sized for (default B)
 };
 
 

@@ -417,11 +417,11 @@ void SolverProgram::build(const R1cs &cs, hipStream_t s) {
     ZK_HIP(hipStreamSynchronize(s));
 }
 
-void SolverBuffers::reserve(const SolverProgram &p, size_t B_) {
+void SolverBuffers::reserve(const SolverProgram &p, size_t B_, size_t c_B) {
     B = B_;
     const size_t N = (size_t)1 << p.log_domain;
     wires.ensure(p.n_wires * B);
-    a.ensure(N * B); b.ensure(N * B); c.ensure(N * B);
+    a.ensure(N * B); b.ensure(N * B); c.ensure(N * (c_B < B ? c_B : B));
     inputs.ensure(p.n_inputs * B);
     raw.ensure(SOLVER_RAW_STRIDE * B);
     randomize.ensure(B); challenge.ensure(B); err.ensure(B);
@@ -1256,7 +1256,7 @@ static size_t persist_max_b() {
 }
 #endif
 void solver_run_levels(const SolverProgram &p, SolverBuffers &buf, size_t first_level, size_t last_level, hipStream_t s) {
-    SolveCtx cx{p.prog.p, p.coeffs.p, p.coeff_inv.p, p.lookup_tables.p, p.count_tables.p, buf.wires.p, buf.a.p, buf.b.p, buf.c.p,
+    SolveCtx cx{p.prog.p, p.coeffs.p, p.coeff_inv.p, p.lookup_tables.p, p.count_tables.p, buf.wires.p, buf.a.p, buf.b.p, buf.c_shared ? buf.c_shared : buf.c.p,
                 buf.randomize.p, buf.challenge.p, buf.err.p, buf.count_scratch.p, buf.B, p.n_count_rows, nullptr};
     if (last_level > p.levels.size()) last_level = p.levels.size();
 #ifdef ZK_EXPERIMENTS

@@ -169,7 +169,11 @@ extern "C" int zkp_msm_comb(long n_, long batch, const uint8_t *points, const ui
     if (n) ZK_HIP(hipMemcpy(dp.p, points, n * 64, hipMemcpyHostToDevice));
     fp_to_mont_dev(dp.p, n * 2, 0);
     CombBases cb;
-    if (!comb_build(cb, dp.p, n, k, 0)) return 1;
+    // mode bits 8.. : n1 = number of leading clumps that hold k + 1 bases (mixed tables, CombShape::n1)
+    const size_t n1 = (size_t)(mode >> 8);
+    mode &= 0xff;
+    if (n1 * (size_t)(k + 1) > n) return -1;
+    if (!comb_build(cb, dp.p, n, k, 0, n1)) return 1;
     std::vector<Fr> hs;
     transpose_in(hs, scalars, B, n);
     DevBuf<Fr> ds(n * B + 1), ones;
