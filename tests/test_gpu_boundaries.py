@@ -21,6 +21,9 @@ import helpers as H
 pytestmark = pytest.mark.gpu
 
 SIZES = [2, 5, 8, 9, 16, 17, 32, 33, 64, 127, 128, 129, 255, 256]
+# second pass, once the batch of 128 has built the comb tables: from 16 proofs on every batch now takes the comb path (quotient walk with
+# (plane, proof) lanes, range levels of the fold, wire combs, transforms beside the wire MSMs), 15 and below keep the bucket pipeline
+SIZES_WITH_TABLES = [15, 16, 17, 31, 33, 64, 65, 100, 127, 8]
 POOL = 256
 
 
@@ -118,7 +121,7 @@ def _picks(B):
 def test_every_batch_size_threshold_from_both_sides(zk, oracle, alg):
     c = Case(zk, alg)
     try:
-        for B in SIZES:
+        for B in SIZES + SIZES_WITH_TABLES:
             idx, picks = c.members(B), _picks(B)
             via_json = c.json_batch(idx)
             c.check_against_oracle(idx, via_json, picks)

@@ -70,6 +70,9 @@ static_assert(pow3(TERN_G) <= 65536, "group patterns are parked as 16-bit words"
 static constexpr int ONES_CHUNK = TERN_G * ONES_GROUPS;    // base points per conditional-sum thread
 static constexpr int SORT_THREADS = 1024;
 static constexpr int WCOMB_CLASSES = 3;                     // wire-comb width classes: 8, 32, 254 bit planes
+// batches from this size take the wire combs (where the scratch they run on holds room for them): the walk's lanes are (plane, proof)
+// pairs, so 16 proofs fill wavefronts with four planes each; below, the one-proof paths (sparse split, tree folds) are faster
+static constexpr size_t WCOMB_MIN_B = 16;
 
 #ifdef ZK_EXPERIMENTS
 static bool tree_enabled();
@@ -1277,7 +1280,7 @@ static void msm_batch_impl(const MsmBases<F> &mb, const Fr *scalars, size_t B, M
     const size_t nchunks = mb.dense ? 0 : (n + ONES_CHUNK - 1) / ONES_CHUNK;      // the dense MSM has no conditional-sum partials
     const size_t max_entries = n * W;
     // wire combs: batches that fill whole wavefronts, scratch reserved (Algorithm::wire_comb_prepare), 9-limb tables
-    bool wcomb = !mb.dense && !mb.wcomb.empty() && mb.f9 && B > 64;
+    bool wcomb = !mb.dense && !mb.wcomb.empty() && mb.f9 && B >= WCOMB_MIN_B;
     if (wcomb) {
         size_t pw = 0, ab = 0, rb = 0;
         wire_comb_needs(mb, B, pw, ab, rb);

@@ -501,7 +501,13 @@ static uint32_t comb_ranges(size_t B, size_t nclumps, int T) {
     return Q < 1 ? 1 : Q;
 }
 size_t comb_pattern_words(const CombShape &cb, size_t B) { return cb.nclumps * (size_t)cb.T * B; }
-size_t comb_acc_bytes(const CombShape &cb, size_t B, size_t x9_bytes) { return (size_t)comb_ranges(B, cb.nclumps, cb.T) * cb.T * B * x9_bytes; }
+// (the largest need of ANY batch up to B: a small batch takes more clump ranges per pair than a large one, and a scratch reserved for
+// B serves every batch up to B)
+size_t comb_acc_bytes(const CombShape &cb, size_t B, size_t x9_bytes) {
+    size_t m = 0;
+    for (size_t b = 1; b <= B; b++) m = std::max(m, (size_t)comb_ranges(b, cb.nclumps, cb.T) * cb.T * b);
+    return m * x9_bytes;
+}
 size_t comb_r1_bytes(const CombShape &cb, size_t B, size_t x9_bytes) { return (size_t)fold_groups(cb.T) * B * x9_bytes; }
 void CombScratch::reserve(const CombBases &cb, size_t B, int nslots) {
     for (int i = 0; i < nslots && i < 2; i++) pat[i].ensure(comb_pattern_words(cb, B));

@@ -11,6 +11,10 @@ namespace zk {
 static constexpr int C_WIRE = 13;   // window bits for the wire-scalar MSMs (few wide scalars)
 static constexpr int C_H = 16;      // window bits for the quotient MSM (all scalars full width)
 static constexpr size_t SIDE_G2_MAX_B = 64;   // up to this batch size the G2 MSM runs beside the G1 MSMs (kernels are latency-bound)
+// Once the comb tables exist (a batch of >= comb_min_batch() proofs has been served) every batch from this size takes them: the walk's
+// lanes are (plane, proof) pairs, so 16 proofs fill wavefronts with four planes each.  Below, the latency-tuned bucket pipeline of the
+// one-proof calls (virtual instances, side streams) stays faster.
+static constexpr size_t COMB_SMALL_MIN_B = 16;
 
 // ------------------------------------------------------------------------------- pk parsing
 namespace {
@@ -589,7 +593,7 @@ void Algorithm::debug_leftovers(long *out3) {
     for (uint32_t v : h) { out3[0] += v; out3[1] = std::max<long>(out3[1], v); out3[2] += v != 0; }
 }
 bool Algorithm::comb_active() const {
-    return pk.Zcomb.ok && res && split_world == 1 && res->B > SIDE_G2_MAX_B && res->comb_cap >= res->B;
+    return pk.Zcomb.ok && res && split_world == 1 && res->B >= COMB_SMALL_MIN_B && res->comb_cap >= res->B;
 }
 // What this replica will still allocate at its reserved capacity: the second and third working set of the pipelined entries, the scratch
 // of the commitment MSMs on the solve stream.  (A peer's budget decision sets this aside; caller holds mu.)
@@ -632,7 +636,7 @@ Algorithm::CombPeer Algorithm::comb_peer_view() {
 // estimates do not list (verifier images, pinned-copy staging, the host application's own buffers)
 static constexpr size_t COMB_HEADROOM = (size_t)9 << 30;
 void Algorithm::comb_prepare(size_t B) {
-    if (!comb_enabled() || split_world != 1 || B <= SIDE_G2_MAX_B) return;
+    if (!comb_enabled() || split_world != 1 || B < COMB_SMALL_MIN_B) return;
     Resident &R = *res;
     if (!pk.comb_tried && B >= comb_min_batch()) {
         pk.comb_tried = true;
@@ -1022,7 +1026,7 @@ void Algorithm::enqueue_solve(SolveSet &S, MsmScratch &commit_scratch, hipStream
         solver_run_levels(prog, S.sb, 0, commit_level, st);
         ZK_HIP(hipEventRecord(S.t1, st));
         // BSB22 commitment: C = sum v_i * Basis_i ; challenge = H2F(C.Marshal(), "bsb22-commitment") ; PoK = sum v_i * BasisExpSigma_i
-        if (B <= SIDE_G2_MAX_B) {
+        if (B <= SIDE_G2_MAX_B && !(wire_comb_on && B >= COMB_SMALL_MIN_B)) {
             // small batch: the two Pedersen MSMs are latency-bound chains -- the proof-of-knowledge one runs on the side stream
             // (scratch of the side G2 MSM, idle until the MSM stage) beside the commitment
             ZK_HIP(hipEventRecord(R.ev[14], st));
@@ -1065,8 +1069,9 @@ bool Algorithm::ahead_eligible() const {
     static const bool on = [] { const char *e = ZK_AB_ENV("ZKPROVE_SORT_AHEAD"); return !(e && e[0] == '0'); }();
     const Resident &R = *res;
     const size_t max_entries = pk.Z.n * (size_t)pk.Z.W, nb = (size_t)1 << (pk.Z.c - 1);
-    if (!(on && R.B > SIDE_G2_MAX_B && split_world == 1)) return false;
-    if (comb_active()) return true;                      // the comb path prepares its bit-plane patterns ahead instead of a sorted list
+    if (!(on && split_world == 1)) return false;
+    if (comb_active()) return true;
+    if (R.B <= SIDE_G2_MAX_B) return false;                      // the comb path prepares its bit-plane patterns ahead instead of a sorted list
     // the complete predicate of msm_dense_presort: a batch that does not meet it takes the in-line sort of enqueue_main
     return pk.Z.dense && pk.Z.n != 0 && msm_dense_presort_applicable(pk.Z, R.B, R.ms) && R.ms.entries_zb.n >= R.B * max_entries + 1 &&
            R.ms.bucket_start_zb.n >= R.B * (nb + 1);
@@ -1166,7 +1171,7 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm,
     }
     // A small batch is a set of latency-bound kernel chains: independent chains go to the otherwise idle streams (the transforms of b
     // and the K MSM to the solve stream, the G2 MSM to the copy stream) -- never to new ones, see resident_reserve
-    const bool side = B <= SIDE_G2_MAX_B;
+    const bool side = B <= SIDE_G2_MAX_B && !comb_active();      // (with tables a batch of >= 16 proofs takes the comb path below)
     hipStream_t sk = R.stream2;
     if (side) {
         // the G2 chain first: MSM, blinding s*delta2, Fp2 inversion -- the longest of the tail's chains (5 ms for one AES proof), and on
@@ -1200,20 +1205,30 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm,
         if (split_world == 1) enqueue_tail_early(S, tail);
         dom.dif(S.sb.a.p, B, true, nullptr, st);
         dom.dit(S.sb.a.p, B, false, dom.coset_pre.p, st);
-    } else {
-        dom.to_coset(S.sb.a.p, S.sb.b.p, B, st);
+    }
+    const bool comb = !side && comb_active();
+    // A mid-size batch on the comb path is one call's latency: its transforms (a third of the chain in front of the walk) go to the copy
+    // stream with the pattern extraction behind them, BESIDE the wire MSMs of the main stream, which only need the wires (ChaCha20, 128
+    // proofs: 17.8 -> ... ms per call).  Large batches keep the transforms in front (VALU-bound either way, and the single-stream pass
+    // of bench.py reads the transforms' own duration from ev[3] .. ev[4]).
+    const bool ntt_beside = comb && B <= 256;
+    if (!side) {
+        if (ntt_beside) {
+            ZK_HIP(hipStreamWaitEvent(R.copy_stream, R.ev[3], 0));
+            dom.to_coset(S.sb.a.p, S.sb.b.p, B, R.copy_stream);
+        } else
+            dom.to_coset(S.sb.a.p, S.sb.b.p, B, st);
     }
     ZK_HIP(hipEventRecord(R.ev[4], st));
     if (before_msm) ZK_HIP(hipStreamWaitEvent(st, before_msm, 0));
     bool presorted = false;
-    const bool comb = !side && comb_active();
     R.used_comb = comb;
     if (!side) {
         // the quotient MSM's scalars f = A*B are complete: its bucket sort (LDS / memory bound) -- or, on the comb path, the extraction
         // of its bit-plane patterns -- runs on the copy stream beside the wire MSMs (multiplier bound) and is joined just before the walk
         if (!comb) { products_rows_check(S.sb, N, B); fr_transpose_mul(S.sb.a.p, S.sb.b.p, S.sb.c.p, N, B, N, st); }
         ZK_HIP(hipEventRecord(R.ev[17], st));
-        ZK_HIP(hipStreamWaitEvent(R.copy_stream, R.ev[17], 0));
+        if (!ntt_beside) ZK_HIP(hipStreamWaitEvent(R.copy_stream, R.ev[17], 0));
         if (comb) { comb_patterns(pk.Zcomb, S.sb.a.p, S.sb.b.p, B, R.comb.pat[0].p, R.copy_stream); presorted = true; }
         else presorted = msm_dense_presort(pk.Z, S.sb.c.p + z_offset, B, R.ms, R.copy_stream);
         if (presorted) ZK_HIP(hipEventRecord(R.ev[18], R.copy_stream));

@@ -703,9 +703,9 @@ __device__ __forceinline__ void solve_instruction(const SolveCtx &cx, const uint
 // 4 resident.  Same box, batch 1024: ChaCha20 88.7 ms per step with 4, 90.9 with 1; AES-256 221.1 with 4, 218.8 with 1 (the countHint
 // and division-heavy levels pay for the spills) -- solver_run_levels picks by the program's level count, ZKPROVE_SOLVER_OCC=3|4 overrides.
 template <int LX, int SL, int MINB = 1>
-__global__ __launch_bounds__(256, MINB) void k_solve_level(SolveCtx cx, const uint32_t *__restrict__ instr_off, const uint32_t *__restrict__ level_instr,
+__global__ __launch_bounds__(LX * SL, MINB) void k_solve_level(SolveCtx cx, const uint32_t *__restrict__ instr_off, const uint32_t *__restrict__ level_instr,
                                                      uint32_t count, uint32_t nwide) {
-    static_assert(LX * SL == 256, "workgroup shape");
+    static_assert(LX * SL == 256 || (LX == 64 && SL == 16), "workgroup shape");
     __shared__ Fr red[SL * LX];
     const size_t B = cx.B;
     const size_t b_raw = (size_t)blockIdx.x * LX + threadIdx.x;
@@ -1348,7 +1348,13 @@ void solver_run_levels(const SolverProgram &p, SolverBuffers &buf, size_t first_
         }
         const uint32_t packed_rows = lv.wide + (lv.count - lv.wide + 3) / 4;
         const bool four = occ_env ? occ_env >= 4 : p.levels.size() <= 256;
-        if (pack && buf.B > 16 && packed_rows <= 65535) {
+        const uint32_t packed_rows16 = lv.wide + (lv.count - lv.wide + 15) / 16;
+        if (pack && !four && buf.B > 16 && buf.B <= 128 && packed_rows16 <= 65535) {
+            // mid-size batches of the long programs (AES): one or two instance tiles cannot hide a level's longest instruction -- the ~3 600
+            // queries of a countHint, a 130-term row -- behind other workgroups, so the instruction gets 16 slices instead of 4 (and the
+            // short instructions sixteen to a workgroup).  AES-256, 64 proofs: the 118 wide levels 6.1 -> ... ms (profiles/r05*)
+            hipLaunchKernelGGL((k_solve_level<64, 16, 1>), dim3(ceil_div(buf.B, 64), packed_rows16), dim3(64, 16), 0, s, cx, p.instr_off.p, p.level_instr.p + lv.first, lv.count, lv.wide);
+        } else if (pack && buf.B > 16 && packed_rows <= 65535) {
             if (four) hipLaunchKernelGGL((k_solve_level<64, 4, 4>), dim3(ceil_div(buf.B, 64), packed_rows), dim3(64, 4), 0, s, cx, p.instr_off.p, p.level_instr.p + lv.first, lv.count, lv.wide);
             else hipLaunchKernelGGL((k_solve_level<64, 4, 1>), dim3(ceil_div(buf.B, 64), packed_rows), dim3(64, 4), 0, s, cx, p.instr_off.p, p.level_instr.p + lv.first, lv.count, lv.wide);
         } else {

@@ -456,6 +456,65 @@ __global__ __launch_bounds__(256) void k_bench_bfly_9(Fr *x, const Fr9 *tw, int 
 #pragma unroll
     for (int m = 0; m < 8; m++) x[i * 8 + m] = Fr9::to_words(Fr9::norm(v[m]));
 }
+// radix-4 groups (2 stages, 4 butterflies per 4 elements): what VERDICT r4 task 6 asks to try before any pass kernel -- four 9-limb
+// elements are 36 registers (the radix-8 group's eight were parked in scratch by the compiler).  kind 14: 9 signed limbs kept across the
+// two stages, inline product; kind 15: the 8 x 32 weak form with the same grouping (the reference for the ratio).  4 butterflies / iteration.
+__global__ __launch_bounds__(256) void k_bench_bfly4_words(Fr *x, const Fr *tw, int iters) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    Fr v[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) v[m] = x[i * 4 + m];
+    for (int k = 0; k < iters; k++) {
+#pragma unroll
+        for (int st = 0; st < 2; st++) {
+            const int half = 2 >> st;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                if ((m / half) & 1) continue;
+                const Fr s = Fr::add_w(v[m], v[m + half]), d = Fr::sub_w(v[m], v[m + half]);
+                v[m] = s;
+                v[m + half] = Fr::mul_wc(d, tw[(k + st * 2 + (m % half)) & 63]);
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; m++) x[i * 4 + m] = v[m];
+}
+template <int WAVES>
+__global__ __launch_bounds__(256, WAVES) void k_bench_bfly4_9(Fr *x, const Fr9 *tw, int iters) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    Fr9 v[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) v[m] = Fr9::from_words(x[i * 4 + m]);
+    for (int k = 0; k < iters; k++) {
+#pragma unroll
+        for (int st = 0; st < 2; st++) {
+            const int half = 2 >> st;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                if ((m / half) & 1) continue;
+                const Fr9 s = Fr9::norm(Fr9::add(v[m], v[m + half])), d = Fr9::sub(v[m], v[m + half]);
+                v[m] = s;
+                v[m + half] = Fr9::mul(d, tw[(k + st * 2 + (m % half)) & 63]);
+            }
+        }
+        // once per three groups (= one 6-stage tile visit of the transform kernels) the sums are brought back near [0, M)
+        if (k % 3 == 2) {
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const int32_t q = v[m].l[8] >> 21;
+                int64_t c = 0;
+#pragma unroll
+                for (int j = 0; j < 9; j++) {
+                    c += (int64_t)v[m].l[j] - (int64_t)q * Fr9Params::M[j];
+                    if (j < 8) { v[m].l[j] = (int32_t)(c & 0x1fffffff); c >>= 29; } else v[m].l[j] = (int32_t)c;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; m++) x[i * 4 + m] = Fr9::to_words(Fr9::norm(v[m]));
+}
 __global__ __launch_bounds__(256) void k_bench_mad_i64(uint32_t *x, int iters) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     int32_t a = (int32_t)x[i], b = (int32_t)(x[i] * 2654435761u + 1u);
@@ -550,6 +609,21 @@ extern "C" double zkp_microbench(int kind, long threads, int iters) {
         hipLaunchKernelGGL(k_bench_mul9, dim3(T / 256), dim3(256), 0, 0, x.p, 4);
         ZK_HIP(hipEventRecord(e0, 0));
         hipLaunchKernelGGL(k_bench_mul9, dim3(T / 256), dim3(256), 0, 0, x.p, iters);
+        ZK_HIP(hipEventRecord(e1, 0));
+    } else if (kind == 14 || kind == 15 || kind == 16) {
+        DevBuf<Fr> x(T * 4);
+        std::vector<Fr> h(T * 4);
+        for (size_t i = 0; i < T * 4; i++) for (int k = 0; k < 8; k++) h[i].l[k] = (uint32_t)(i * 2654435761u + k * 40503u) & (k == 7 ? 0x0fffffffu : 0xffffffffu);
+        x.upload(h.data(), T * 4);
+        DevBuf<Fr> tw(64);
+        DevBuf<Fr9> tw9(64);
+        std::vector<Fr9> h9(64);
+        for (int i = 0; i < 64; i++) h9[i] = Fr9::from_words(h[i]);
+        tw.upload(h.data(), 64); tw9.upload(h9.data(), 64);
+        ZK_HIP(hipEventRecord(e0, 0));
+        if (kind == 15) hipLaunchKernelGGL(k_bench_bfly4_words, dim3(T / 256), dim3(256), 0, 0, x.p, tw.p, iters);
+        else if (kind == 14) hipLaunchKernelGGL(k_bench_bfly4_9<1>, dim3(T / 256), dim3(256), 0, 0, x.p, tw9.p, iters);
+        else hipLaunchKernelGGL(k_bench_bfly4_9<2>, dim3(T / 256), dim3(256), 0, 0, x.p, tw9.p, iters);
         ZK_HIP(hipEventRecord(e1, 0));
     } else if (kind == 11 || kind == 12 || kind == 13) {
         DevBuf<Fr> x(T * 8);
