@@ -11,6 +11,9 @@ r1cs = zk.synth.r1cs_bytes(alg)
 pk, _ = zk.setup(r1cs, zk.synth.toxic_from_seed(1), raw=True)
 assert zk.init_algorithm(alg, pk, r1cs)
 rng = zk.synth.SplitMix64(5)
+if "--tables" in sys.argv:      # a server that has served a large batch: comb tables exist, batches >= 16 take them
+    big = json.dumps([json.loads(zk.synth.request_json(alg, zk.synth.make_instance(alg, rng))) for _ in range(128)]).encode()
+    zk.prove_batch_raw(big)
 body = json.dumps([json.loads(zk.synth.request_json(alg, zk.synth.make_instance(alg, rng))) for _ in range(n)]).encode()
 lat = []
 for _ in range(8):

@@ -240,6 +240,41 @@ struct Ntt9 {
     }
 };
 
+// Timing diagnostic (ZKPROVE_NTT_DIAG=9, results are WRONG once a lazy sum leaves the multiplier's range): the butterflies VERDICT r4
+// task 6 asks about -- 9 signed limbs kept LAZY across the stages of a pass (sum and difference limb by limb, no carry, no fold; the
+// product inline against a twiddle re-limbed from its 2^261-form words), one range reduction + carry propagation + conversion per
+// element and HBM pass -- in the production pass kernels.  What the transforms would cost on them at best (the bound-correct version
+// adds a reduction of two of eight elements at the LDS exchange): scripts/debug/ntt_bench.py, profiles/r05*_ntt_lazy9.txt.
+struct Ntt9Lazy {
+    using E = Fr9;
+    static constexpr bool F9 = true;
+    static __device__ __forceinline__ E load(const Fr &w) { return Fr9::from_words(w); }
+    static __device__ __forceinline__ E zero() { return Fr9::zero(); }
+    static __device__ __forceinline__ Fr store(const E &x, bool) {
+        E v = x;
+        const int32_t q = v.l[8] >> 21;            // value / 2^253, estimated on the top limb: v - q M lands within a few M of zero
+        int64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < 9; j++) {
+            c += (int64_t)v.l[j] - (int64_t)q * Fr9Params::M[j];
+            if (j < 8) { v.l[j] = (int32_t)(c & 0x1fffffff); c >>= 29; } else v.l[j] = (int32_t)c;
+        }
+        return Fr9::to_words(v);
+    }
+    static __device__ __forceinline__ E mul(const E &x, const Fr &t) { return Fr9::mul(x, Fr9::from_words(t)); }
+    static __device__ __forceinline__ void dif(E &u, E &v, const Fr *t) {
+        const E s = Fr9::add(u, v), d = Fr9::sub(u, v);
+        u = s;
+        v = Fr9::mul(d, Fr9::from_words(*t));
+    }
+    static __device__ __forceinline__ void dit(E &u, E &v, const Fr *t) {
+        const E w = Fr9::mul(v, Fr9::from_words(*t));
+        const E s = Fr9::add(u, w), d = Fr9::sub(u, w);
+        u = s;
+        v = d;
+    }
+};
+
 #endif  // ZK_EXPERIMENTS
 
 // ---------------------------------------------------------------------------------------------
@@ -1061,9 +1096,10 @@ void NttDomain::dif(Fr *data, size_t B, bool inverse, const Fr *postmul, hipStre
     const Fr *tw = inverse ? tw_inv.p : tw_fwd.p;
 #ifdef ZK_EXPERIMENTS
     static const int diag = [] { const char *e = getenv("ZKPROVE_NTT_DIAG"); return e ? atoi(e) : 0; }();
-    if (diag == 1 || diag == 2 || f9) {
+    if (diag == 1 || diag == 2 || diag == 9 || f9) {
         if (diag == 1) dif_passes<NttDiag<1>>(logn, data, B, tw, postmul, s);
         else if (diag == 2) dif_passes<NttDiag<2>>(logn, data, B, tw, postmul, s);
+        else if (diag == 9) dif_passes<Ntt9Lazy>(logn, data, B, tw, postmul, s);
         else dif_passes<Ntt9>(logn, data, B, table9(tw), table9(postmul), s);
         ZK_HIP(hipGetLastError());
         return;
@@ -1077,9 +1113,10 @@ void NttDomain::dit(Fr *data, size_t B, bool inverse, const Fr *premul, hipStrea
     const Fr *tw = inverse ? tw_inv.p : tw_fwd.p;
 #ifdef ZK_EXPERIMENTS
     static const int diag = [] { const char *e = getenv("ZKPROVE_NTT_DIAG"); return e ? atoi(e) : 0; }();
-    if (diag == 1 || diag == 2 || f9) {
+    if (diag == 1 || diag == 2 || diag == 9 || f9) {
         if (diag == 1) dit_passes<NttDiag<1>>(logn, data, B, tw, premul, s);
         else if (diag == 2) dit_passes<NttDiag<2>>(logn, data, B, tw, premul, s);
+        else if (diag == 9) dit_passes<Ntt9Lazy>(logn, data, B, tw, premul, s);
         else dit_passes<Ntt9>(logn, data, B, table9(tw), table9(premul), s);
         ZK_HIP(hipGetLastError());
         return;

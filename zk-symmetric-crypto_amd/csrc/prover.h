@@ -135,6 +135,7 @@ class Algorithm {
     // Filling the device (comb_prepare): once every circuit loaded on the device has reserved its working sets and built its tables, what
     // is still free goes into the tables -- a prefix of clumps one base larger (CombShape::n1) -- shared between the circuits by relative
     // gain per byte.  One rebuild per algorithm.
+    int wide_run_strikes = 0;                               // grid-barrier timeouts of the one-call solver (resident_prove)
     bool comb_topped = false;
     struct CombPeer { bool settled = false, can_top = false; size_t pending = 0, weight = 0; };
     CombPeer comb_peer_view();                              // caller holds this->mu (try_lock)

@@ -962,6 +962,19 @@ void Algorithm::resident_reserve_buffers(size_t B) {
     wire_comb_reserve(R.ms, true, R.cap);
     if (R.ms_b2.entries.n) wire_comb_reserve(R.ms_b2, true, R.cap);
     if (R.ms2.entries.n) wire_comb_reserve(R.ms2, false, R.cap);
+    if (wire_comb_on) {
+        // the side scratches of batches <= 64 (one MSM chain per stream): room for the wire combs of the base sets that run on them
+        const size_t Bs = std::min(R.cap, SIDE_G2_MAX_B);
+        auto side_room = [&](MsmScratch &sc, std::initializer_list<const MsmBasesG1 *> g1, const MsmBasesG2 *g2) {
+            size_t pw = 0, ab = 0, rb = 0, p = 0, a = 0, r = 0;
+            for (const MsmBasesG1 *mb : g1) { msm_wire_comb_needs(*mb, Bs, p, a, r); pw = std::max(pw, p); ab = std::max(ab, a); rb = std::max(rb, r); }
+            if (g2) { msm_wire_comb_needs(*g2, Bs, p, a, r); pw = std::max(pw, p); ab = std::max(ab, a); rb = std::max(rb, r); }
+            sc.reserve_wire_comb(pw, ab, rb);
+        };
+        side_room(R.ms_a, {&pk.A, &pk.B1}, nullptr);
+        side_room(R.ms_k, {&pk.K}, nullptr);
+        if (has_commit) side_room(R.ms_g2, {&pk.ped_sigma}, &pk.B2); else side_room(R.ms_g2, {}, &pk.B2);
+    }
     // bucket pipeline of the quotient MSM: for every batch when there are no comb tables, else only for the batches too small for the comb
     const size_t nbz = (size_t)1 << (pk.Z.c - 1), ez = pk.Z.n * (size_t)pk.Z.W;
     const size_t Bd = pk.Zcomb.ok ? std::min(B, SIDE_G2_MAX_B) : B;
@@ -1026,7 +1039,7 @@ void Algorithm::enqueue_solve(SolveSet &S, MsmScratch &commit_scratch, hipStream
         solver_run_levels(prog, S.sb, 0, commit_level, st);
         ZK_HIP(hipEventRecord(S.t1, st));
         // BSB22 commitment: C = sum v_i * Basis_i ; challenge = H2F(C.Marshal(), "bsb22-commitment") ; PoK = sum v_i * BasisExpSigma_i
-        if (B <= SIDE_G2_MAX_B && !(wire_comb_on && B >= COMB_SMALL_MIN_B)) {
+        if (B <= SIDE_G2_MAX_B) {
             // small batch: the two Pedersen MSMs are latency-bound chains -- the proof-of-knowledge one runs on the side stream
             // (scratch of the side G2 MSM, idle until the MSM stage) beside the commitment
             ZK_HIP(hipEventRecord(R.ev[14], st));
@@ -1069,9 +1082,8 @@ bool Algorithm::ahead_eligible() const {
     static const bool on = [] { const char *e = ZK_AB_ENV("ZKPROVE_SORT_AHEAD"); return !(e && e[0] == '0'); }();
     const Resident &R = *res;
     const size_t max_entries = pk.Z.n * (size_t)pk.Z.W, nb = (size_t)1 << (pk.Z.c - 1);
-    if (!(on && split_world == 1)) return false;
-    if (comb_active()) return true;
-    if (R.B <= SIDE_G2_MAX_B) return false;                      // the comb path prepares its bit-plane patterns ahead instead of a sorted list
+    if (!(on && R.B > SIDE_G2_MAX_B && split_world == 1)) return false;
+    if (comb_active()) return true;                      // the comb path prepares its bit-plane patterns ahead instead of a sorted list
     // the complete predicate of msm_dense_presort: a batch that does not meet it takes the in-line sort of enqueue_main
     return pk.Z.dense && pk.Z.n != 0 && msm_dense_presort_applicable(pk.Z, R.B, R.ms) && R.ms.entries_zb.n >= R.B * max_entries + 1 &&
            R.ms.bucket_start_zb.n >= R.B * (nb + 1);
@@ -1171,7 +1183,7 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm,
     }
     // A small batch is a set of latency-bound kernel chains: independent chains go to the otherwise idle streams (the transforms of b
     // and the K MSM to the solve stream, the G2 MSM to the copy stream) -- never to new ones, see resident_reserve
-    const bool side = B <= SIDE_G2_MAX_B && !comb_active();      // (with tables a batch of >= 16 proofs takes the comb path below)
+    const bool side = B <= SIDE_G2_MAX_B;      // (with tables a batch of >= 16 proofs takes the comb for its quotient MSM and the wire combs inside these chains)
     hipStream_t sk = R.stream2;
     if (side) {
         // the G2 chain first: MSM, blinding s*delta2, Fp2 inversion -- the longest of the tail's chains (5 ms for one AES proof), and on
@@ -1198,20 +1210,28 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm,
         // at once, beside the transforms
         ZK_HIP(hipStreamWaitEvent(tail, R.ev[3], 0));
         msm_batch(pk.A, S.sb.wires.p, B, R.ms_a, R.m_ar.p, tail);
-        if (before_msm) ZK_HIP(hipStreamWaitEvent(st, before_msm, 0));
-        msm_batch(pk.B1, S.sb.wires.p, B, R.ms, R.m_bs1.p, st);            // beside the A MSM; the main stream's own chain is the shortest
-        ZK_HIP(hipEventRecord(R.ev[12], st));
-        ZK_HIP(hipStreamWaitEvent(tail, R.ev[12], 0));
+        if (comb_active()) {
+            // with tables the main stream carries the call's longest chain -- transforms of a, patterns, quotient walk, fold -- and starts it
+            // at once; the B1 sum follows A on the tail stream (AES-256, 64 proofs: the walk used to wait 4.7 ms for B1's wire combs)
+            if (before_msm) ZK_HIP(hipStreamWaitEvent(tail, before_msm, 0));
+            msm_batch(pk.B1, S.sb.wires.p, B, R.ms, R.m_bs1.p, tail);
+            ZK_HIP(hipEventRecord(R.ev[12], tail));
+        } else {
+            if (before_msm) ZK_HIP(hipStreamWaitEvent(st, before_msm, 0));
+            msm_batch(pk.B1, S.sb.wires.p, B, R.ms, R.m_bs1.p, st);            // beside the A MSM; the main stream's own chain is the shortest
+            ZK_HIP(hipEventRecord(R.ev[12], st));
+            ZK_HIP(hipStreamWaitEvent(tail, R.ev[12], 0));
+        }
         if (split_world == 1) enqueue_tail_early(S, tail);
         dom.dif(S.sb.a.p, B, true, nullptr, st);
         dom.dit(S.sb.a.p, B, false, dom.coset_pre.p, st);
     }
-    const bool comb = !side && comb_active();
+    const bool comb = comb_active();
     // A mid-size batch on the comb path is one call's latency: its transforms (a third of the chain in front of the walk) go to the copy
     // stream with the pattern extraction behind them, BESIDE the wire MSMs of the main stream, which only need the wires (ChaCha20, 128
     // proofs: 17.8 -> ... ms per call).  Large batches keep the transforms in front (VALU-bound either way, and the single-stream pass
     // of bench.py reads the transforms' own duration from ev[3] .. ev[4]).
-    const bool ntt_beside = comb && B <= 256;
+    const bool ntt_beside = comb && !side && B <= 256;
     if (!side) {
         if (ntt_beside) {
             ZK_HIP(hipStreamWaitEvent(R.copy_stream, R.ev[3], 0));
@@ -1258,8 +1278,11 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm,
     // instance-major products
     if (side) {
         ZK_HIP(hipStreamWaitEvent(st, R.ev[15], 0));      // b on the coset comes from the side stream
-        products_rows_check(S.sb, N, B);
-        fr_transpose_mul(S.sb.a.p, S.sb.b.p, S.sb.c.p, N, B, N, st);
+        if (comb) comb_patterns(pk.Zcomb, S.sb.a.p, S.sb.b.p, B, R.comb.pat[0].p, st);
+        else {
+            products_rows_check(S.sb, N, B);
+            fr_transpose_mul(S.sb.a.p, S.sb.b.p, S.sb.c.p, N, B, N, st);
+        }
     }
     if (presorted) ZK_HIP(hipStreamWaitEvent(st, R.ev[18], 0));
     if (comb) comb_msm(pk.Zcomb, R.comb.pat[0].p, B, R.comb, R.m_z.p, st, &R.ev[8]);
@@ -1320,13 +1343,31 @@ void Algorithm::resident_prove(PhaseTimes *times) {
     Resident &R = *res;
     hipStream_t st = R.stream;
     R.last_set = 0;
-    enqueue_solve(R.set[0], R.ms, st);
-    enqueue_main(R.set[0], st, nullptr, R.stream3);
-    ZK_HIP(hipEventRecord(R.ev[10], st));
-    ZK_HIP(hipStreamWaitEvent(R.stream3, R.ev[10], 0));
-    enqueue_finalize(R.set[0], R.stream3);
-    ZK_HIP(hipStreamSynchronize(st));
-    ZK_HIP(hipStreamSynchronize(R.stream3));
+    SolveSet &S0 = R.set[0];
+    // one-call batches of the long programs solve runs of wide levels in one launch each, behind a grid barrier with a bounded poll
+    // (solver.hip, k_solve_wide_run); three timeouts in an algorithm's life and it keeps the per-level launches
+    S0.sb.allow_wide_run = wide_run_strikes < 3;
+    for (int attempt = 0;; attempt++) {
+        enqueue_solve(S0, R.ms, st);
+        enqueue_main(S0, st, nullptr, R.stream3);
+        ZK_HIP(hipEventRecord(R.ev[10], st));
+        ZK_HIP(hipStreamWaitEvent(R.stream3, R.ev[10], 0));
+        enqueue_finalize(S0, R.stream3);
+        ZK_HIP(hipStreamSynchronize(st));
+        ZK_HIP(hipStreamSynchronize(R.stream3));
+        if (S0.sb.sync_arrivals == 0 || attempt) break;                 // no wide-run launch in this call / this was the repeat
+        uint32_t herr[8] = {0};
+        ZK_HIP(hipMemcpy(herr, S0.sb.err.p, std::min<size_t>(R.B, 8) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        bool retry = false;
+        for (size_t i = 0; i < R.B && i < 8; i++) retry = retry || herr[i] == SERR_RETRY;
+        if (!retry) break;
+        wide_run_strikes++;
+        fprintf(stderr, "zkprove: solver grid barrier timed out (device busy): the call is repeated with per-level launches\n");
+        ZK_HIP(hipStreamSynchronize(R.stream2));
+        ZK_HIP(hipStreamSynchronize(R.copy_stream));
+        S0.sb.allow_wide_run = false;
+    }
+    S0.sb.allow_wide_run = false;
     if (times) {
         collect_times(R.set[0], times);
         ZK_HIP(hipEventElapsedTime(&times->total, R.set[0].t0, R.ev[7]));

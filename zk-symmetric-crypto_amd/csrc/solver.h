@@ -13,7 +13,8 @@ namespace zk {
 enum SolverOp : uint32_t { OP_R1C = 1, OP_NBITS = 2, OP_COUNT = 3, OP_RANDOMIZE = 4, OP_BSB22 = 5, OP_LOOKUP = 6 };
 
 // error codes reported per instance (first error wins)
-enum SolverErr : uint32_t { SERR_NONE = 0, SERR_UNSATISFIED = 1, SERR_LOOKUP_RANGE = 2, SERR_COUNT_QUERY = 3 };
+enum SolverErr : uint32_t { SERR_NONE = 0, SERR_UNSATISFIED = 1, SERR_LOOKUP_RANGE = 2, SERR_COUNT_QUERY = 3,
+                            SERR_RETRY = 0xFFFFFFFFu };      // k_solve_wide_run gave up at its grid barrier: the host repeats the call with per-level launches
 
 struct SolverLevel {
     uint32_t first = 0, count = 0;   // range in level_instr
@@ -62,6 +63,9 @@ struct SolverBuffers {
     DevBuf<Fr> challenge;      // [B] Montgomery (commitment challenge)
     DevBuf<uint32_t> err;      // [B] (code | constraint<<8)
     DevBuf<uint32_t> count_scratch;
+    DevBuf<uint32_t> sync;     // [0] arrival counter, [1] abort word of k_solve_wide_run's grid barrier (cleared by solver_begin)
+    uint32_t sync_arrivals = 0;      // what the counter holds after the wide-run launches enqueued since solver_begin
+    bool allow_wide_run = false;     // set by the one entry that can repeat a call after SERR_RETRY (Algorithm::resident_prove); the pipelined entries keep per-level launches
     void reserve(const SolverProgram &p, size_t B, size_t c_B = (size_t)-1);      // c_B: instances the own c rows are sized for (default B)
 };
 

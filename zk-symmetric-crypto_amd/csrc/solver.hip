@@ -426,6 +426,7 @@ void SolverBuffers::reserve(const SolverProgram &p, size_t B_, size_t c_B) {
     raw.ensure(SOLVER_RAW_STRIDE * B);
     randomize.ensure(B); challenge.ensure(B); err.ensure(B);
     count_scratch.ensure((p.n_count_rows ? p.n_count_rows : 1) * (p.n_count_slots ? p.n_count_slots : 1) * B);
+    sync.ensure(2);
 }
 
 // ----------------------------------------------------------------------------------- kernels
@@ -944,6 +945,85 @@ __global__ __launch_bounds__(LX * SL) void k_solve_narrow_run(SolveCtx cx, const
     }
 }
 
+// ---------------------------------------------------------------------------------------- one-call batches: runs of WIDE levels in one launch
+// A single AES Prove() call (B <= 8; VERDICT r4 task 5): its 118 wide levels -- up to ~100 instructions each, long rows and countHints --
+// cost 2.5 ms as 118 dependent launches (21 us each: the launch gap plus, inside every launch, the chain  level -> instruction number
+// -> program offset -> header -> terms -> wires  of dependent loads), and the eleven division launches around them another millisecond.
+// Here a run of consecutive levels is ONE launch of G workgroups (G = the widest level of the run, at most WIDE_RUN_MAX_G: a fraction of
+// the device, so every workgroup is resident as soon as the kernel starts on an idle device): workgroup w solves instructions w, w + G, ...
+// of a level with the same code as k_solve_level<8, 32>, then all meet at a grid barrier -- one monotonic counter in HBM, lane 0 of every
+// workgroup: agent-scope release, arrive, poll, agent-scope acquire (MI355X_MICROARCH.md, barrier-counter) -- and the level's deferred
+// divisions follow behind a second one.  What a launch boundary cannot do: the PROGRAM of the next level does not depend on the wires, so
+// a workgroup fetches its next instruction's words while it waits at the barrier; behind the barrier only the wire values are new.
+// The barrier cannot hang: the poll is BOUNDED (spin_limit iterations, ~50 ms).  A workgroup that gives up raises an abort word that
+// every poll also reads, all workgroups leave, and every instance's error word becomes SERR_RETRY: the host then repeats the call with
+// the per-level launches (Algorithm::resident_prove).  (Co-residency is only delayed, never denied, when another stream's kernel
+// holds the wave slots: its workgroups retire and ours start; the spinning ones keep their slots.)
+static constexpr uint32_t WIDE_RUN_MAX_G = 96;
+static constexpr uint32_t WIDE_RUN_SPIN_LIMIT = 200000;
+// all threads of the workgroup call it; false: aborted (timeout here or in another workgroup)
+__device__ __forceinline__ bool grid_barrier(uint32_t *sync, uint32_t target, uint32_t spin_limit, int *ok_s) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wavefront drains its stores before the workgroup's barrier ...
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // ... and one lane releases them to the other XCDs
+        __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool ok = true;
+        uint32_t spins = 0;
+        while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (__hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || ++spins > spin_limit) { ok = false; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (!ok) __hip_atomic_store(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // this CU's vector L1 forgets what other workgroups have overwritten
+        *ok_s = ok ? 1 : 0;
+    }
+    __syncthreads();
+    return *ok_s != 0;
+}
+template <int LX, int SL>
+__global__ __launch_bounds__(LX * SL) void k_solve_wide_run(SolveCtx cx, const uint32_t *__restrict__ instr_off, const uint32_t *__restrict__ level_instr,
+                                                            const uint32_t *__restrict__ level_desc, const uint32_t *__restrict__ div_list, uint32_t l0, uint32_t l1,
+                                                            uint32_t *__restrict__ sync, uint32_t sync_base, uint32_t spin_limit) {
+    __shared__ Fr red[SL * LX];
+    __shared__ int ok_s;
+    const uint32_t G = gridDim.x, w = blockIdx.x;
+    const size_t b_raw = threadIdx.x;                  // one tile of instances: B <= LX
+    const bool live = b_raw < cx.B;
+    const size_t b = live ? b_raw : cx.B - 1;
+    uint32_t epoch = sync_base;                        // arrivals the counter holds when this launch starts (earlier launches of the call)
+    if (threadIdx.x == 0 && threadIdx.y == 0) ok_s = 1;
+    __syncthreads();
+    for (uint32_t l = l0; l < l1; l++) {
+        const uint32_t first = level_desc[5 * l], count = level_desc[5 * l + 1], div_first = level_desc[5 * l + 3], div_count = level_desc[5 * l + 4];
+        const uint32_t *li = level_instr + first;
+        for (uint32_t i = w; i < count; i += G) solve_instruction<LX, SL, true>(cx, instr_off, li[i], b, live, threadIdx.y == 0 && live, red);
+        // the next level's program for this workgroup -- description, instruction number, offset, record -- is requested now, by the
+        // last slice, and sits in the scalar cache when the barrier opens (k_solve_narrow_run's prefetcher, across workgroups here)
+        if (threadIdx.y == SL - 1 && l + 1 < l1) {
+            const uint32_t f2 = level_desc[5 * (l + 1)], c2 = level_desc[5 * (l + 1) + 1];
+            uint32_t sink = level_desc[5 * (l + 1) + 2] ^ level_desc[5 * (l + 1) + 3] ^ level_desc[5 * (l + 1) + 4];
+            if (w < c2) {
+                const uint32_t *p = cx.prog + instr_off[level_instr[f2 + w]];
+                uint32_t words = p[0] == OP_R1C ? 8 + 2 * (p[2] + p[3] + p[4]) : (p[0] == OP_NBITS ? 4 + 2 * p[3] : 16u);
+                if (words > 1024) words = 1024;
+                for (uint32_t k = 0; k < words; k += 16) sink ^= p[k];
+                sink ^= p[words - 1];
+            }
+            asm volatile("" ::"s"(sink));
+        }
+        epoch += G;
+        if (!grid_barrier(sync, epoch, spin_limit, &ok_s)) break;
+        if (div_count) {
+            for (uint32_t g = w * SL + threadIdx.y; g * 2 < div_count; g += G * SL)
+                if (live) solve_division_group<2>(cx, div_list + 4 * (size_t)div_first, div_count, g * 2, b);
+            epoch += G;
+            if (!grid_barrier(sync, epoch, spin_limit, &ok_s)) break;
+        }
+    }
+    if (!ok_s && live && threadIdx.y == 0) cx.err[b] = SERR_RETRY;      // (ok_s is only ever cleared by an aborted barrier; every workgroup that saw one says so)
+}
+
 // ---------------------------------------------------------------------------------------- small batches: the lane program
 // A single Prove() call -- what the reference's own harness and the unchanged JS operator issue (gnark/libraries/core_test.go:121-150) --
 // is latency: one launch per level costs 163 (ChaCha20) / 137 (AES-256, after the narrow runs) dependent launches of ~15 us, 2.5 / 5 ms
@@ -1239,6 +1319,8 @@ void solver_begin(const SolverProgram &p, SolverBuffers &buf, hipStream_t s) {
         ZK_HIP(hipMemsetAsync(buf.b.p + first_clear * B, 0, (N - first_clear) * B * sizeof(Fr), s));
     }
     ZK_HIP(hipMemsetAsync(buf.err.p, 0, B * sizeof(uint32_t), s));
+    ZK_HIP(hipMemsetAsync(buf.sync.p, 0, 2 * sizeof(uint32_t), s));
+    buf.sync_arrivals = 0;
     if (buf.raw_alg >= 0) {
         const size_t want = buf.raw_alg == 0 ? 2560 : (buf.raw_alg == 1 ? 241 : 257);
         if (p.n_inputs != want) throw ZkError("solver: raw witness records do not match the circuit");
@@ -1327,8 +1409,31 @@ void solver_run_levels(const SolverProgram &p, SolverBuffers &buf, size_t first_
     static const bool pack = [] { const char *e = ZK_AB_ENV("ZKPROVE_SOLVER_PACK"); return !(e && e[0] == '0'); }();
     static const int occ_env = [] { const char *e = ZK_AB_ENV("ZKPROVE_SOLVER_OCC"); return e ? atoi(e) : 0; }();
     static const bool fuse_runs = [] { const char *e = ZK_AB_ENV("ZKPROVE_SOLVER_RUNS"); return !(e && e[0] == '0'); }();
+    // one-call batches of the long programs (B <= 8: a single AES Prove(), a few coalesced ones): the levels between two narrow runs as
+    // ONE launch each (k_solve_wide_run: grid barrier with a bounded poll); SolverBuffers::allow_wide_run: only where the caller can repeat the call after a timeout
+    static const bool wide_runs = [] { const char *e = ZK_AB_ENV("ZKPROVE_SOLVER_WIDE_RUN"); return !(e && e[0] == '0'); }();
+    static const uint32_t spin_limit = [] { const char *e = ZK_AB_ENV("ZKPROVE_SOLVER_SPIN_LIMIT"); return e ? (uint32_t)atol(e) : WIDE_RUN_SPIN_LIMIT; }();
+    const bool use_wide = wide_runs && fuse_runs && buf.B <= 8 && buf.allow_wide_run && buf.sync.n >= 2;
+    auto narrow_run_at = [&](size_t l) { return p.levels[l].narrow && l + 1 < last_level && l + 1 < p.levels.size() && p.levels[l + 1].narrow; };
     for (size_t l = first_level; l < last_level && l < p.levels.size(); l++) {
         const SolverLevel &lv = p.levels[l];
+        if (use_wide && !narrow_run_at(l)) {
+            size_t e = l;
+            uint32_t maxc = 1, barriers = 0;
+            while (e < last_level && e < p.levels.size() && !narrow_run_at(e)) {
+                maxc = std::max(maxc, p.levels[e].count);
+                barriers += 1 + (p.levels[e].div_count ? 1 : 0);
+                e++;
+            }
+            if (e - l >= 2) {
+                const uint32_t G = std::min(maxc, WIDE_RUN_MAX_G);
+                hipLaunchKernelGGL((k_solve_wide_run<8, 32>), dim3(G), dim3(8, 32), 0, s, cx, p.instr_off.p, p.level_instr.p, p.level_desc.p, p.div_list.p, (uint32_t)l, (uint32_t)e,
+                                   buf.sync.p, buf.sync_arrivals, spin_limit);
+                buf.sync_arrivals += G * barriers;
+                l = e - 1;
+                continue;
+            }
+        }
         if (!lv.count) continue;
         if (fuse_runs && lv.narrow) {
             // a run of narrow levels: one launch (a single narrow level takes the ordinary launch)
