@@ -665,7 +665,14 @@ void Algorithm::comb_prepare(size_t B) {
         const double by_share = 0.42 * (double)total_b / (double)share;
         const double by_free = free_b > still_needed ? 0.75 * (double)(free_b - still_needed) : 0.0;
         CombPick pick = comb_pick_shape(pk.ze.n, std::min(by_share, by_free), false);
-        if (comb_forced_k()) { pick = CombPick(); pick.k = comb_forced_k(); pick.bytes = zk::comb_table_bytes(pk.ze.n, pick.k); pick.clumps = (pk.ze.n + pick.k - 1) / pick.k; }
+        if (comb_forced_k()) {      // ZKPROVE_COMB_K (and ZKPROVE_COMB_N1: leading clumps of k + 1 bases): a fixed shape, e.g. the two-circuit shape for a one-circuit profiling run
+            static const size_t forced_n1 = [] { const char *e = getenv("ZKPROVE_COMB_N1"); return e ? (size_t)atol(e) : (size_t)0; }();
+            pick = CombPick();
+            pick.k = comb_forced_k();
+            pick.n1 = std::min(forced_n1, pk.ze.n / (size_t)(pick.k + 1));
+            pick.bytes = comb_mixed_bytes(pk.ze.n, pick.k, pick.n1);
+            pick.clumps = comb_mixed_clumps(pk.ze.n, pick.k, pick.n1);
+        }
         else if (settled && pick.k) {
             // everything the neighbours need is known: fill the device
             const double avail = (double)free_b - (double)still_needed - (double)peers_pending;
@@ -1210,9 +1217,12 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm,
         // at once, beside the transforms
         ZK_HIP(hipStreamWaitEvent(tail, R.ev[3], 0));
         msm_batch(pk.A, S.sb.wires.p, B, R.ms_a, R.m_ar.p, tail);
-        if (comb_active()) {
+        if (comb_active() && !has_commit) {
             // with tables the main stream carries the call's longest chain -- transforms of a, patterns, quotient walk, fold -- and starts it
-            // at once; the B1 sum follows A on the tail stream (AES-256, 64 proofs: the walk used to wait 4.7 ms for B1's wire combs)
+            // at once; the B1 sum (conditional sums only for ChaCha20) follows A on the tail stream: 64 proofs 10.97 -> 10.60 ms, 16: 5.98 ->
+            // 5.59.  NOT for the AES programs: their wire MSMs are chains of ~15 short kernels each, and whatever of them is still queued when
+            // the walk starts waits for wave slots under it (the walk's single-wave workgroups take them all): 31.4 -> 33.0 ms at 64 proofs
+            // with the walk first (profiles/r05g_timeline_aes_64.txt) -- there the chains go first and the walk last
             if (before_msm) ZK_HIP(hipStreamWaitEvent(tail, before_msm, 0));
             msm_batch(pk.B1, S.sb.wires.p, B, R.ms, R.m_bs1.p, tail);
             ZK_HIP(hipEventRecord(R.ev[12], tail));

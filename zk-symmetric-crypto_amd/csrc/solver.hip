@@ -1411,7 +1411,12 @@ void solver_run_levels(const SolverProgram &p, SolverBuffers &buf, size_t first_
     static const bool fuse_runs = [] { const char *e = ZK_AB_ENV("ZKPROVE_SOLVER_RUNS"); return !(e && e[0] == '0'); }();
     // one-call batches of the long programs (B <= 8: a single AES Prove(), a few coalesced ones): the levels between two narrow runs as
     // ONE launch each (k_solve_wide_run: grid barrier with a bounded poll); SolverBuffers::allow_wide_run: only where the caller can repeat the call after a timeout
-    static const bool wide_runs = [] { const char *e = ZK_AB_ENV("ZKPROVE_SOLVER_WIDE_RUN"); return !(e && e[0] == '0'); }();
+    // MEASURED AND LOST (profiles/r05g_*): AES-256 Prove() 14.7 ms with it against 10.7 ms without, same box.  The premise was wrong: a wide level
+    // of these programs holds up to ~5 000 instructions, which a launch spreads over the whole device in ~20 us; a barrier that cannot hang
+    // needs every workgroup resident, and at the <= 96 workgroups that is safe for, each of them works through ~50 instructions per level
+    // one after the other (at 768+ workgroups a barrier costs as much as the launch it replaces: MI355X_MICROARCH.md, barrier-counter).
+    // Off unless ZKPROVE_SOLVER_WIDE_RUN=1 in the experiments build, where the parity and forced-timeout tests keep it bit-exact.
+    static const bool wide_runs = [] { const char *e = ZK_AB_ENV("ZKPROVE_SOLVER_WIDE_RUN"); return e && e[0] == '1'; }();
     static const uint32_t spin_limit = [] { const char *e = ZK_AB_ENV("ZKPROVE_SOLVER_SPIN_LIMIT"); return e ? (uint32_t)atol(e) : WIDE_RUN_SPIN_LIMIT; }();
     const bool use_wide = wide_runs && fuse_runs && buf.B <= 8 && buf.allow_wide_run && buf.sync.n >= 2;
     auto narrow_run_at = [&](size_t l) { return p.levels[l].narrow && l + 1 < last_level && l + 1 < p.levels.size() && p.levels[l + 1].narrow; };
