@@ -574,6 +574,11 @@ static CombPick comb_pick_shape(size_t n, double budget, bool mixed) {
     p.clumps = comb_mixed_clumps(n, p.k, p.n1);
     return p;
 }
+// ZKPROVE_COMB_FILL=0: the round-4 budget only -- a share of the device, one clump size, no top-up (same-box A/B of the device-filling budget)
+static bool comb_fill_enabled() {
+    static const bool on = [] { const char *e = getenv("ZKPROVE_COMB_FILL"); return !(e && e[0] == '0'); }();
+    return on;
+}
 static int comb_forced_k() {
     static const int forced = [] { const char *e = getenv("ZKPROVE_COMB_K"); return e ? atoi(e) : 0; }();
     return forced;
@@ -673,7 +678,7 @@ void Algorithm::comb_prepare(size_t B) {
             pick.bytes = comb_mixed_bytes(pk.ze.n, pick.k, pick.n1);
             pick.clumps = comb_mixed_clumps(pk.ze.n, pick.k, pick.n1);
         }
-        else if (settled && pick.k) {
+        else if (settled && pick.k && comb_fill_enabled()) {
             // everything the neighbours need is known: fill the device
             const double avail = (double)free_b - (double)still_needed - (double)peers_pending;
             const size_t my_weight = pick.k < 20 ? zk::comb_table_bytes(pk.ze.n, pick.k + 1) - zk::comb_table_bytes(pk.ze.n, pick.k) : 0;
@@ -713,7 +718,7 @@ void Algorithm::comb_prepare(size_t B) {
 // neighbour's needs were unknown; now that every circuit on the device has settled, this replica's share of what is still free goes
 // into a prefix of larger clumps.  The old table is released first (both do not fit), so a failed build falls back to the old shape.
 void Algorithm::comb_top_up() {
-    if (!res || !pk.Zcomb.ok || comb_topped || comb_forced_k() || split_world != 1 || res->B < comb_min_batch() || !peers_visit) return;
+    if (!res || !pk.Zcomb.ok || comb_topped || comb_forced_k() || !comb_fill_enabled() || split_world != 1 || res->B < comb_min_batch() || !peers_visit) return;
     Resident &R = *res;
     std::lock_guard<std::mutex> budget(g_comb_budget_lock[device & 63]);
     bool settled = true;
