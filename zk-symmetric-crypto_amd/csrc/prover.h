@@ -147,6 +147,7 @@ class Algorithm {
     bool relieve_pressure(bool rereserve);                  // own tables first (rereserve: + the bucket pipeline's buffers, comb_release), one idle neighbour's next
     void enqueue_ntt_sort(struct SolveSet &S, hipStream_t sn, int slot, hipEvent_t slot_free = nullptr);
     hipStream_t side_chain_stream(hipStream_t solve_stream, struct SolveSet &S);
+    void enqueue_patterns_late(struct SolveSet &S, hipEvent_t walk_done);
     void enqueue_tail_early(struct SolveSet &S, hipStream_t st);
     void enqueue_finalize(struct SolveSet &S, hipStream_t st);
     void collect_times(struct SolveSet &S, PhaseTimes *times);

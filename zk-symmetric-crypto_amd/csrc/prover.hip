@@ -123,6 +123,7 @@ struct SolveSet {
     hipEvent_t zdone = nullptr;        // the quotient MSM of this batch has read its sorted list (the slot may be refilled)
     bool ahead = false;                // ... were enqueued by enqueue_ntt_sort (enqueue_main then starts at the wire MSMs)
     int zslot = 0;                     // which copy of the sorted list / of the comb patterns they filled
+    bool pat_pending = false;          // one pattern slot: the transforms are enqueued, the patterns wait for the walk in front (enqueue_patterns_late)
     bool comb = false;                 // ... as comb patterns (msm_comb.hip) rather than a sorted bucket list
     bool ready = false;
     void reserve(const SolverProgram &prog, size_t B, size_t c_B = (size_t)-1) {
@@ -575,6 +576,14 @@ static CombPick comb_pick_shape(size_t n, double budget, bool mixed) {
     return p;
 }
 // ZKPROVE_COMB_FILL=0: the round-4 budget only -- a share of the device, one clump size, no top-up (same-box A/B of the device-filling budget)
+// Copies of the bit-plane patterns of the quotient comb (nclumps x 254 x B words each: 3.4 GB ChaCha20, 7.4 GB AES-256 at B = 1024).  TWO let the
+// next batch's patterns be written while this batch is walked -- but nothing runs under the walk (its single-wave workgroups take every
+// wave slot), so the extraction ends up in the window behind it anyway; with ONE (default since round 5) it is enqueued behind the
+// walk in front and the second copy's 10.7 GB go into the tables.  ZKPROVE_PAT_SLOTS=2: the old double buffer (same-box A/B: DESIGN.md section 9).
+static int pat_slots() {
+    static const int v = [] { const char *e = getenv("ZKPROVE_PAT_SLOTS"); return e && e[0] == '2' ? 2 : 1; }();
+    return v;
+}
 static bool comb_fill_enabled() {
     static const bool on = [] { const char *e = getenv("ZKPROVE_COMB_FILL"); return !(e && e[0] == '0'); }();
     return on;
@@ -648,7 +657,7 @@ void Algorithm::comb_prepare(size_t B) {
         std::lock_guard<std::mutex> budget(g_comb_budget_lock[device & 63]);
         // still to come for this replica: the second and third working set of the pipelined entries, the two pattern copies (~ the
         // table's clump count x 254 x B words: bounded by the k = 16 figure), range accumulators, and slack for the allocator
-        const size_t still_needed = pending_bytes() + 2 * ((pk.ze.n / 16 + 1) * 254 * B * sizeof(uint32_t)) + COMB_HEADROOM;
+        const size_t still_needed = pending_bytes() + (size_t)pat_slots() * ((pk.ze.n / 16 + 1) * 254 * B * sizeof(uint32_t)) + COMB_HEADROOM;
         const int loaded = loaded_on_device ? loaded_on_device(device) : comb_share;      // algorithm replicas on this GPU right now, this one included
         const int share = std::max(std::max(loaded, comb_share), 1);
         size_t free_b = 0, total_b = 0;
@@ -710,7 +719,7 @@ void Algorithm::comb_prepare(size_t B) {
         if (!ok) fprintf(stderr, "zkprove: comb tables of the quotient MSM not built (%s): the bucket pipeline is kept\n", why.c_str());
     }
     if (pk.Zcomb.ok && R.comb_cap < B) {
-        R.comb.reserve(pk.Zcomb, B, 2);
+        R.comb.reserve(pk.Zcomb, B, pat_slots());
         R.comb_cap = B;
     }
 }
@@ -764,7 +773,7 @@ void Algorithm::comb_top_up() {
         try { ok = comb_build(pk.Zcomb, pk.ze.p, n, old_k, R.stream, old_n1); } catch (const ZkError &) { pk.Zcomb = CombBases(); (void)hipGetLastError(); }
         if (!ok) { fprintf(stderr, "zkprove: comb tables lost: this algorithm continues on the bucket pipeline\n"); comb_release(); return; }
     }
-    R.comb.reserve(pk.Zcomb, R.cap, 2);
+    R.comb.reserve(pk.Zcomb, R.cap, pat_slots());
 }
 
 void bsb22_challenge_device(const G1Affine *com_canonical, Fr *challenge_mont, size_t n, hipStream_t s) {
@@ -1122,6 +1131,14 @@ void Algorithm::enqueue_ntt_sort(SolveSet &S, hipStream_t sn, int slot, hipEvent
     ZK_HIP(hipEventRecord(R.ev[17], sn));
     ZK_HIP(hipStreamWaitEvent(R.copy_stream, R.ev[17], 0));
     if (slot_free) ZK_HIP(hipStreamWaitEvent(R.copy_stream, slot_free, 0));      // the quotient MSM that walked this copy of the list is done
+    if (S.comb && pat_slots() == 1) {
+        // one pattern copy: written once the walk in front has read it -- enqueue_patterns_late, called by the pipelined entries right
+        // after that walk has been enqueued (its event must be the one of THAT batch)
+        S.pat_pending = true;
+        S.ahead = true;
+        S.zslot = 0;
+        return;
+    }
     if (S.comb) {
         // comb path: the products f = A*B are formed on the fly and only their bit planes (table indices) are written
         comb_patterns(pk.Zcomb, S.sb.a.p, S.sb.b.p, B, R.comb.pat[slot].p, R.copy_stream);
@@ -1132,6 +1149,16 @@ void Algorithm::enqueue_ntt_sort(SolveSet &S, hipStream_t sn, int slot, hipEvent
     ZK_HIP(hipEventRecord(S.sorted, R.copy_stream));
     S.ahead = true;
     S.zslot = slot;
+}
+// One pattern slot: the patterns of an ahead-prepared batch, behind the walk of the batch in front of it (walk_done: that batch's zdone,
+// nullptr for the first batch of a call).  Copy stream: behind this batch's transforms, which were enqueued there (ev[17] of its own).
+void Algorithm::enqueue_patterns_late(SolveSet &S, hipEvent_t walk_done) {
+    if (!S.pat_pending) return;
+    Resident &R = *res;
+    if (walk_done) ZK_HIP(hipStreamWaitEvent(R.copy_stream, walk_done, 0));
+    comb_patterns(pk.Zcomb, S.sb.a.p, S.sb.b.p, R.B, R.comb.pat[0].p, R.copy_stream);
+    ZK_HIP(hipEventRecord(S.sorted, R.copy_stream));
+    S.pat_pending = false;
 }
 // NTT + MSM of one solved batch on stream st.  R.ev[3..9] bracket the phases.  before_msm (optional): an event the MSMs must
 // wait for -- they overwrite the per-batch sums that the previous batch's tail (on another stream) still reads.
@@ -1511,12 +1538,14 @@ void Algorithm::resident_prove_pipelined(int nsteps, PhaseTimes *times) {
     ZK_HIP(hipStreamWaitEvent(F, R.ev[0], 0));
     auto prepare = [&](int j, hipEvent_t set_free, hipEvent_t slot_free) {      // solve stage of batch j on the solve stream, its ahead work (transforms, patterns / sort) on the copy stream
         SolveSet &nx = R.set[j % NS];
+        nx.pat_pending = false;
         if (set_free) ZK_HIP(hipStreamWaitEvent(S, set_free, 0));
         enqueue_solve(nx, has_commit ? R.ms2 : R.ms, S);
         ZK_HIP(hipEventRecord(nx.solved, S));
         if (ahead) enqueue_ntt_sort(nx, side_chain_stream(S, nx), j & 1, slot_free);
     };
     for (int j = 0; j < D && j < nsteps; j++) prepare(j, nullptr, nullptr);
+    enqueue_patterns_late(R.set[0], nullptr);                  // (one pattern slot: batch 0's patterns have no walk in front of them)
     for (int k = 0; k < nsteps; k++) {
         SolveSet &cur = R.set[k % NS];
         ZK_HIP(hipStreamWaitEvent(M, cur.solved, 0));
@@ -1526,6 +1555,9 @@ void Algorithm::resident_prove_pipelined(int nsteps, PhaseTimes *times) {
         enqueue_finalize(cur, F);
         ZK_HIP(hipEventRecord(R.ev[11], F));
         ZK_HIP(hipEventRecord(cur.consumed, F));
+        // one pattern slot: batch k + 1's patterns behind THIS walk (its event is recorded now), in front of batch k + 2's transforms on
+        // the copy stream; with one batch of lead batch k + 1 is only prepared below, and its patterns follow there
+        if (k + 1 < nsteps) enqueue_patterns_late(R.set[(k + 1) % NS], cur.zdone);
         const int j = k + D;
         if (j < nsteps) {
             // set j % NS last held batch j - NS (= k - 1 for D = 2, k for D = 1 ... no: k - 1 in both): free once that batch's tail is done;
@@ -1535,6 +1567,7 @@ void Algorithm::resident_prove_pipelined(int nsteps, PhaseTimes *times) {
             hipEvent_t slot_free = (ahead && j >= 2) ? R.set[(j - 2) % NS].zdone : nullptr;
             prepare(j, reused ? nx.consumed : nullptr, slot_free);
         }
+        if (k + 1 < nsteps) enqueue_patterns_late(R.set[(k + 1) % NS], cur.zdone);
     }
     ZK_HIP(hipStreamSynchronize(S));
     ZK_HIP(hipStreamSynchronize(R.copy_stream));
@@ -1723,6 +1756,7 @@ void Algorithm::prove_stream(ChunkFeed &feed, PhaseTimes *times) {
         const size_t j = fetched++;
         SolveSet &nx = R.set[j % NS];
         held[j % NS] = c;
+        nx.pat_pending = false;
         set_batch(c.count);
         nx.sb.B = c.count;
         // inputs go up on the solve stream itself (the set is free: its previous chunk has been downloaded); the copy stream carries
@@ -1733,10 +1767,17 @@ void Algorithm::prove_stream(ChunkFeed &feed, PhaseTimes *times) {
         if (ahead_eligible()) enqueue_ntt_sort(nx, side_chain_stream(S, nx), (int)(j & 1), j >= 2 ? R.set[(j - 2) % NS].zdone : nullptr);
         return true;
     };
+    // one pattern slot: the patterns of chunk n go behind the walk of chunk n - 1 (enqueue_patterns_late), with chunk n's own batch size
+    auto late_patterns = [&](size_t n, hipEvent_t walk_done) {
+        if (n >= fetched || !R.set[n % NS].pat_pending) return;
+        set_batch(held[n % NS].count);
+        enqueue_patterns_late(R.set[n % NS], walk_done);
+    };
     size_t k = 0;
     try {
     for (size_t j = 0; j < D; j++)
         if (!prepare()) break;
+    late_patterns(0, nullptr);
     for (; k < fetched; k++) {
         SolveSet &cur = R.set[k % NS];
         set_batch(held[k % NS].count);
@@ -1748,8 +1789,10 @@ void Algorithm::prove_stream(ChunkFeed &feed, PhaseTimes *times) {
         enqueue_finalize(cur, F);
         ZK_HIP(hipEventRecord(R.ev[11], F));
         ZK_HIP(hipEventRecord(cur.consumed, F));
+        late_patterns(k + 1, cur.zdone);        // (before the host blocks in download; in front of chunk k + 2's transforms on the copy stream)
         if (k >= 1) download(k - 1);            // frees set (k - 1) % NS == (k + D) % NS; at most NS chunks are away from the feed
         prepare();                              // chunk k + D
+        late_patterns(k + 1, cur.zdone);        // (one chunk of lead: chunk k + 1 was prepared just now)
     }
     } catch (...) {
         // nothing may still read the caller's pinned chunk buffers or write this replica's sets when the error reaches the caller
