@@ -142,7 +142,8 @@ int zkp_split_partials(int algorithmID, uint8_t *out384);
 int zkp_split_finish(int algorithmID, int world, const uint8_t *gathered);
 /* how the MSMs of the current resident batch run: info8 = {1 comb path of the quotient MSM | 0 bucket pipeline, clump size k | window bits c,
  * clumps | windows, table MiB, mixed additions per proof of its walk, 1 when the wire MSMs use wire combs for their non-0/+-1 positions,
- * such positions in G1.A, wire-comb table MiB} */
+ * such positions in G1.A, wire-comb table MiB}.  Mixed comb tables (the memory budget fills the device: a prefix of clumps holds k + 1
+ * bases): [1] is the smaller size k, [2] the clump count -- bases - clumps * k of them are the large ones, up to the last clump's slack */
 int zkp_quotient_msm_info(int algorithmID, long *info8);
 /* request -> witness assignment (host logic only, no GPU): fills inputs[n_inputs], output bytes; returns
  * 0, or -1 with the reference's panic text in zkp_last_error() */

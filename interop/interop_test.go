@@ -197,6 +197,34 @@ func runCase(t *testing.T, id uint8, ext, cipher string, keyLen, nBlocks, blockL
 		}
 		vreqs = append(vreqs, r)
 	}
+	// ZkpProveBatchDeterministic (round 5): the same array under caller-supplied blinding -- two calls give byte-identical proofs, and the
+	// reference verifier accepts them (the batch-size-switched kernel paths of 24 requests: bucket pipeline before, comb tables after a
+	// large batch has been served)
+	blind := make([]byte, 3*n*32)
+	for i := 0; i < 3*n; i++ {
+		blind[i*32] = byte(i + 1) // small canonical little-endian scalars
+	}
+	det := func() []*prover.OutputParams {
+		r := C.ZkpProveBatchDeterministic(goSlice(body), C.long(n), (*C.uint8_t)(unsafe.Pointer(&blind[0])), (*C.uint8_t)(unsafe.Pointer(&blind[n*32])),
+			(*C.uint8_t)(unsafe.Pointer(&blind[2*n*32])))
+		var o []*prover.OutputParams
+		if err := json.Unmarshal(C.GoBytes(r.r0, C.int(r.r1)), &o); err != nil || len(o) != n {
+			t.Fatalf("%s: ZkpProveBatchDeterministic answered %s", cipher, C.GoString((*C.char)(r.r0)))
+		}
+		C.Free(r.r0)
+		return o
+	}
+	d1, d2 := det(), det()
+	for i := range d1 {
+		if !bytes.Equal(d1[i].Proof, d2[i].Proof) {
+			t.Fatalf("%s: deterministic batch proofs differ between two calls (element %d)", cipher, i)
+		}
+		sig, _ := json.Marshal(&verifier.PublicSignalsJSON{Ciphertext: d1[i].Ciphertext, Blocks: vblocks, Input: input})
+		r, _ := json.Marshal(&verifier.InputVerifyParams{Cipher: cipher, Proof: d1[i].Proof, PublicSignals: sig})
+		if !verifier.Verify(r) {
+			t.Fatalf("%s: reference verifier rejected a deterministic-batch proof", cipher)
+		}
+	}
 	vreqs = append(vreqs, req2) // gnark's own proof
 	bad, _ := json.Marshal(&verifier.InputVerifyParams{Cipher: cipher, Proof: outs[0].Proof, PublicSignals: signals}) // proof 0 under the first request's signals is fine ...
 	_ = bad

@@ -454,17 +454,20 @@ print(json.dumps(out))
 """
 
 def test_a_third_circuit_takes_the_idle_neighbours_tables():
-    """Three circuits with 1024-chunks on one GPU: the tables and working sets of ChaCha20 and AES-256 fill the device, AES-128's working
-    sets do not fit and it has no tables of its own to give back.  Its request must not fail for the sake of another circuit's
-    optimisation: the least recently used idle neighbour (ChaCha20) gives its comb tables back (cabi.cpp release_neighbours,
-    prover.hip relieve_pressure) and continues on the bucket pipeline; every request of every circuit is answered in both rounds."""
-    res = subprocess.run([sys.executable, "-c", _THREE_SCRIPT.format(root=H.ROOT)], capture_output=True, text=True, timeout=1500)
+    """Three circuits with 1024-chunks on one GPU, the first two with tables of a FIXED clump size (ZKPROVE_COMB_K=19: 54 + 108 GiB -- since
+    round 5 three circuits fit one MI355X at the one-third table shares the budget would give them, so the pressure is made by pinning
+    the size): tables and working sets of ChaCha20 and AES-256 fill the device, AES-128's working sets do not fit and it has no
+    tables of its own to give back.  Its request must not fail for the sake of another circuit's optimisation: the least recently used
+    idle neighbour gives its comb tables back (cabi.cpp release_neighbours, prover.hip relieve_pressure) and continues on the bucket
+    pipeline (tables that went under pressure may be rebuilt at a later call when memory allows: comb_second_chance); every request of
+    every circuit is answered in both rounds."""
+    res = subprocess.run([sys.executable, "-c", _THREE_SCRIPT.format(root=H.ROOT)], capture_output=True, text=True, timeout=1500,
+                         env=dict(os.environ, ZKPROVE_COMB_K="19"))
     assert res.returncode == 0, res.stderr[-3000:]
     out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
     assert all(v == 2048 for v in out["ok"].values()) and len(out["ok"]) == 6, (out, res.stderr[-3000:])
     assert out["comb_before"] == {"0": 1, "2": 1}, out
-    assert out["comb_after"]["0"] == 0, out                     # ChaCha20 was used least recently
-    assert "comb tables" in res.stderr and "released" in res.stderr
+    assert "comb tables" in res.stderr and "released" in res.stderr, (out, res.stderr[-3000:])
 
 def test_two_ciphers_streamed_at_the_same_time():
     """Two host threads, one streamed ProveBatch call each (ChaCha20 and AES-256, 3 000 requests = three device chunks), at the same time,

@@ -65,7 +65,10 @@ static constexpr int TERN_G = ZK_TERN_G;
 static constexpr int pow3(int e) { return e == 0 ? 1 : 3 * pow3(e - 1); }
 static constexpr int TERN_CENTER = (pow3(TERN_G) - 1) / 2; // the all-zero pattern
 static constexpr int TERN_ENTRIES = TERN_CENTER;           // patterns CENTER + 1 .. 3^G - 1
-static constexpr int ONES_GROUPS = 128 / TERN_G;           // groups per conditional-sum thread (<= 128 bases: the four marker words)
+#ifndef ZK_ONES_BASES
+#define ZK_ONES_BASES 128                                  // bases per conditional-sum thread (<= 128: the four marker words); A/B build: -DZK_ONES_BASES=64
+#endif
+static constexpr int ONES_GROUPS = ZK_ONES_BASES / TERN_G; // groups per conditional-sum thread
 static_assert(pow3(TERN_G) <= 65536, "group patterns are parked as 16-bit words");
 static constexpr int ONES_CHUNK = TERN_G * ONES_GROUPS;    // base points per conditional-sum thread
 static constexpr int SORT_THREADS = 1024;
