@@ -454,7 +454,7 @@ print(json.dumps(out))
 """
 
 def test_a_third_circuit_takes_the_idle_neighbours_tables():
-    """Three circuits with 1024-chunks on one GPU, the first two with tables of a FIXED clump size (ZKPROVE_COMB_K=19: 54 + 108 GiB -- since
+    """Three circuits with 1024-chunks on one GPU, the first two with tables of a FIXED clump size (ZKPROVE_COMB_K=18: 28 + 57 GiB, and 57 more for the third -- since
     round 5 three circuits fit one MI355X at the one-third table shares the budget would give them, so the pressure is made by pinning
     the size): tables and working sets of ChaCha20 and AES-256 fill the device, AES-128's working sets do not fit and it has no
     tables of its own to give back.  Its request must not fail for the sake of another circuit's optimisation: the least recently used
@@ -462,7 +462,7 @@ def test_a_third_circuit_takes_the_idle_neighbours_tables():
     pipeline (tables that went under pressure may be rebuilt at a later call when memory allows: comb_second_chance); every request of
     every circuit is answered in both rounds."""
     res = subprocess.run([sys.executable, "-c", _THREE_SCRIPT.format(root=H.ROOT)], capture_output=True, text=True, timeout=1500,
-                         env=dict(os.environ, ZKPROVE_COMB_K="19"))
+                         env=dict(os.environ, ZKPROVE_COMB_K="18"))
     assert res.returncode == 0, res.stderr[-3000:]
     out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
     assert all(v == 2048 for v in out["ok"].values()) and len(out["ok"]) == 6, (out, res.stderr[-3000:])
