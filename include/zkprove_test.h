@@ -27,7 +27,8 @@ int zkp_msm_g1_dense(long n, long batch, const uint8_t *points, const uint8_t *s
  * 1: < 2^8, 2: < 2^32, 3: any); group 1 = G1, 2 = G2; values wider than their class must still give the right sum (bucket hand-over) */
 int zkp_msm_wire_comb(int group, long n, long batch, const uint8_t *points, const uint8_t *scalars, uint8_t *out, int c, int k, const uint8_t *cls);
 /* same sum through the fixed-base bit-plane comb of the quotient MSM of large batches (csrc/msm_comb.hip): clumps of k bases, table
- * of their signed subset sums; mode & 0xff == 1 passes the scalars as products of two matrices (the prover's call shape); mode >> 8 = n1:
+ * of their signed subset sums; mode & 0x0f == 1 passes the scalars as products of two matrices (the prover's call shape); mode & 0x10: the
+ * split walk / fold of mid-size batches (comb_msm_split); mode >> 8 = n1:
  * the first n1 clumps hold k + 1 bases (mixed table, the shape the memory budget of the quotient tables produces).
  * returns 0, or 1 when the bases are degenerate for the comb (point at infinity, coinciding subset sum) and nothing was computed */
 int zkp_msm_comb(long n, long batch, const uint8_t *points, const uint8_t *scalars, uint8_t *out, int k, int mode);

@@ -151,7 +151,10 @@ def test_msm_g1_dense_path_matches_oracle(zk, oracle, n, batch, c):
                                              (700, 3, 16, 1 | (20 << 8)), (400, 17, 19, 1 | (9 << 8)), (260, 2, 20, 1 | (5 << 8)),
                                              # lanes = (plane, proof) pairs: batches that are not a multiple of 64, and clump counts large enough
                                              # for more than 8 ranges per pair (the in-place range levels of the fold)
-                                             (9000, 1, 4, 0), (9000, 5, 5, 1), (7000, 16, 3, 1 | (900 << 8)), (5000, 33, 4, 0)])
+                                             (9000, 1, 4, 0), (9000, 5, 5, 1), (7000, 16, 3, 1 | (900 << 8)), (5000, 33, 4, 0),
+                                             # mode & 0x10: the split walk / fold of mid-size batches (upper planes folded on a second stream beside
+                                             # the lower planes' walk), with and without range levels, mixed table
+                                             (300, 65, 8, 0x11), (5000, 3, 4, 0x10), (2500, 130, 11, 0x11 | (100 << 8)), (900, 70, 19, 0x11)])
 def test_msm_comb_matches_oracle(zk, oracle, n, batch, k, mode):
     """quotient MSM of large batches: fixed-base bit-plane comb (csrc/msm_comb.hip) -- clumps of k bases incl. a short last clump,
     signed subset-sum tables of the halved bases, one accumulator per (plane, proof, clump range), range levels, Horner fold"""

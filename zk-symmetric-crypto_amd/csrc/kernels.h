@@ -79,6 +79,8 @@ void comb_patterns(const CombBases &cb, const Fr *x, const Fr *y, size_t B, uint
 void comb_patterns_rows(const CombShape &cb, const Fr *scalars, size_t B, uint32_t *pat, uint32_t *gen_count, uint32_t *gen_idx, Fr *gen_val, size_t gen_stride, hipStream_t s);
 // out[b] = sum_i scalar_i(b) * P_i
 void comb_msm(const CombBases &cb, const uint32_t *pat, size_t B, CombScratch &sc, G1XYZZ *out, hipStream_t s, hipEvent_t *seg_events = nullptr);
+// the same for a mid-size batch (one call's latency): two walk launches, the upper planes' fold on `side` beside the lower planes' walk; ev2: two events
+void comb_msm_split(const CombBases &cb, const uint32_t *pat, size_t B, CombScratch &sc, G1XYZZ *out, hipStream_t s, hipStream_t side, hipEvent_t *ev2, hipEvent_t *seg_events = nullptr);
 // its two halves: the walk leaves range accumulators in sc, the fold (latency bound) turns them into out[b]; the fold may run on another stream
 void comb_walk(const CombBases &cb, const uint32_t *pat, size_t B, CombScratch &sc, hipStream_t s, hipEvent_t *seg_events = nullptr);
 void comb_fold(const CombBases &cb, size_t B, CombScratch &sc, G1XYZZ *out, hipStream_t s);

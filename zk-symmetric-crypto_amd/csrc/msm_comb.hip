@@ -379,16 +379,19 @@ __global__ __launch_bounds__(64) void k_comb_patterns_rows(const Fr *__restrict_
 #define ZK_COMB_BOUNDS(F) (sizeof(F) == 64 ? 2 : ZK_COMB_WAVES)
 template <class F, bool MAY_INF>
 __global__ __launch_bounds__(64, ZK_COMB_BOUNDS(F)) void k_comb_walk(const Affine<F> *__restrict__ table, const uint32_t *__restrict__ pat, size_t B, size_t nclumps, size_t E,
-                                                                    int T, uint32_t Q, size_t n1, typename Nine<F>::X9 *__restrict__ acc_out) {
+                                                                    int T, uint32_t Q, size_t n1, typename Nine<F>::X9 *__restrict__ acc_out, size_t f0, size_t fcount) {
     using F9 = typename Nine<F>::F9;
     using X9 = typename Nine<F>::X9;
     // lanes = 64 consecutive (plane, proof) pairs of one clump range: f = t * B + b.  With B a multiple of 64 a wavefront holds 64 proofs
     // of one plane; a small batch fills its wavefronts with several planes (B = 16: four) instead of leaving 48 lanes idle -- the
     // pattern words of a clump are [T][B], so the read stays one contiguous segment either way
-    const size_t TB = (size_t)T * B, tiles = (TB + 63) / 64;
+    // (f0, fcount: the pairs of this launch -- all T * B of them, or one half of the planes when a mid-size batch walks in two launches so
+    // that the fold of the upper planes runs beside the walk of the lower ones, comb_msm_split)
+    const size_t TB = (size_t)T * B, tiles = (fcount + 63) / 64;
     const size_t blk = blockIdx.x;
-    const size_t q = blk / tiles, f = (blk % tiles) * 64 + threadIdx.x;
-    if (f >= TB) return;
+    const size_t q = blk / tiles, fl = (blk % tiles) * 64 + threadIdx.x;
+    if (fl >= fcount) return;
+    const size_t f = f0 + fl;
     const size_t c0 = nclumps * q / Q, c1 = nclumps * (q + 1) / Q;
     X9 acc = X9::inf();
     if (c0 < c1) {
@@ -415,10 +418,10 @@ __global__ __launch_bounds__(64, ZK_COMB_BOUNDS(F)) void k_comb_walk(const Affin
 // fold, stage 1: thread (g, b): Horner over the bit planes 8g+7 .. 8g of proof b (each plane = the sum of its Q range accumulators)
 template <class F>
 __global__ __launch_bounds__(64, ZK_COMB_BOUNDS(F)) void k_comb_fold1(const typename Nine<F>::X9 *__restrict__ acc, size_t B, int T, uint32_t Q, uint32_t qstride,
-                                                                     typename Nine<F>::X9 *__restrict__ r1) {
+                                                                     typename Nine<F>::X9 *__restrict__ r1, int g0) {
     using X9 = typename Nine<F>::X9;
     const size_t tiles = (B + 63) / 64;
-    const size_t g = blockIdx.x / tiles, b = (blockIdx.x % tiles) * 64 + threadIdx.x;
+    const size_t g = (size_t)g0 + blockIdx.x / tiles, b = (blockIdx.x % tiles) * 64 + threadIdx.x;
     if (b >= B) return;
     const int t0 = (int)g * FOLD_BITS, t1 = (t0 + FOLD_BITS < T ? t0 + FOLD_BITS : T);
     X9 r = X9::inf();
@@ -434,11 +437,12 @@ __global__ __launch_bounds__(64, ZK_COMB_BOUNDS(F)) void k_comb_fold1(const type
 // accumulators (8j + i) * stride, i < 8, of pair f = (plane, proof) into slot 8j * stride -- its own first slot, so the pass is in
 // place; repeated until at most 8 slots per pair are left.  7 dependent additions per level instead of Q per plane in stage 1.
 template <class F>
-__global__ __launch_bounds__(64, ZK_COMB_BOUNDS(F)) void k_comb_fold_ranges(typename Nine<F>::X9 *__restrict__ acc, size_t TB, uint32_t Q, uint32_t stride) {
+__global__ __launch_bounds__(64, ZK_COMB_BOUNDS(F)) void k_comb_fold_ranges(typename Nine<F>::X9 *__restrict__ acc, size_t TB, uint32_t Q, uint32_t stride, size_t f0, size_t fcount) {
     using X9 = typename Nine<F>::X9;
-    const size_t tiles = (TB + 63) / 64;
-    const size_t j = blockIdx.x / tiles, f = (blockIdx.x % tiles) * 64 + threadIdx.x;
-    if (f >= TB) return;
+    const size_t tiles = (fcount + 63) / 64;
+    const size_t j = blockIdx.x / tiles, fl = (blockIdx.x % tiles) * 64 + threadIdx.x;
+    if (fl >= fcount) return;
+    const size_t f = f0 + fl;
     const uint32_t q0 = (uint32_t)j * 8;
     X9 r = acc[(size_t)q0 * stride * TB + f];
 #pragma unroll 1
@@ -448,18 +452,22 @@ __global__ __launch_bounds__(64, ZK_COMB_BOUNDS(F)) void k_comb_fold_ranges(type
 // stage 2: thread b: Horner over the partial results (8 doublings apart), + the constant of the signed-bit form; out[b * out_stride]
 template <class F>
 __global__ __launch_bounds__(64, ZK_COMB_BOUNDS(F)) void k_comb_fold2(const typename Nine<F>::X9 *__restrict__ r1, size_t B, int groups, const Affine<F> *__restrict__ corr,
-                                                                     XYZZ<F> *__restrict__ out, size_t out_stride) {
+                                                                     XYZZ<F> *__restrict__ out, size_t out_stride, int g_lo, const typename Nine<F>::X9 *__restrict__ init,
+                                                                     typename Nine<F>::X9 *__restrict__ part) {
     using F9 = typename Nine<F>::F9;
     using X9 = typename Nine<F>::X9;
     const size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (b >= B) return;
-    X9 r = X9::inf();
+    // groups `groups - 1` .. g_lo of the chain; init: the value the chain has reached above them (nullptr: it starts here); part: stop
+    // at g_lo and hand the value on (the other half of a split fold, comb_msm_split), else finish: the constant, the XYZZ form
+    X9 r = init ? init[b] : X9::inf();
 #pragma unroll 1
-    for (int g = groups - 1; g >= 0; g--) {
+    for (int g = groups - 1; g >= g_lo; g--) {
 #pragma unroll 1
         for (int i = 0; i < FOLD_BITS; i++) r = X9::dbl_of(r);
         r.add(r1[(size_t)g * B + b]);
     }
+    if (part) { part[b] = r; return; }
     const Affine<F> c = corr[0];
     if (!c.is_inf()) r.madd(F9::from_words(c.x), F9::from_words(c.y));
     out[b * out_stride] = r.to_xyzz();
@@ -508,7 +516,7 @@ size_t comb_acc_bytes(const CombShape &cb, size_t B, size_t x9_bytes) {
     for (size_t b = 1; b <= B; b++) m = std::max(m, (size_t)comb_ranges(b, cb.nclumps, cb.T) * cb.T * b);
     return m * x9_bytes;
 }
-size_t comb_r1_bytes(const CombShape &cb, size_t B, size_t x9_bytes) { return (size_t)fold_groups(cb.T) * B * x9_bytes; }
+size_t comb_r1_bytes(const CombShape &cb, size_t B, size_t x9_bytes) { return (size_t)(fold_groups(cb.T) + 1) * B * x9_bytes; }      // (+ the hand-over row of a split fold)
 void CombScratch::reserve(const CombBases &cb, size_t B, int nslots) {
     for (int i = 0; i < nslots && i < 2; i++) pat[i].ensure(comb_pattern_words(cb, B));
     acc.ensure(comb_acc_bytes(cb, B, sizeof(G1X9)));
@@ -558,8 +566,8 @@ static void comb_walk_impl(const CombBasesT<F> &cb, const uint32_t *pat, size_t 
     const size_t tiles = ((size_t)cb.T * B + 63) / 64;
     X9 *acc = reinterpret_cast<X9 *>(sc.acc.p);
     if (seg_events) ZK_HIP(hipEventRecord(seg_events[0], s));
-    if (cb.has_inf) hipLaunchKernelGGL((k_comb_walk<F, true>), dim3((unsigned)(tiles * Q)), dim3(64), 0, s, cb.table.p, pat, B, cb.nclumps, cb.E, cb.T, Q, cb.n1, acc);
-    else hipLaunchKernelGGL((k_comb_walk<F, false>), dim3((unsigned)(tiles * Q)), dim3(64), 0, s, cb.table.p, pat, B, cb.nclumps, cb.E, cb.T, Q, cb.n1, acc);
+    if (cb.has_inf) hipLaunchKernelGGL((k_comb_walk<F, true>), dim3((unsigned)(tiles * Q)), dim3(64), 0, s, cb.table.p, pat, B, cb.nclumps, cb.E, cb.T, Q, cb.n1, acc, (size_t)0, (size_t)cb.T * B);
+    else hipLaunchKernelGGL((k_comb_walk<F, false>), dim3((unsigned)(tiles * Q)), dim3(64), 0, s, cb.table.p, pat, B, cb.nclumps, cb.E, cb.T, Q, cb.n1, acc, (size_t)0, (size_t)cb.T * B);
     if (seg_events) ZK_HIP(hipEventRecord(seg_events[1], s));
     ZK_HIP(hipGetLastError());
 }
@@ -581,7 +589,7 @@ static void comb_fold_impl(const CombBasesT<F> &cb, size_t B, CombScratch &sc, X
     const size_t TB = (size_t)cb.T * B, tb_tiles = (TB + 63) / 64;
     while (Qr > 8) {
         const uint32_t groups8 = (Qr + 7) / 8;
-        hipLaunchKernelGGL(k_comb_fold_ranges<F>, dim3((unsigned)(tb_tiles * groups8)), dim3(64), 0, s, acc, TB, Qr, qstride);
+        hipLaunchKernelGGL(k_comb_fold_ranges<F>, dim3((unsigned)(tb_tiles * groups8)), dim3(64), 0, s, acc, TB, Qr, qstride, (size_t)0, TB);
         Qr = groups8;
         qstride *= 8;
     }
@@ -590,9 +598,61 @@ static void comb_fold_impl(const CombBasesT<F> &cb, size_t B, CombScratch &sc, X
         ZK_HIP(hipGetLastError());
         return;
     }
-    hipLaunchKernelGGL(k_comb_fold1<F>, dim3((unsigned)(tiles * groups)), dim3(64), 0, s, acc, B, cb.T, Qr, qstride, r1);
-    hipLaunchKernelGGL(k_comb_fold2<F>, dim3((unsigned)tiles), dim3(64), 0, s, r1, B, groups, cb.corr.p, out, out_stride);
+    hipLaunchKernelGGL(k_comb_fold1<F>, dim3((unsigned)(tiles * groups)), dim3(64), 0, s, acc, B, cb.T, Qr, qstride, r1, 0);
+    hipLaunchKernelGGL(k_comb_fold2<F>, dim3((unsigned)tiles), dim3(64), 0, s, r1, B, groups, cb.corr.p, out, out_stride, 0, (const X9 *)nullptr, (X9 *)nullptr);
     ZK_HIP(hipGetLastError());
+}
+// A mid-size batch is one call's latency, and the fold is a chain of 254 dependent doublings per proof (1.5 ms) behind a walk of a few
+// milliseconds.  Walk in two launches -- the upper half of the bit planes first -- and fold the upper half on `side` while the lower half
+// is walked on `s`: range levels, stage 1 and the first half of the Horner chain (groups 31 .. 16) there; the lower planes' range levels
+// and stage 1 on `s`, which then takes the chain over at group 15.  Same additions in the same order per proof: the same point.
+// ev[0], ev[1]: two events of the caller's.  (Quotient shape only: T = 254.)
+template <class F>
+static void comb_msm_split_impl(const CombBasesT<F> &cb, const uint32_t *pat, size_t B, CombScratch &sc, XYZZ<F> *out, hipStream_t s, hipStream_t side, hipEvent_t *ev,
+                                hipEvent_t *seg_events) {
+    using X9 = typename Nine<F>::X9;
+    if (!cb.ok) throw ZkError("comb MSM: table not built");
+    const uint32_t Q = comb_ranges(B, cb.nclumps, cb.T);
+    const int groups = fold_groups(cb.T), g_mid = groups / 2;
+    if (sc.acc.n < (size_t)Q * cb.T * B * sizeof(X9) || sc.r1.n < (size_t)(groups + 1) * B * sizeof(X9)) throw ZkError("comb MSM: scratch too small");
+    X9 *acc = reinterpret_cast<X9 *>(sc.acc.p), *r1 = reinterpret_cast<X9 *>(sc.r1.p), *hand = r1 + (size_t)groups * B;
+    const size_t TB = (size_t)cb.T * B, f_mid = (size_t)g_mid * FOLD_BITS * B, tiles = (B + 63) / 64;
+    auto walk = [&](size_t f0, size_t fc) {
+        const size_t wt = (fc + 63) / 64;
+        if (cb.has_inf) hipLaunchKernelGGL((k_comb_walk<F, true>), dim3((unsigned)(wt * Q)), dim3(64), 0, s, cb.table.p, pat, B, cb.nclumps, cb.E, cb.T, Q, cb.n1, acc, f0, fc);
+        else hipLaunchKernelGGL((k_comb_walk<F, false>), dim3((unsigned)(wt * Q)), dim3(64), 0, s, cb.table.p, pat, B, cb.nclumps, cb.E, cb.T, Q, cb.n1, acc, f0, fc);
+    };
+    // range levels of the pairs [f0, f0 + fc) on stream st; returns (ranges left, their stride)
+    auto ranges = [&](size_t f0, size_t fc, hipStream_t st, uint32_t &Qr, uint32_t &qstride) {
+        Qr = Q; qstride = 1;
+        const size_t ft = (fc + 63) / 64;
+        while (Qr > 8) {
+            const uint32_t groups8 = (Qr + 7) / 8;
+            hipLaunchKernelGGL(k_comb_fold_ranges<F>, dim3((unsigned)(ft * groups8)), dim3(64), 0, st, acc, TB, Qr, qstride, f0, fc);
+            Qr = groups8;
+            qstride *= 8;
+        }
+    };
+    if (seg_events) ZK_HIP(hipEventRecord(seg_events[0], s));
+    walk(f_mid, TB - f_mid);
+    ZK_HIP(hipEventRecord(ev[0], s));
+    walk(0, f_mid);
+    if (seg_events) ZK_HIP(hipEventRecord(seg_events[1], s));
+    uint32_t Qr, qstride;
+    ZK_HIP(hipStreamWaitEvent(side, ev[0], 0));
+    ranges(f_mid, TB - f_mid, side, Qr, qstride);
+    hipLaunchKernelGGL(k_comb_fold1<F>, dim3((unsigned)(tiles * (groups - g_mid))), dim3(64), 0, side, acc, B, cb.T, Qr, qstride, r1, g_mid);
+    hipLaunchKernelGGL(k_comb_fold2<F>, dim3((unsigned)tiles), dim3(64), 0, side, r1, B, groups, cb.corr.p, out, (size_t)1, g_mid, (const X9 *)nullptr, hand);
+    ZK_HIP(hipEventRecord(ev[1], side));
+    ranges(0, f_mid, s, Qr, qstride);
+    hipLaunchKernelGGL(k_comb_fold1<F>, dim3((unsigned)(tiles * g_mid)), dim3(64), 0, s, acc, B, cb.T, Qr, qstride, r1, 0);
+    ZK_HIP(hipStreamWaitEvent(s, ev[1], 0));
+    hipLaunchKernelGGL(k_comb_fold2<F>, dim3((unsigned)tiles), dim3(64), 0, s, r1, B, g_mid, cb.corr.p, out, (size_t)1, 0, (const X9 *)hand, (X9 *)nullptr);
+    ZK_HIP(hipGetLastError());
+}
+void comb_msm_split(const CombBases &cb, const uint32_t *pat, size_t B, CombScratch &sc, G1XYZZ *out, hipStream_t s, hipStream_t side, hipEvent_t *ev2, hipEvent_t *seg_events) {
+    if (cb.T <= 32) throw ZkError("comb MSM: the split fold is for the quotient shape");
+    comb_msm_split_impl<Fp>(cb, pat, B, sc, out, s, side, ev2, seg_events);
 }
 template <class F>
 static void comb_msm_impl(const CombBasesT<F> &cb, const uint32_t *pat, size_t B, CombScratch &sc, XYZZ<F> *out, size_t out_stride, hipStream_t s, hipEvent_t *seg_events) {

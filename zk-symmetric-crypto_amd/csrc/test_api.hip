@@ -171,7 +171,8 @@ extern "C" int zkp_msm_comb(long n_, long batch, const uint8_t *points, const ui
     CombBases cb;
     // mode bits 8.. : n1 = number of leading clumps that hold k + 1 bases (mixed tables, CombShape::n1)
     const size_t n1 = (size_t)(mode >> 8);
-    mode &= 0xff;
+    const bool split_fold = (mode & 0x10) != 0;          // comb_msm_split: two walk launches, the upper planes' fold on a second stream
+    mode &= 0x0f;
     if (n1 * (size_t)(k + 1) > n) return -1;
     if (!comb_build(cb, dp.p, n, k, 0, n1)) return 1;
     std::vector<Fr> hs;
@@ -188,7 +189,17 @@ extern "C" int zkp_msm_comb(long n_, long batch, const uint8_t *points, const ui
     DevBuf<G1XYZZ> res(B);
     DevBuf<G1Affine> aff(B);
     comb_patterns(cb, ds.p, mode == 1 ? ones.p : nullptr, B, sc.pat[0].p, 0);
-    comb_msm(cb, sc.pat[0].p, B, sc, res.p, 0);
+    if (split_fold) {
+        hipStream_t side;
+        hipEvent_t ev[2];
+        ZK_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        ZK_HIP(hipEventCreate(&ev[0])); ZK_HIP(hipEventCreate(&ev[1]));
+        ZK_HIP(hipDeviceSynchronize());                  // (the patterns above ran on the null stream; `side` does not wait for it by itself)
+        comb_msm_split(cb, sc.pat[0].p, B, sc, res.p, 0, side, ev);
+        ZK_HIP(hipDeviceSynchronize());
+        (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]); (void)hipStreamDestroy(side);
+    } else
+        comb_msm(cb, sc.pat[0].p, B, sc, res.p, 0);
     g1_to_affine_canonical(res.p, aff.p, B, 0);
     ZK_HIP(hipMemcpy(out, aff.p, B * 64, hipMemcpyDeviceToHost));
     return 0;
