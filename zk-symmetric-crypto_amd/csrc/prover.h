@@ -126,6 +126,7 @@ class Algorithm {
     bool comb_drop_tables();
     void resident_reserve_buffers(size_t B);
     size_t own_c_rows(size_t B) const;
+    size_t side_max_b() const;                              // batches up to this size run their MSM chains side by side (prover.hip)
     bool comb_release();                                    // out of memory: give the comb tables back, continue on the bucket pipeline                            // lazy table build + scratch (resident_reserve)
     // Memory pressure across algorithms: the hook (set by cabi.cpp, which owns the registry) asks every OTHER algorithm on this device
     // that is idle right now to give its comb tables back (release_comb_if_idle); true when something was freed

@@ -10,7 +10,11 @@ namespace zk {
 
 static constexpr int C_WIRE = 13;   // window bits for the wire-scalar MSMs (few wide scalars)
 static constexpr int C_H = 16;      // window bits for the quotient MSM (all scalars full width)
-static constexpr size_t SIDE_G2_MAX_B = 64;   // up to this batch size the G2 MSM runs beside the G1 MSMs (kernels are latency-bound)
+// Up to this batch size the MSM chains run side by side on four streams (their kernels are latency-bound): Algorithm::side_max_b() -- 64 proofs,
+// and 128 for the programs with a commitment (AES): their six wire MSMs end in ~15 fold chains of 1.4-3.8 ms, which the one-stream path of
+// larger batches runs one after the other (65 proofs: 47.7 ms against 31.3 for 64, profiles/r06a_*)
+static constexpr size_t SIDE_G2_MAX_B = 64;
+static constexpr size_t SIDE_G2_MAX_B_COMMIT = 128;
 // Once the comb tables exist (a batch of >= comb_min_batch() proofs has been served) every batch from this size takes them: the walk's
 // lanes are (plane, proof) pairs, so 16 proofs fill wavefronts with four planes each.  Below, the latency-tuned bucket pipeline of the
 // one-proof calls (virtual instances, side streams) stays faster.
@@ -923,7 +927,8 @@ void Algorithm::resident_reserve(size_t B) {
 // Instances the c rows of the second / third working set are sized for: with comb tables only the products buffer of the batches too
 // small for the comb (the solver writes its output column into the first set's rows, SolverBuffers::c_shared); without tables the
 // bucket pipeline keeps every batch's products there.
-size_t Algorithm::own_c_rows(size_t B) const { return pk.Zcomb.ok ? std::min(B, SIDE_G2_MAX_B) : B; }
+size_t Algorithm::side_max_b() const { return has_commit ? SIDE_G2_MAX_B_COMMIT : SIDE_G2_MAX_B; }
+size_t Algorithm::own_c_rows(size_t B) const { return pk.Zcomb.ok ? std::min(B, side_max_b()) : B; }
 void Algorithm::resident_reserve_buffers(size_t B) {
     Resident &R = *res;
     R.B = B;
@@ -947,13 +952,13 @@ void Algorithm::resident_reserve_buffers(size_t B) {
         R.ms.reserve(B, max_entries, max_nb, max_part);
         R.ms.reserve_compact(B, std::max({pk.A.n, pk.B1.n, pk.K.n, pk.B2.n, has_commit ? pk.ped.n : (size_t)1}));
         static const bool g2_side_on = [] { const char *e = ZK_AB_ENV("ZKPROVE_G2_SIDE"); return e && e[0] == '1'; }();
-        if (g2_side_on && B > SIDE_G2_MAX_B && split_world == 1) {          // opt-in: the G2 MSM of large batches beside the G1 MSMs (enqueue_main)
+        if (g2_side_on && B > side_max_b() && split_world == 1) {          // opt-in: the G2 MSM of large batches beside the G1 MSMs (enqueue_main)
             R.ms_b2.reserve(B, pk.B2.n * (size_t)pk.B2.W, (size_t)1 << (pk.B2.c - 1), msm_part_stride(pk.B2.n, pk.B2.c));
             R.ms_b2.reserve_compact(B, pk.B2.n);
             R.ms_b2.reserve_sums(B, 1, (size_t)1 << (pk.B2.c - 1));
         }
         {
-            const size_t Bs = std::min(B, SIDE_G2_MAX_B);
+            const size_t Bs = std::min(B, side_max_b());
             const size_t n_side = std::max(pk.B2.n, has_commit ? pk.ped_sigma.n : (size_t)1);
             const int c_side = std::max(pk.B2.c, has_commit ? pk.ped_sigma.c : 1);
             R.ms_g2.reserve(Bs, n_side * (size_t)std::max(pk.B2.W, has_commit ? pk.ped_sigma.W : 1), (size_t)1 << (c_side - 1),
@@ -985,7 +990,7 @@ void Algorithm::resident_reserve_buffers(size_t B) {
     if (R.ms2.entries.n) wire_comb_reserve(R.ms2, false, R.cap);
     if (wire_comb_on) {
         // the side scratches of batches <= 64 (one MSM chain per stream): room for the wire combs of the base sets that run on them
-        const size_t Bs = std::min(R.cap, SIDE_G2_MAX_B);
+        const size_t Bs = std::min(R.cap, side_max_b());
         auto side_room = [&](MsmScratch &sc, std::initializer_list<const MsmBasesG1 *> g1, const MsmBasesG2 *g2) {
             size_t pw = 0, ab = 0, rb = 0, p = 0, a = 0, r = 0;
             for (const MsmBasesG1 *mb : g1) { msm_wire_comb_needs(*mb, Bs, p, a, r); pw = std::max(pw, p); ab = std::max(ab, a); rb = std::max(rb, r); }
@@ -998,11 +1003,11 @@ void Algorithm::resident_reserve_buffers(size_t B) {
     }
     // bucket pipeline of the quotient MSM: for every batch when there are no comb tables, else only for the batches too small for the comb
     const size_t nbz = (size_t)1 << (pk.Z.c - 1), ez = pk.Z.n * (size_t)pk.Z.W;
-    const size_t Bd = pk.Zcomb.ok ? std::min(B, SIDE_G2_MAX_B) : B;
+    const size_t Bd = pk.Zcomb.ok ? std::min(B, side_max_b()) : B;
     if (R.dense_cap < Bd) {
         R.ms.reserve(Bd, ez, nbz, msm_part_stride(pk.Z.n, pk.Z.c));
         R.ms.reserve_dense(Bd, ez, nbz);
-        if (Bd > SIDE_G2_MAX_B) R.ms.reserve_dense_second(Bd, ez, nbz);      // ahead mode, enqueue_ntt_sort
+        if (Bd > side_max_b()) R.ms.reserve_dense_second(Bd, ez, nbz);      // ahead mode, enqueue_ntt_sort
         R.ms.reserve_tree(Bd, ez, nbz);
         R.ms.reserve_sums(Bd, nbz, 1);
         R.dense_cap = Bd;               // only now: an allocation above may throw, and the retry (resident_reserve) must come back here
@@ -1060,7 +1065,7 @@ void Algorithm::enqueue_solve(SolveSet &S, MsmScratch &commit_scratch, hipStream
         solver_run_levels(prog, S.sb, 0, commit_level, st);
         ZK_HIP(hipEventRecord(S.t1, st));
         // BSB22 commitment: C = sum v_i * Basis_i ; challenge = H2F(C.Marshal(), "bsb22-commitment") ; PoK = sum v_i * BasisExpSigma_i
-        if (B <= SIDE_G2_MAX_B) {
+        if (B <= side_max_b()) {
             // small batch: the two Pedersen MSMs are latency-bound chains -- the proof-of-knowledge one runs on the side stream
             // (scratch of the side G2 MSM, idle until the MSM stage) beside the commitment
             ZK_HIP(hipEventRecord(R.ev[14], st));
@@ -1103,7 +1108,7 @@ bool Algorithm::ahead_eligible() const {
     static const bool on = [] { const char *e = ZK_AB_ENV("ZKPROVE_SORT_AHEAD"); return !(e && e[0] == '0'); }();
     const Resident &R = *res;
     const size_t max_entries = pk.Z.n * (size_t)pk.Z.W, nb = (size_t)1 << (pk.Z.c - 1);
-    if (!(on && R.B > SIDE_G2_MAX_B && split_world == 1)) return false;
+    if (!(on && R.B > side_max_b() && split_world == 1)) return false;
     if (comb_active()) return true;                      // the comb path prepares its bit-plane patterns ahead instead of a sorted list
     // the complete predicate of msm_dense_presort: a batch that does not meet it takes the in-line sort of enqueue_main
     return pk.Z.dense && pk.Z.n != 0 && msm_dense_presort_applicable(pk.Z, R.B, R.ms) && R.ms.entries_zb.n >= R.B * max_entries + 1 &&
@@ -1222,7 +1227,7 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm,
     }
     // A small batch is a set of latency-bound kernel chains: independent chains go to the otherwise idle streams (the transforms of b
     // and the K MSM to the solve stream, the G2 MSM to the copy stream) -- never to new ones, see resident_reserve
-    const bool side = B <= SIDE_G2_MAX_B;      // (with tables a batch of >= 16 proofs takes the comb for its quotient MSM and the wire combs inside these chains)
+    const bool side = B <= side_max_b();      // (with tables a batch of >= 16 proofs takes the comb for its quotient MSM and the wire combs inside these chains)
     hipStream_t sk = R.stream2;
     if (side) {
         // the G2 chain first: MSM, blinding s*delta2, Fp2 inversion -- the longest of the tail's chains (5 ms for one AES proof), and on
