@@ -12,7 +12,7 @@ static constexpr int C_WIRE = 13;   // window bits for the wire-scalar MSMs (few
 static constexpr int C_H = 16;      // window bits for the quotient MSM (all scalars full width)
 // Up to this batch size the MSM chains run side by side on four streams (their kernels are latency-bound): Algorithm::side_max_b() -- 64 proofs,
 // and 128 for the programs with a commitment (AES): their six wire MSMs end in ~15 fold chains of 1.4-3.8 ms, which the one-stream path of
-// larger batches runs one after the other (65 proofs: 47.7 ms against 31.3 for 64, profiles/r06a_*)
+// larger batches runs one after the other (65 proofs: 47.7 ms against 31.3 for 64, profiles/r06a_*); only while the wire combs exist
 static constexpr size_t SIDE_G2_MAX_B = 64;
 static constexpr size_t SIDE_G2_MAX_B_COMMIT = 128;
 // Once the comb tables exist (a batch of >= comb_min_batch() proofs has been served) every batch from this size takes them: the walk's
@@ -156,6 +156,7 @@ struct Algorithm::Resident {
     DevBuf<G1XYZZ> f_t, f_u, f_v;
     CombScratch comb;               // bit-plane patterns (two copies) and range accumulators of the comb quotient MSM
     size_t comb_cap = 0, dense_cap = 0;      // batch sizes the comb scratch / the dense bucket-sort buffers are reserved for
+    size_t side_cap = 0;                     // ... and the side scratches ms_a / ms_k / ms_g2 (at most side_max_b() instances)
     bool used_comb = false;         // the last enqueue_main took the comb path (debug_fetch then forms the products f itself)
     int last_set = 0;               // the set that holds the most recent batch
     hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr, copy_stream = nullptr;
@@ -919,7 +920,7 @@ void Algorithm::resident_reserve(size_t B) {
             // the failure may survive it -- neither for the retry nor, when the retries run out, for the next (smaller) call, which
             // would otherwise skip its ensure() calls and launch kernels on a null pointer.  Every reservation is "grow if smaller",
             // so starting from zero costs nothing for the buffers that are still in place.
-            R.cap = 0; R.dense_cap = 0; R.comb_cap = 0; R.B = 0;
+            R.cap = 0; R.dense_cap = 0; R.comb_cap = 0; R.side_cap = 0; R.B = 0;
             if (attempt >= 5 || !relieve_pressure(false)) throw;      // memory-pressure valve, see comb_release
         }
     }
@@ -927,7 +928,7 @@ void Algorithm::resident_reserve(size_t B) {
 // Instances the c rows of the second / third working set are sized for: with comb tables only the products buffer of the batches too
 // small for the comb (the solver writes its output column into the first set's rows, SolverBuffers::c_shared); without tables the
 // bucket pipeline keeps every batch's products there.
-size_t Algorithm::side_max_b() const { return has_commit ? SIDE_G2_MAX_B_COMMIT : SIDE_G2_MAX_B; }
+size_t Algorithm::side_max_b() const { return has_commit && wire_comb_on ? SIDE_G2_MAX_B_COMMIT : SIDE_G2_MAX_B; }
 size_t Algorithm::own_c_rows(size_t B) const { return pk.Zcomb.ok ? std::min(B, side_max_b()) : B; }
 void Algorithm::resident_reserve_buffers(size_t B) {
     Resident &R = *res;
@@ -958,33 +959,37 @@ void Algorithm::resident_reserve_buffers(size_t B) {
             R.ms_b2.reserve_sums(B, 1, (size_t)1 << (pk.B2.c - 1));
         }
         {
-            const size_t Bs = std::min(B, side_max_b());
-            const size_t n_side = std::max(pk.B2.n, has_commit ? pk.ped_sigma.n : (size_t)1);
-            const int c_side = std::max(pk.B2.c, has_commit ? pk.ped_sigma.c : 1);
-            R.ms_g2.reserve(Bs, n_side * (size_t)std::max(pk.B2.W, has_commit ? pk.ped_sigma.W : 1), (size_t)1 << (c_side - 1),
-                            std::max(msm_part_stride(pk.B2.n, pk.B2.c), has_commit ? msm_part_stride(pk.ped_sigma.n, pk.ped_sigma.c) : (size_t)1));
-            {
-                const size_t na = std::max(pk.A.n, pk.B1.n);
-                R.ms_a.reserve(Bs, na * (size_t)pk.A.W, (size_t)1 << (pk.A.c - 1), std::max(msm_part_stride(pk.A.n, pk.A.c), msm_part_stride(pk.B1.n, pk.B1.c)));
-                R.ms_a.reserve_compact(Bs, na);
-                R.ms_a.reserve_sums(Bs, (size_t)1 << (pk.A.c - 1), 1);
-            }
-            R.ms_k.reserve(Bs, pk.K.n * (size_t)pk.K.W, (size_t)1 << (pk.K.c - 1), msm_part_stride(pk.K.n, pk.K.c));
-            R.ms_k.reserve_compact(Bs, pk.K.n);
-            R.ms_k.reserve_sums(Bs, (size_t)1 << (pk.K.c - 1), 1);
-            R.ms_g2.reserve_compact(Bs, n_side);
-            R.ms_g2.reserve_sums(Bs, has_commit ? (size_t)1 << (pk.ped_sigma.c - 1) : 1, (size_t)1 << (pk.B2.c - 1));
-        }
-        {
             size_t nb1 = (size_t)1 << (std::max({pk.A.c, pk.B1.c, pk.K.c, has_commit ? pk.ped.c : 1}) - 1);
             R.ms.reserve_sums(B, nb1, (size_t)1 << (pk.B2.c - 1));
         }
         R.m_ar.alloc(B); R.m_bs1.alloc(B); R.m_k.alloc(B); R.m_z.alloc(B); R.m_bs2.alloc(B);
         R.ar_aff.alloc(B); R.bs1_aff.alloc(B); R.f_t.alloc(B); R.f_u.alloc(B); R.f_v.alloc(B);
     }
+    // the side scratches of the batches whose MSM chains run side by side (side_max_b: 64 proofs; 128 once an AES program has its wire
+    // combs): before the table decision -- the budget looks at what is left -- and again when the wire combs have raised the limit
+    auto reserve_side = [&]() {
+        const size_t Bs = std::min(R.cap, side_max_b());
+        if (R.side_cap >= Bs) return;
+        const size_t n_side = std::max(pk.B2.n, has_commit ? pk.ped_sigma.n : (size_t)1);
+        const int c_side = std::max(pk.B2.c, has_commit ? pk.ped_sigma.c : 1);
+        R.ms_g2.reserve(Bs, n_side * (size_t)std::max(pk.B2.W, has_commit ? pk.ped_sigma.W : 1), (size_t)1 << (c_side - 1),
+                        std::max(msm_part_stride(pk.B2.n, pk.B2.c), has_commit ? msm_part_stride(pk.ped_sigma.n, pk.ped_sigma.c) : (size_t)1));
+        const size_t na = std::max(pk.A.n, pk.B1.n);
+        R.ms_a.reserve(Bs, na * (size_t)pk.A.W, (size_t)1 << (pk.A.c - 1), std::max(msm_part_stride(pk.A.n, pk.A.c), msm_part_stride(pk.B1.n, pk.B1.c)));
+        R.ms_a.reserve_compact(Bs, na);
+        R.ms_a.reserve_sums(Bs, (size_t)1 << (pk.A.c - 1), 1);
+        R.ms_k.reserve(Bs, pk.K.n * (size_t)pk.K.W, (size_t)1 << (pk.K.c - 1), msm_part_stride(pk.K.n, pk.K.c));
+        R.ms_k.reserve_compact(Bs, pk.K.n);
+        R.ms_k.reserve_sums(Bs, (size_t)1 << (pk.K.c - 1), 1);
+        R.ms_g2.reserve_compact(Bs, n_side);
+        R.ms_g2.reserve_sums(Bs, has_commit ? (size_t)1 << (pk.ped_sigma.c - 1) : 1, (size_t)1 << (pk.B2.c - 1));
+        R.side_cap = Bs;
+    };
+    reserve_side();
     // the comb tables of the quotient MSM are decided once the working buffers above exist (the budget looks at what is left)
     comb_prepare(B);
     wire_comb_prepare(B);
+    reserve_side();
     wire_comb_reserve(R.ms, true, R.cap);
     if (R.ms_b2.entries.n) wire_comb_reserve(R.ms_b2, true, R.cap);
     if (R.ms2.entries.n) wire_comb_reserve(R.ms2, false, R.cap);
@@ -1439,6 +1444,8 @@ bool Algorithm::comb_drop_tables() {
     for (MsmBasesG1 *mb : {&pk.A, &pk.B1, &pk.K, &pk.ped, &pk.ped_sigma}) { mb->wcomb.clear(); mb->wide_mask.release(); }
     pk.B2.wcomb.clear(); pk.B2.wide_mask.release();
     wire_comb_on = false;
+    R.ms_a = MsmScratch(); R.ms_k = MsmScratch(); R.ms_g2 = MsmScratch();      // (sized for side_max_b() instances: 64 again without the wire combs)
+    R.side_cap = 0;
     comb_dropped = true;
     fprintf(stderr, "zkprove: out of device memory: comb tables (%zu MiB) released, this algorithm continues on the bucket pipeline\n", mib);
     return true;
