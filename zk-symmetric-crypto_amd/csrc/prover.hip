@@ -1339,7 +1339,9 @@ void Algorithm::enqueue_main(SolveSet &S, hipStream_t st, hipEvent_t before_msm,
     if (presorted) ZK_HIP(hipStreamWaitEvent(st, R.ev[18], 0));
     // (65 .. 256 proofs with tables: the copy stream, which carried transforms and patterns, is idle now and takes the upper planes' fold
     // beside the lower planes' walk -- ChaCha20, 128 proofs: 16.4 -> ... ms per call)
-    if (comb && ntt_beside) comb_msm_split(pk.Zcomb, R.comb.pat[0].p, B, R.comb, R.m_z.p, st, R.copy_stream, &R.ev[21], &R.ev[8]);
+    // (16 .. 64 / 128 proofs, chains side by side: the solve stream -- K chain and the transforms of b, long done when the walk starts -- takes it)
+    if (comb && side) comb_msm_split(pk.Zcomb, R.comb.pat[0].p, B, R.comb, R.m_z.p, st, sk, &R.ev[21], &R.ev[8]);
+    else if (comb && ntt_beside) comb_msm_split(pk.Zcomb, R.comb.pat[0].p, B, R.comb, R.m_z.p, st, R.copy_stream, &R.ev[21], &R.ev[8]);
     else if (comb) comb_msm(pk.Zcomb, R.comb.pat[0].p, B, R.comb, R.m_z.p, st, &R.ev[8]);
     else msm_batch(pk.Z, S.sb.c.p + z_offset, B, R.ms, R.m_z.p, st, &R.ev[8]);
     ZK_HIP(hipGetLastError());
