@@ -386,6 +386,25 @@ def run_rank(args):
             zk.prove_raw(one)
             lat.append(time.perf_counter() - t0)
         lat.sort()
+        # one ProveBatch call by array size (median of 5 after a warm-up call): what a caller with 1 .. 1024 requests in hand gets -- the
+        # reference's own JS benchmark issues 8 proofs per call (js/src/tests/benchmark.ts:14-34); the comb tables exist by now
+        sweep = {}
+        try:
+            for nb in (1, 8, 64, 256, 1024):
+                if nb > nreq:
+                    break
+                bb = json.dumps(reqs[:nb]).encode()
+                zk.prove_batch_raw(bb)
+                ts = []
+                for _ in range(5):
+                    t0 = time.perf_counter()
+                    ob = zk.prove_batch_raw(bb)
+                    ts.append(time.perf_counter() - t0)
+                ts.sort()
+                okb = sum(1 for x in json.loads(ob) if isinstance(x, dict) and "proof" in x)
+                sweep[str(nb)] = {"ms_per_call": ts[2] * 1e3, "proofs_per_s": nb / ts[2], "ok": okb}
+        except Exception as e:
+            sweep["error"] = repr(e)
         # the verifier side of the same ABI: VerifyBatch over the first 1024 responses (one pairing-product check on the GPU)
         ver = None
         try:
@@ -403,7 +422,7 @@ def run_rank(args):
         except Exception as e:
             ver = {"error": repr(e)}
         return {"proofs_per_s": nreq / best, "requests_per_call": nreq, "ok": ok, "seconds_per_call": best,
-                "single_prove_ms": lat[len(lat) // 2] * 1e3, "single_prove_ms_min": lat[0] * 1e3, "verify_batch": ver,
+                "single_prove_ms": lat[len(lat) // 2] * 1e3, "single_prove_ms_min": lat[0] * 1e3, "batch_sweep": sweep, "verify_batch": ver,
                 "what": "ProveBatch(JSON array) -> JSON array and Prove(JSON) -> JSON through the C ABI; host decoding, ciphers, witness packing, PCIe, serialisation included"}
 
     manifest = profile_manifest()
