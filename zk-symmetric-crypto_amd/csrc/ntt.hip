@@ -366,6 +366,13 @@ __global__ __launch_bounds__(256) void k_ntt_dit(Fr *__restrict__ data, size_t B
 #ifndef ZK_NTT_TILE
 #define ZK_NTT_TILE 2048
 #endif
+// A/B build (-DZK_NTT_PRIO=n): the transforms are the critical chain of the window between two quotient walks (transforms -> patterns -> walk)
+// while the wire MSMs beside them are not; n > 0 raises the issue priority of the pass kernels' wavefronts (s_setprio n)
+#ifdef ZK_NTT_PRIO
+#define ZK_NTT_SETPRIO() __builtin_amdgcn_s_setprio(ZK_NTT_PRIO)
+#else
+#define ZK_NTT_SETPRIO() ((void)0)
+#endif
 #ifndef ZK_NTT_TPW
 #define ZK_NTT_TPW 4                                // tiles per workgroup of the pipelined kernels
 #endif
@@ -539,6 +546,7 @@ __global__ __launch_bounds__(ZK_NTT_TILE / 8) void k_ntt_dif_lds_pipe(Fr *__rest
     using El = typename P::E;
     constexpr int K = T::K, E = T::E, TI = T::TI, R1 = 1 << K1, R2 = 1 << K2, NT = T::THREADS, STR = E / R1;
     static_assert(STR == NT / TI, "one group-A element set per thread");
+    ZK_NTT_SETPRIO();
     extern __shared__ uint4 lds_raw[];
     El *lds = (El *)lds_raw;                       // [E][TI]
     const int tid = threadIdx.x;
@@ -616,6 +624,7 @@ __global__ __launch_bounds__(ZK_NTT_TILE / 8) void k_ntt_dit_lds_pipe(Fr *__rest
     using El = typename P::E;
     constexpr int K = T::K, E = T::E, TI = T::TI, R1 = 1 << K1, R2 = 1 << K2, NT = T::THREADS;
     static_assert(E / R1 == NT / TI, "one group-A element set per thread");
+    ZK_NTT_SETPRIO();
     extern __shared__ uint4 lds_raw[];
     El *lds = (El *)lds_raw;
     const int tid = threadIdx.x;
