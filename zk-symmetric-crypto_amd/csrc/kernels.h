@@ -13,6 +13,7 @@ struct NttDomain {
     size_t n = 0;
     DevBuf<Fr> consts, tw_fwd, tw_inv, coset_pre, coset_post;
     bool f9 = false;                                           // butterflies on the 9 x 29-bit field (ntt.hip, Ntt9): opt-in experiment, ZKPROVE_NTT_F9=1
+    bool hi_prio = false;                                      // the tile pass kernels raise their wavefronts' issue priority (ntt.hip, ZK_NTT_PRIO): set for the programs whose transforms are the window's critical chain
     DevBuf<Fr> tw_fwd9, tw_inv9, coset_pre9, coset_post9;      // the same multiplier tables in the 2^261-Montgomery form
     const Fr *table9(const Fr *t) const;
     void init(int logn, hipStream_t s);
@@ -46,6 +47,7 @@ struct CombShape {
     DevBuf<uint32_t> rows;                 // wire comb: row of base j in the [row][B] scalar matrix
     DevBuf<uint32_t> base_index;           // wire comb: index of base j in the owning MsmBases (for the bucket-pipeline hand-over)
     bool ok = false;
+    bool hi_prio = false;                  // the pattern kernel raises its wavefronts' issue priority (as the transforms in front of it: NttDomain::hi_prio)
     bool has_inf = false;                  // the table holds entries at infinity (a base at infinity, equal / opposite bases in a clump): the walk skips them
 };
 template <class F>

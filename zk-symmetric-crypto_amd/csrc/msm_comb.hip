@@ -32,6 +32,9 @@
 
 namespace zk {
 
+#ifndef ZK_PAT_PRIO
+#define ZK_PAT_PRIO 3                           // issue priority of the pattern kernel's wavefronts (A/B build: -DZK_PAT_PRIO=0)
+#endif
 static constexpr int COMB_T = 254;              // bit planes of the quotient MSM: scalars are canonical, < r < 2^254
 static constexpr int COMB_KMAX = 24;
 static constexpr int FOLD_BITS = 8;             // bit planes per thread of the first fold stage
@@ -279,7 +282,10 @@ __device__ __forceinline__ void comb_transpose32(uint32_t (&a)[32]) {
 // start at row base0 of the matrices and whose first clump is clump0 of the table.
 template <int K>
 __global__ __launch_bounds__(64) void k_comb_patterns_reg(const Fr *__restrict__ x, const Fr *__restrict__ y, size_t B, size_t n, size_t base0, size_t clump0,
-                                                          uint32_t *__restrict__ pat) {
+                                                          uint32_t *__restrict__ pat, int prio) {
+#if ZK_PAT_PRIO > 0
+    if (prio) __builtin_amdgcn_s_setprio(ZK_PAT_PRIO);      // part of the window's critical chain transforms -> patterns -> walk (ntt.hip, ZK_NTT_PRIO)
+#endif
     const size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
     const size_t c = blockIdx.y;
     const int kc = (int)zmin((size_t)K, n - c * K);
@@ -532,12 +538,12 @@ void comb_patterns(const CombBases &cb, const Fr *x, const Fr *y, size_t B, uint
         const dim3 grid(ceil_div(B, 64), (unsigned)nc);
         if (y && reg_form && kk >= 16 && kk <= 21) {
             switch (kk) {
-                case 16: hipLaunchKernelGGL(k_comb_patterns_reg<16>, grid, dim3(64), 0, s, x, y, B, ns, base0, clump0, pat); break;
-                case 17: hipLaunchKernelGGL(k_comb_patterns_reg<17>, grid, dim3(64), 0, s, x, y, B, ns, base0, clump0, pat); break;
-                case 18: hipLaunchKernelGGL(k_comb_patterns_reg<18>, grid, dim3(64), 0, s, x, y, B, ns, base0, clump0, pat); break;
-                case 19: hipLaunchKernelGGL(k_comb_patterns_reg<19>, grid, dim3(64), 0, s, x, y, B, ns, base0, clump0, pat); break;
-                case 20: hipLaunchKernelGGL(k_comb_patterns_reg<20>, grid, dim3(64), 0, s, x, y, B, ns, base0, clump0, pat); break;
-                default: hipLaunchKernelGGL(k_comb_patterns_reg<21>, grid, dim3(64), 0, s, x, y, B, ns, base0, clump0, pat); break;
+                case 16: hipLaunchKernelGGL(k_comb_patterns_reg<16>, grid, dim3(64), 0, s, x, y, B, ns, base0, clump0, pat, cb.hi_prio ? 1 : 0); break;
+                case 17: hipLaunchKernelGGL(k_comb_patterns_reg<17>, grid, dim3(64), 0, s, x, y, B, ns, base0, clump0, pat, cb.hi_prio ? 1 : 0); break;
+                case 18: hipLaunchKernelGGL(k_comb_patterns_reg<18>, grid, dim3(64), 0, s, x, y, B, ns, base0, clump0, pat, cb.hi_prio ? 1 : 0); break;
+                case 19: hipLaunchKernelGGL(k_comb_patterns_reg<19>, grid, dim3(64), 0, s, x, y, B, ns, base0, clump0, pat, cb.hi_prio ? 1 : 0); break;
+                case 20: hipLaunchKernelGGL(k_comb_patterns_reg<20>, grid, dim3(64), 0, s, x, y, B, ns, base0, clump0, pat, cb.hi_prio ? 1 : 0); break;
+                default: hipLaunchKernelGGL(k_comb_patterns_reg<21>, grid, dim3(64), 0, s, x, y, B, ns, base0, clump0, pat, cb.hi_prio ? 1 : 0); break;
             }
         } else
             hipLaunchKernelGGL(k_comb_patterns, grid, dim3(64), (size_t)kk * 8 * 64 * 4, s, x, y, B, ns, kk, base0, clump0, pat);

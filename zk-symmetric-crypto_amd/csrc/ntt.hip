@@ -366,13 +366,21 @@ __global__ __launch_bounds__(256) void k_ntt_dit(Fr *__restrict__ data, size_t B
 #ifndef ZK_NTT_TILE
 #define ZK_NTT_TILE 2048
 #endif
-// A/B build (-DZK_NTT_PRIO=n): the transforms are the critical chain of the window between two quotient walks (transforms -> patterns -> walk)
-// while the wire MSMs beside them are not; n > 0 raises the issue priority of the pass kernels' wavefronts (s_setprio n)
-#ifdef ZK_NTT_PRIO
-#define ZK_NTT_SETPRIO() __builtin_amdgcn_s_setprio(ZK_NTT_PRIO)
+// The transforms are the critical chain of the window between two quotient walks (transforms -> patterns -> walk) while the wire MSMs, the
+// solver and the tail beside them are not: the pass kernels raise the issue priority of their wavefronts (s_setprio 3), so that they win the
+// arbitration against the other streams' wavefronts on their SIMD.  Same box, twice each (profiles/r06h_*): ChaCha20 11 420 / 11 399 -> 11 527 /
+// 11 504 proofs/s (the window 32.3 -> 31.3 ms), AES-256 unchanged.  -DZK_NTT_PRIO=0: A/B build without it.
+#ifndef ZK_NTT_PRIO
+#define ZK_NTT_PRIO 3
+#endif
+// (bit 1 of the kernels' `last` argument: the domain wants it -- NttDomain::hi_prio, set for the programs whose copy stream carries the
+// critical chain, i.e. the short ones; for the AES programs the main stream's wire MSMs are the longer chain and the raise costs 0.2 %)
+#if ZK_NTT_PRIO > 0
+#define ZK_NTT_SETPRIO() do { if (last & 2) __builtin_amdgcn_s_setprio(ZK_NTT_PRIO); } while (0)
 #else
 #define ZK_NTT_SETPRIO() ((void)0)
 #endif
+static thread_local int t_ntt_prio_bit = 0;      // set by NttDomain::dif / dit around their launches
 #ifndef ZK_NTT_TPW
 #define ZK_NTT_TPW 4                                // tiles per workgroup of the pipelined kernels
 #endif
@@ -395,6 +403,7 @@ __global__ __launch_bounds__(ZK_NTT_TILE / 8) void k_ntt_dif_lds(Fr *__restrict_
     using T = LdsTile<P, K1, K2>;
     using El = typename P::E;
     constexpr int K = T::K, E = T::E, TI = T::TI, R1 = 1 << K1, R2 = 1 << K2, NT = T::THREADS;
+    ZK_NTT_SETPRIO();
     extern __shared__ uint4 lds_raw[];
     El *lds = (El *)lds_raw;                       // [E][TI]
     const int tid = threadIdx.x;
@@ -458,7 +467,7 @@ __global__ __launch_bounds__(ZK_NTT_TILE / 8) void k_ntt_dif_lds(Fr *__restrict_
                     const size_t idx = base + (((size_t)q2 * R2 + m) << logS);
                     El v = x[m];
                     if (postmul) v = P::mul(v, postmul[idx]);
-                    data[idx * B + b] = P::store(v, last != 0);
+                    data[idx * B + b] = P::store(v, (last & 1) != 0);
                 }
             }
         }
@@ -472,6 +481,7 @@ __global__ __launch_bounds__(ZK_NTT_TILE / 8) void k_ntt_dit_lds(Fr *__restrict_
     using T = LdsTile<P, K1, K2>;
     using El = typename P::E;
     constexpr int K = T::K, E = T::E, TI = T::TI, R1 = 1 << K1, R2 = 1 << K2, NT = T::THREADS;
+    ZK_NTT_SETPRIO();
     extern __shared__ uint4 lds_raw[];
     El *lds = (El *)lds_raw;
     const int tid = threadIdx.x;
@@ -528,7 +538,7 @@ __global__ __launch_bounds__(ZK_NTT_TILE / 8) void k_ntt_dit_lds(Fr *__restrict_
             }
             if (active) {
 #pragma unroll
-                for (int m = 0; m < R2; m++) data[(base + (((size_t)q2 + (size_t)R1 * m) << logS)) * B + b] = P::store(x[m], last != 0);
+                for (int m = 0; m < R2; m++) data[(base + (((size_t)q2 + (size_t)R1 * m) << logS)) * B + b] = P::store(x[m], (last & 1) != 0);
             }
         }
     }
@@ -610,7 +620,7 @@ __global__ __launch_bounds__(ZK_NTT_TILE / 8) void k_ntt_dif_lds_pipe(Fr *__rest
                     const size_t idx = base + (((size_t)q2 * R2 + m) << logS);
                     El v = y[m];
                     if (postmul) v = P::mul(v, postmul[idx]);
-                    data[idx * B + b] = P::store(v, last != 0);
+                    data[idx * B + b] = P::store(v, (last & 1) != 0);
                 }
             }
         }
@@ -687,7 +697,7 @@ __global__ __launch_bounds__(ZK_NTT_TILE / 8) void k_ntt_dit_lds_pipe(Fr *__rest
             }
             if (active) {
 #pragma unroll
-                for (int m = 0; m < R2; m++) data[(base + (((size_t)q2 + (size_t)R1 * m) << logS)) * B + b] = P::store(y[m], last != 0);
+                for (int m = 0; m < R2; m++) data[(base + (((size_t)q2 + (size_t)R1 * m) << logS)) * B + b] = P::store(y[m], (last & 1) != 0);
             }
         }
         __syncthreads();
@@ -707,11 +717,11 @@ static void launch_dif_lds(Fr *data, size_t B, int logn, int loglen, const Fr *t
             static PerDeviceOnce attr2;
             attr2.run([] { ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_dif_lds_pipe<P, K1, K2, TPW>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES)); });
             grid.y /= TPW;
-            hipLaunchKernelGGL((k_ntt_dif_lds_pipe<P, K1, K2, TPW>), grid, dim3(T::THREADS), T::LDS_BYTES, s, data, B, logn, loglen, tw, postmul, (int)last);
+            hipLaunchKernelGGL((k_ntt_dif_lds_pipe<P, K1, K2, TPW>), grid, dim3(T::THREADS), T::LDS_BYTES, s, data, B, logn, loglen, tw, postmul, (int)last | t_ntt_prio_bit);
             return;
         }
     }
-    hipLaunchKernelGGL((k_ntt_dif_lds<P, K1, K2>), grid, dim3(T::THREADS), T::LDS_BYTES, s, data, B, logn, loglen, tw, postmul, (int)last);
+    hipLaunchKernelGGL((k_ntt_dif_lds<P, K1, K2>), grid, dim3(T::THREADS), T::LDS_BYTES, s, data, B, logn, loglen, tw, postmul, (int)last | t_ntt_prio_bit);
 }
 template <class P, int K1, int K2>
 static void launch_dit_lds(Fr *data, size_t B, int logn, int logS, const Fr *tw, const Fr *premul, bool last, hipStream_t s) {
@@ -726,11 +736,11 @@ static void launch_dit_lds(Fr *data, size_t B, int logn, int logS, const Fr *tw,
             static PerDeviceOnce attr2;
             attr2.run([] { ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_dit_lds_pipe<P, K1, K2, TPW>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES)); });
             grid.y /= TPW;
-            hipLaunchKernelGGL((k_ntt_dit_lds_pipe<P, K1, K2, TPW>), grid, dim3(T::THREADS), T::LDS_BYTES, s, data, B, logn, logS, tw, premul, (int)last);
+            hipLaunchKernelGGL((k_ntt_dit_lds_pipe<P, K1, K2, TPW>), grid, dim3(T::THREADS), T::LDS_BYTES, s, data, B, logn, logS, tw, premul, (int)last | t_ntt_prio_bit);
             return;
         }
     }
-    hipLaunchKernelGGL((k_ntt_dit_lds<P, K1, K2>), grid, dim3(T::THREADS), T::LDS_BYTES, s, data, B, logn, logS, tw, premul, (int)last);
+    hipLaunchKernelGGL((k_ntt_dit_lds<P, K1, K2>), grid, dim3(T::THREADS), T::LDS_BYTES, s, data, B, logn, logS, tw, premul, (int)last | t_ntt_prio_bit);
 }
 
 template <class P, int K>
@@ -1103,6 +1113,7 @@ const Fr *NttDomain::table9(const Fr *t) const {
 }
 void NttDomain::dif(Fr *data, size_t B, bool inverse, const Fr *postmul, hipStream_t s) const {
     const Fr *tw = inverse ? tw_inv.p : tw_fwd.p;
+    t_ntt_prio_bit = hi_prio ? 2 : 0;
 #ifdef ZK_EXPERIMENTS
     static const int diag = [] { const char *e = getenv("ZKPROVE_NTT_DIAG"); return e ? atoi(e) : 0; }();
     if (diag == 1 || diag == 2 || diag == 9 || f9) {
@@ -1120,6 +1131,7 @@ void NttDomain::dif(Fr *data, size_t B, bool inverse, const Fr *postmul, hipStre
 }
 void NttDomain::dit(Fr *data, size_t B, bool inverse, const Fr *premul, hipStream_t s) const {
     const Fr *tw = inverse ? tw_inv.p : tw_fwd.p;
+    t_ntt_prio_bit = hi_prio ? 2 : 0;
 #ifdef ZK_EXPERIMENTS
     static const int diag = [] { const char *e = getenv("ZKPROVE_NTT_DIAG"); return e ? atoi(e) : 0; }();
     if (diag == 1 || diag == 2 || diag == 9 || f9) {

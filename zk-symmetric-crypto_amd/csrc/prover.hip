@@ -191,6 +191,7 @@ void Algorithm::load(const uint8_t *pkb, size_t pk_len, const uint8_t *r1cs_byte
     for (size_t l = 0; l < prog.levels.size(); l++) if (prog.levels[l].has_commit) commit_level = l;
     const int logn = cs.log_domain();
     dom.init(logn, st);
+    dom.hi_prio = prog.levels.size() <= 256;      // short programs: the copy stream's chain transforms -> patterns -> walk bounds the window between two walks (ntt.hip, ZK_NTT_PRIO)
     const size_t N = (size_t)1 << logn, nw = cs.nb_wires();
 
     PkCursor c{pkb, pk_len};
@@ -714,6 +715,7 @@ void Algorithm::comb_prepare(size_t B) {
         if (pick.k) {
             try {
                 ok = comb_build(pk.Zcomb, pk.ze.p, pk.ze.n, pick.k, R.stream, pick.n1);
+                pk.Zcomb.hi_prio = dom.hi_prio;
                 if (!ok) why = "degenerate bases";
             } catch (const ZkError &e) {
                 pk.Zcomb.table.release();
@@ -769,13 +771,14 @@ void Algorithm::comb_top_up() {
     bool ok = false;
     try {
         ok = comb_build(pk.Zcomb, pk.ze.p, n, pick.k, R.stream, pick.n1);
+        pk.Zcomb.hi_prio = dom.hi_prio;
     } catch (const ZkError &e) {
         pk.Zcomb = CombBases();
         (void)hipGetLastError();
         fprintf(stderr, "zkprove: comb top-up failed (%s): rebuilding the previous tables\n", e.what());
     }
     if (!ok) {
-        try { ok = comb_build(pk.Zcomb, pk.ze.p, n, old_k, R.stream, old_n1); } catch (const ZkError &) { pk.Zcomb = CombBases(); (void)hipGetLastError(); }
+        try { ok = comb_build(pk.Zcomb, pk.ze.p, n, old_k, R.stream, old_n1); pk.Zcomb.hi_prio = dom.hi_prio; } catch (const ZkError &) { pk.Zcomb = CombBases(); (void)hipGetLastError(); }
         if (!ok) { fprintf(stderr, "zkprove: comb tables lost: this algorithm continues on the bucket pipeline\n"); comb_release(); return; }
     }
     R.comb.reserve(pk.Zcomb, R.cap, pat_slots());
