@@ -32,6 +32,16 @@
 
 namespace zk {
 
+// The fold kernels are chains of dependent group operations on a handful of wavefronts (latency, not throughput); raising their issue
+// priority (-DZK_FOLD_PRIO=3) was measured: nothing for either circuit (same box, three runs each, profiles/r06k_*) -- off
+#ifndef ZK_FOLD_PRIO
+#define ZK_FOLD_PRIO 0
+#endif
+#if ZK_FOLD_PRIO > 0
+#define ZK_FOLD_SETPRIO() __builtin_amdgcn_s_setprio(ZK_FOLD_PRIO)
+#else
+#define ZK_FOLD_SETPRIO() ((void)0)
+#endif
 #ifndef ZK_PAT_PRIO
 #define ZK_PAT_PRIO 3                           // issue priority of the pattern kernel's wavefronts (A/B build: -DZK_PAT_PRIO=0)
 #endif
@@ -425,6 +435,7 @@ __global__ __launch_bounds__(64, ZK_COMB_BOUNDS(F)) void k_comb_walk(const Affin
 template <class F>
 __global__ __launch_bounds__(64, ZK_COMB_BOUNDS(F)) void k_comb_fold1(const typename Nine<F>::X9 *__restrict__ acc, size_t B, int T, uint32_t Q, uint32_t qstride,
                                                                      typename Nine<F>::X9 *__restrict__ r1, int g0) {
+    ZK_FOLD_SETPRIO();
     using X9 = typename Nine<F>::X9;
     const size_t tiles = (B + 63) / 64;
     const size_t g = (size_t)g0 + blockIdx.x / tiles, b = (blockIdx.x % tiles) * 64 + threadIdx.x;
@@ -444,6 +455,7 @@ __global__ __launch_bounds__(64, ZK_COMB_BOUNDS(F)) void k_comb_fold1(const type
 // place; repeated until at most 8 slots per pair are left.  7 dependent additions per level instead of Q per plane in stage 1.
 template <class F>
 __global__ __launch_bounds__(64, ZK_COMB_BOUNDS(F)) void k_comb_fold_ranges(typename Nine<F>::X9 *__restrict__ acc, size_t TB, uint32_t Q, uint32_t stride, size_t f0, size_t fcount) {
+    ZK_FOLD_SETPRIO();
     using X9 = typename Nine<F>::X9;
     const size_t tiles = (fcount + 63) / 64;
     const size_t j = blockIdx.x / tiles, fl = (blockIdx.x % tiles) * 64 + threadIdx.x;
@@ -460,6 +472,7 @@ template <class F>
 __global__ __launch_bounds__(64, ZK_COMB_BOUNDS(F)) void k_comb_fold2(const typename Nine<F>::X9 *__restrict__ r1, size_t B, int groups, const Affine<F> *__restrict__ corr,
                                                                      XYZZ<F> *__restrict__ out, size_t out_stride, int g_lo, const typename Nine<F>::X9 *__restrict__ init,
                                                                      typename Nine<F>::X9 *__restrict__ part) {
+    ZK_FOLD_SETPRIO();
     using F9 = typename Nine<F>::F9;
     using X9 = typename Nine<F>::X9;
     const size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
@@ -487,6 +500,7 @@ __global__ __launch_bounds__(64, ZK_COMB_BOUNDS(F)) void k_comb_fold2(const type
 template <class F>
 __global__ __launch_bounds__(64, ZK_COMB_BOUNDS(F)) void k_comb_fold_narrow(const typename Nine<F>::X9 *__restrict__ acc, size_t B, int T, uint32_t Q, uint32_t qstride,
                                                                            const Affine<F> *__restrict__ corr, XYZZ<F> *__restrict__ out, size_t out_stride) {
+    ZK_FOLD_SETPRIO();
     using F9 = typename Nine<F>::F9;
     using X9 = typename Nine<F>::X9;
     const size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;

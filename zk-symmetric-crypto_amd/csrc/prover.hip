@@ -191,7 +191,8 @@ void Algorithm::load(const uint8_t *pkb, size_t pk_len, const uint8_t *r1cs_byte
     for (size_t l = 0; l < prog.levels.size(); l++) if (prog.levels[l].has_commit) commit_level = l;
     const int logn = cs.log_domain();
     dom.init(logn, st);
-    dom.hi_prio = prog.levels.size() <= 256;      // short programs: the copy stream's chain transforms -> patterns -> walk bounds the window between two walks (ntt.hip, ZK_NTT_PRIO)
+    static const bool prio_off = [] { const char *e = getenv("ZKPROVE_NTT_PRIO"); return e && e[0] == '0'; }();      // A/B knob
+    dom.hi_prio = !prio_off && prog.levels.size() <= 256;      // short programs: the copy stream's chain transforms -> patterns -> walk bounds the window between two walks (ntt.hip, ZK_NTT_PRIO)
     const size_t N = (size_t)1 << logn, nw = cs.nb_wires();
 
     PkCursor c{pkb, pk_len};
