@@ -33,7 +33,7 @@
 namespace zk {
 
 // The fold kernels are chains of dependent group operations on a handful of wavefronts (latency, not throughput); raising their issue
-// priority (-DZK_FOLD_PRIO=3) was measured: nothing for either circuit (same box, three runs each, profiles/r06k_*) -- off
+// priority (-DZK_FOLD_PRIO=3) was measured: nothing for either circuit (same box, three runs each, profiles/r05zk_*) -- off
 #ifndef ZK_FOLD_PRIO
 #define ZK_FOLD_PRIO 0
 #endif

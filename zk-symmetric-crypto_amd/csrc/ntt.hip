@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void k_ntt_dit(Fr *__restrict__ data, size_t B
 #endif
 // The transforms are the critical chain of the window between two quotient walks (transforms -> patterns -> walk) while the wire MSMs, the
 // solver and the tail beside them are not: the pass kernels raise the issue priority of their wavefronts (s_setprio 3), so that they win the
-// arbitration against the other streams' wavefronts on their SIMD.  Same box, twice each (profiles/r06h_*): ChaCha20 11 420 / 11 399 -> 11 527 /
+// arbitration against the other streams' wavefronts on their SIMD.  Same box, twice each (profiles/r05zh_*): ChaCha20 11 420 / 11 399 -> 11 527 /
 // 11 504 proofs/s (the window 32.3 -> 31.3 ms), AES-256 unchanged.  -DZK_NTT_PRIO=0: A/B build without it.
 #ifndef ZK_NTT_PRIO
 #define ZK_NTT_PRIO 3

@@ -12,7 +12,7 @@ static constexpr int C_WIRE = 13;   // window bits for the wire-scalar MSMs (few
 static constexpr int C_H = 16;      // window bits for the quotient MSM (all scalars full width)
 // Up to this batch size the MSM chains run side by side on four streams (their kernels are latency-bound): Algorithm::side_max_b() -- 64 proofs,
 // and 128 for the programs with a commitment (AES): their six wire MSMs end in ~15 fold chains of 1.4-3.8 ms, which the one-stream path of
-// larger batches runs one after the other (65 proofs: 47.7 ms against 31.3 for 64, profiles/r06a_*); only while the wire combs exist
+// larger batches runs one after the other (65 proofs: 47.7 ms against 31.3 for 64, profiles/r05za_*); only while the wire combs exist
 static constexpr size_t SIDE_G2_MAX_B = 64;
 static constexpr size_t SIDE_G2_MAX_B_COMMIT = 128;
 // Once the comb tables exist (a batch of >= comb_min_batch() proofs has been served) every batch from this size takes them: the walk's
