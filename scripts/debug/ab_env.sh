@@ -1,11 +1,10 @@
-# same-box A/B of a default-on feature: ab_env.sh VAR  -> bench with VAR=0 first, then with VAR unset
-cd /root/repo
-for v in 0 ""; do
-  if [ -n "$v" ]; then export $1=$v; else unset $1; fi
-  python bench.py --cpu-proofs 0 --steps 8 2>/dev/null > /tmp/ab_$v.json
-  python -c "
-import json
-d=json.load(open('/tmp/ab_$v.json')); a=d['aes256_ctr']
-print('$1=$v', round(d['value']), round(d['ms_per_step'],1), 'ntt', round(d['phases_ms']['ntt'],1), 'z', round(d['phases_ms']['z_segments'],1), 'g1', round(d['phases_ms']['msm_g1'],1), d['gather_spot_check_verified'], '| aes', round(a['value']), round(a['ms_per_step'],1), 'ntt', round(a['phases_ms']['ntt'],1), 'g1', round(a['phases_ms']['msm_g1'],1), a['gather_spot_check_verified'])
-"
+#!/bin/bash
+# same-box A/B of one environment switch on the single-call latencies: bash scripts/debug/ab_env.sh "<VAR=value>" <alg> <sizes...>
+cd $GRAFT_REPO_ROOT
+sw=$1; alg=$2; shift 2
+O=gpurun_out/ab_env_$(echo $sw | tr -c 'A-Za-z0-9\n' '_')_$alg.txt; : > $O
+for rep in 1 2 3; do
+  echo "== base rep $rep" >> $O; python3 scripts/debug/small_batch_latency.py $alg "$@" --tables 2>&1 | grep " n " >> $O
+  echo "== $sw rep $rep" >> $O; env $sw python3 scripts/debug/small_batch_latency.py $alg "$@" --tables 2>&1 | grep " n " >> $O
 done
+cat $O

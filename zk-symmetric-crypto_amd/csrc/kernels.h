@@ -5,6 +5,18 @@
 #include "common.h"
 #include "curve.cuh"
 
+// The fold kernels are chains of dependent group operations on a handful of wavefronts (latency, not throughput); raising their issue
+// priority (-DZK_FOLD_PRIO=3; the tail kernels and k_fold_parts_tree take it too) was measured twice: nothing for either circuit at 1 024 proofs
+// (same box, three runs each, profiles/r05zk_*), nothing at 1..128 proofs per call (profiles/r05zn_*_fold_and_tail_priority_ab.txt) -- off
+#ifndef ZK_FOLD_PRIO
+#define ZK_FOLD_PRIO 0
+#endif
+#if ZK_FOLD_PRIO > 0
+#define ZK_FOLD_SETPRIO() __builtin_amdgcn_s_setprio(ZK_FOLD_PRIO)
+#else
+#define ZK_FOLD_SETPRIO() ((void)0)
+#endif
+
 namespace zk {
 
 // ------------------------------------------------------------------------------------------ NTT

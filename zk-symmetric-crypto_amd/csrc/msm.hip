@@ -1042,6 +1042,7 @@ static void partition_attr() {
 template <class F>
 __global__ __launch_bounds__(256) void k_fold_parts_tree(const XYZZ<F> *__restrict__ part, size_t stride, size_t npart, XYZZ<F> *__restrict__ out) {
     extern __shared__ uint4 fold_lds_raw[];
+    ZK_FOLD_SETPRIO();
     XYZZ<F> *lds = reinterpret_cast<XYZZ<F> *>(fold_lds_raw);
     const size_t b = blockIdx.x;
     const int t = threadIdx.x;

@@ -32,16 +32,6 @@
 
 namespace zk {
 
-// The fold kernels are chains of dependent group operations on a handful of wavefronts (latency, not throughput); raising their issue
-// priority (-DZK_FOLD_PRIO=3) was measured: nothing for either circuit (same box, three runs each, profiles/r05zk_*) -- off
-#ifndef ZK_FOLD_PRIO
-#define ZK_FOLD_PRIO 0
-#endif
-#if ZK_FOLD_PRIO > 0
-#define ZK_FOLD_SETPRIO() __builtin_amdgcn_s_setprio(ZK_FOLD_PRIO)
-#else
-#define ZK_FOLD_SETPRIO() ((void)0)
-#endif
 #ifndef ZK_PAT_PRIO
 #define ZK_PAT_PRIO 3                           // issue priority of the pattern kernel's wavefronts (A/B build: -DZK_PAT_PRIO=0)
 #endif

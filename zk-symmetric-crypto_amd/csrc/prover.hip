@@ -192,7 +192,8 @@ void Algorithm::load(const uint8_t *pkb, size_t pk_len, const uint8_t *r1cs_byte
     const int logn = cs.log_domain();
     dom.init(logn, st);
     static const bool prio_off = [] { const char *e = getenv("ZKPROVE_NTT_PRIO"); return e && e[0] == '0'; }();      // A/B knob
-    dom.hi_prio = !prio_off && prog.levels.size() <= 256;      // short programs: the copy stream's chain transforms -> patterns -> walk bounds the window between two walks (ntt.hip, ZK_NTT_PRIO)
+    static const bool prio_all = [] { const char *e = getenv("ZKPROVE_NTT_PRIO"); return e && e[0] == '2'; }();      // A/B knob: every program
+    dom.hi_prio = prio_all || (!prio_off && prog.levels.size() <= 256);      // short programs: the copy stream's chain transforms -> patterns -> walk bounds the window between two walks (ntt.hip, ZK_NTT_PRIO)
     const size_t N = (size_t)1 << logn, nw = cs.nb_wires();
 
     PkCursor c{pkb, pk_len};
@@ -346,6 +347,7 @@ __global__ __launch_bounds__(16) void k_finalize_stage1_small(const G1XYZZ *__re
                                                               const G1Affine *__restrict__ dtab, const U256 *__restrict__ r, const U256 *__restrict__ s,
                                                               G1Affine *__restrict__ ar_aff, G1Affine *__restrict__ bs1_aff, G1XYZZ *__restrict__ t_out, size_t B) {
     __shared__ G1XYZZ lds[16];
+    ZK_FOLD_SETPRIO();
     const size_t b = blockIdx.x;
     const int task = blockIdx.y, lane = threadIdx.x;
     Fr rm, sm;
@@ -366,6 +368,7 @@ __global__ __launch_bounds__(16) void k_finalize_stage1_small(const G1XYZZ *__re
 __global__ __launch_bounds__(16) void k_finalize_g2_small(const G2XYZZ *__restrict__ m_bs2, const G2Affine *__restrict__ misc, const G2Affine *__restrict__ dtab,
                                                           const U256 *__restrict__ s, ProofPoints *__restrict__ out, size_t B) {
     __shared__ G2XYZZ lds[16];
+    ZK_FOLD_SETPRIO();
     const size_t b = blockIdx.x;
     const int lane = threadIdx.x;
     uint32_t sl[8];
@@ -411,6 +414,7 @@ __global__ __launch_bounds__(320) void k_finalize_stage2_pipe(const G1Affine *__
     static_assert(RING % 2 == 0, "even and odd positions keep their slots");
     __shared__ G1XYZZ ring[RING][32];      // lanes 0..31 hold instances (64 KB of static LDS would not fit both arrays at 64)
     __shared__ G1XYZZ part[4][32];
+    ZK_FOLD_SETPRIO();
     __shared__ volatile int produced, consumed[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t b_raw = (size_t)blockIdx.x * 32 + lane;
@@ -484,6 +488,7 @@ __global__ __launch_bounds__(320) void k_finalize_stage2_pipe(const G1Affine *__
 __global__ __launch_bounds__(64) void k_finalize_stage3(const G1XYZZ *__restrict__ m_k, const G1XYZZ *__restrict__ m_z, const G1XYZZ *__restrict__ t_in,
                                                         const G1XYZZ *__restrict__ u_in, const G1XYZZ *__restrict__ v_in, const G1Affine *__restrict__ ar_aff,
                                                         ProofPoints *__restrict__ out, size_t B) {
+    ZK_FOLD_SETPRIO();
     const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     G1XYZZ krs = m_k[b];
