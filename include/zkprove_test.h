@@ -70,6 +70,9 @@ int zkp_bsb22_challenge_host(const uint8_t *com_be64, long n, uint8_t *out);
 /* ---- parity-test views of the resident batch (zkp_bench_upload / zkp_bench_step of THIS library; the drop-in does not export them) */
 /* after a step: {sum, max, instances with any} of the entries the last main-stream wire MSM handed to the bucket pipeline */
 int zkp_debug_leftovers(int algorithmID, long *out3);
+/* the solver program of an initialised algorithm: {levels, chain runs, levels inside chain runs, wavefronts of the longest chain run}
+ * (csrc/solver.hip, k_solve_chains: runs of narrow levels walked by one wavefront per independent component) */
+int zkp_debug_solver_plan(int algorithmID, long *out4);
 /* after a step: the solved wire vectors [n][n_wires][32] and the quotient-stage products f_i = A(g w^i) * B(g w^i) [n][N][32] (canonical LE,
  * natural order; the scalars of the folded quotient MSM, see csrc/keyfold.hip) of the n listed instances of the batch (instances == NULL:
  * all of them, n ignored); either output may be NULL */

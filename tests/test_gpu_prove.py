@@ -186,22 +186,50 @@ def test_pipelined_steps_produce_the_same_proofs(zk, oracle, algs):
         assert zk.proof_serialize(ref_proofs[3], alg != 0) == exp
 
 
-def test_unsatisfiable_witness_is_flagged_per_instance(zk, oracle, algs):
+@pytest.mark.parametrize("alg_id,flip", [(0, 1500), (2, 40)])
+def test_unsatisfiable_witness_is_flagged_per_instance(zk, oracle, algs, alg_id, flip):
     """a witness whose Out does not match the cipher output violates a constraint: that instance (only) reports a
-    solver error -- the reference's groth16.Prove returns an error there (panic -> {} at the ABI)"""
-    alg = algs(0)
+    solver error -- the reference's groth16.Prove returns an error there (panic -> {} at the ABI).  AES-256: the same through the
+    levels that k_solve_chains walks (the instance's neighbours in the wavefront keep their wires and proofs)"""
+    alg = algs(alg_id)
     rng = H.SplitMix64(31)
     insts = [H.make_instance(alg, rng) for _ in range(4)]
     wits = np.array([H.oracle_witness(alg, i)[0] for i in insts], np.uint32)
-    wits[2, 1500] ^= 1                      # flip one bit of Out
-    rb = zk.ResidentBatch(alg, wits, [i["r"] for i in insts], [i["s"] for i in insts], [0] * 4)
+    wits[2, flip] ^= 1                      # flip one bit of Out
+    rb = zk.ResidentBatch(alg, wits, [i["r"] for i in insts], [i["s"] for i in insts], [i["randomize"] for i in insts])
     rb.step()
     proofs, errs = rb.fetch()
-    assert errs[2] != 0 and (errs[2] & 0xFF) == 1 and not errs[[0, 1, 3]].any()
-    exp, *_ = H.oracle_proof_bytes(alg, insts[0])
-    assert zk.proof_serialize(proofs[0], False) == exp
-    with pytest.raises(ValueError, match="not satisfied"):
+    assert errs[2] != 0 and not errs[[0, 1, 3]].any()
+    if alg_id == 0:
+        assert (errs[2] & 0xFF) == 1
+    for k in (0, 3):
+        exp, *_ = H.oracle_proof_bytes(alg, insts[k])
+        assert zk.proof_serialize(proofs[k], alg_id != 0) == exp
+    with pytest.raises(ValueError):
         H.circuit(alg).solve([int(x) for x in wits[2]])
+
+
+def test_chain_runs_cover_the_tail_of_the_aes_programs(zk):
+    """csrc/solver.hip, k_solve_chains: the 321 narrow levels that end the AES programs (five permutations of dependent multiplications
+    and their check rows) are one chain run -- components that read none of each other's wires, a wavefront each; ChaCha20 has no such
+    run.  (Its wires are pinned by every parity test of the AES circuits; ZKPROVE_SOLVER_CHAINS=0 keeps the level-by-level walk of the
+    same run bit-exact, test_gpu_kernels.py::test_alternative_field_paths_stay_bit_exact.)"""
+    import ctypes
+    plans = {}
+    for alg_id in (0, 1, 2):
+        out = (ctypes.c_long * 4)()
+        tl = zk.testlib
+        r1cs = zk.synth.r1cs_bytes(alg_id)
+        pk, _ = zk.setup(r1cs, zk.synth.toxic_from_seed(1), raw=True)
+        tl.ZkpAllowUnpinnedKeys(1)
+        assert zk.init_algorithm(alg_id, pk, r1cs, lib=tl)
+        assert tl.zkp_debug_solver_plan(alg_id, out) == 0
+        plans[alg_id] = list(out)
+    tl.ZkpReset()
+    assert plans[0][1] == 0, plans
+    for a in (1, 2):
+        levels, runs, inside, waves = plans[a]
+        assert runs >= 1 and inside >= 300 and inside < levels and 5 <= waves <= 8, plans
 
 
 @pytest.mark.parametrize("alg", [0, 1, 2])

@@ -74,6 +74,7 @@ def _load_testlib():
                 ("zkp_debug_tree", _i32, [_i32, _i32, _i32, _i32]),
                 ("zkp_debug_fetch", _i32, [_i32, _vp, _i64, _vp, _vp]),
                 ("zkp_debug_leftovers", _i32, [_i32, _vp]),
+                ("zkp_debug_solver_plan", _i32, [_i32, _vp]),
                 ("zkp_pairing_product_check", _i32, [_vp, _vp, _i64, _i32]),
                 ("zkp_vk_pairing_identities", _i32, [_vp, _i64, _i32]),
                 ("zkp_expand_message_xmd", _i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i32]),

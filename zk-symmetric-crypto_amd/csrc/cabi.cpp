@@ -722,6 +722,18 @@ void debug_leftovers(int id, long *out3) {
     if (!a || !a->res) throw ZkError("algorithm not initialised / nothing uploaded");
     a->debug_leftovers(out3);
 }
+// {levels, chain runs (SolverProgram::chain_runs), levels inside them, wavefronts of the longest run}
+void debug_solver_plan(int id, long *out4) {
+    Algorithm *a = (id >= 0 && id < 3) ? get_alg(id) : nullptr;
+    if (!a) throw ZkError("algorithm not initialised");
+    const SolverProgram &p = a->prog;
+    out4[0] = (long)p.levels.size(); out4[1] = (long)p.chain_runs.size(); out4[2] = 0; out4[3] = 0;
+    uint32_t longest = 0;
+    for (const auto &r : p.chain_runs) {
+        out4[2] += r.l1 - r.l0;
+        if (r.l1 - r.l0 > longest) { longest = r.l1 - r.l0; out4[3] = r.waves; }
+    }
+}
 void debug_fetch(int id, const uint32_t *instances, size_t n, uint8_t *wires, uint8_t *h) {
     Algorithm *a = (id >= 0 && id < 3) ? get_alg(id) : nullptr;
     if (!a || !a->res) throw ZkError("algorithm not initialised / nothing uploaded");

@@ -33,6 +33,15 @@ struct SolverProgram {
     DevBuf<uint32_t> level_desc;                    // (first, count, wide, div_first, div_count) per level: what k_solve_narrow_run reads on the device
     DevBuf<Fr> coeffs, coeff_inv, lookup_tables, count_tables;   // lookup_tables: [table][256]
     DevBuf<uint32_t> div_list;                      // (constraint, loc, wire, coeff) x deferred divisions, grouped by level
+    // "chain runs" (k_solve_chains): a run of narrow levels whose instructions are all multiplication rows (unknown in O, or none) and fall
+    // into components that never read each other's wires -- the AES programs end in five MiMC-like permutations, 321 levels of five
+    // dependent multiplications.  Every component is walked by ONE wavefront from the run's first level to its last, without a barrier:
+    // chain_recs = 16 words per instruction of wave w (level order), records chain_wave_first[first + w] .. [first + w + 1];
+    // chain_consts = the per-side sums of an instruction's constant terms (entry 0 = zero)
+    struct ChainRun { uint32_t l0 = 0, l1 = 0, waves = 0, first = 0; };
+    std::vector<ChainRun> chain_runs;
+    DevBuf<uint32_t> chain_recs, chain_wave_first;
+    DevBuf<Fr> chain_consts;
     // "lane program" of the small-batch kernel (k_solve_lanes; see there): per level a list of wavefront tasks -- 64 instructions of
     // ONE shape with their wire / constraint numbers as structure-of-arrays columns, or one long instruction for the lanes to share
     DevBuf<uint32_t> lp_shapes, lp_tasks, lp_soa, lp_level;

@@ -25,6 +25,7 @@ namespace zk {
 static constexpr int COOP_MIN_TERMS = 16;
 // levels of at most this many instructions are "narrow": runs of them are walked by one launch (k_solve_narrow_run)
 static constexpr uint32_t NARROW_MAX = 16;
+static constexpr uint32_t CHAIN_MAX_WAVES = 8;      // wavefronts of a k_solve_chains workgroup: components of a chain run share them
 // lane program (k_solve_lanes): instructions with a linear expression of at least this many terms are shared by the lanes of a wavefront
 static constexpr uint32_t LP_WIDE_TERMS = 32;
 enum : uint32_t { LP_TASK_LANES = 0, LP_TASK_WIDE = 1, LP_TASK_COUNT = 2 };
@@ -309,6 +310,121 @@ void SolverProgram::build(const R1cs &cs, hipStream_t s) {
         for (auto &lv : levels) desc.insert(desc.end(), {lv.first, lv.count, lv.wide, lv.div_first, lv.div_count});
         (void)max_counts;
         level_desc.upload(desc.data(), desc.size(), s);
+    }
+    // ---- chain runs (k_solve_chains, below): maximal runs of narrow levels, every instruction a multiplication row
+    {
+        chain_runs.clear();
+        std::vector<uint32_t> c_rec, c_first;                       // 16 words per instruction (layout: k_solve_chains)
+        std::vector<Fr> c_const(1, Fr::zero());                     // folded constants; entry 0 = zero
+        std::map<std::array<uint32_t, 8>, uint32_t> const_at;
+        auto intern = [&](const Fr &v) -> uint32_t {
+            if (v.is_zero()) return 0;
+            std::array<uint32_t, 8> key;
+            memcpy(key.data(), v.l, 32);
+            auto it = const_at.find(key);
+            if (it == const_at.end()) { it = const_at.emplace(key, (uint32_t)c_const.size()).first; c_const.push_back(v); }
+            return it->second;
+        };
+        // Terms over wire 0 (the circuit's constant ONE: k_assign_inputs writes Fr::one() there for every proof) and constant terms are the
+        // same number for every proof: folded per side here, with the values the device code gives them (term_apply).  Field additions are
+        // exact on canonical values, so the order of a side's terms does not show in the result.
+        auto emit = [&](uint32_t i) {
+            const uint32_t *rec = prg.data() + off[i];
+            Fr K[3] = {Fr::zero(), Fr::zero(), Fr::zero()};
+            uint32_t dyn[3] = {0, 0, 0};
+            std::vector<uint32_t> terms;
+            const uint32_t *q = rec + 8;
+            for (int side = 0; side < 3; side++)
+                for (uint32_t k = 0; k < rec[2 + side]; k++, q += 2) {
+                    const uint32_t cid = q[0], wid = q[1];
+                    if (wid != WIRE_CONST && wid != 0) { dyn[side]++; terms.push_back(cid); terms.push_back(wid); continue; }
+                    Fr cv;
+                    memcpy(cv.l, cs.coeffs[cid].data(), 32);
+                    const Fr one = Fr::one();
+                    Fr v = cv;
+                    if (wid == 0)
+                        switch (cid) {
+                            case 0: v = Fr::zero(); break;
+                            case 1: v = one; break;
+                            case 2: v = one.dbl(); break;
+                            case 3: v = one.neg(); break;
+                            case 4: v = one.dbl().neg(); break;
+                            default: break;
+                        }
+                    K[side] = K[side] + v;
+                }
+            uint32_t w16[16] = {0};
+            if (terms.size() > 8) {
+                w16[4] = 0xFFFFFFFFu; w16[5] = off[i];              // long rows (the checks): the ordinary evaluation of the program's record
+            } else {
+                w16[0] = rec[1]; w16[1] = rec[5]; w16[2] = rec[6]; w16[3] = rec[7];
+                w16[4] = dyn[0] | dyn[1] << 8 | dyn[2] << 16;
+                for (int side = 0; side < 3; side++) w16[5 + side] = intern(K[side]);
+                for (size_t k = 0; k < terms.size(); k++) w16[8 + k] = terms[k];
+            }
+            c_rec.insert(c_rec.end(), w16, w16 + 16);
+        };
+        for (size_t l = 0; l < levels.size();) {
+            if (!levels[l].narrow) { l++; continue; }
+            size_t e = l;
+            while (e < levels.size() && levels[e].narrow) e++;
+            const size_t l0 = l;
+            l = e;
+            if (e - l0 < 2) continue;
+            bool ok = true;
+            std::vector<uint32_t> ins;                           // the run's instructions in level order
+            for (size_t q = l0; q < e && ok; q++) {
+                if (levels[q].div_count) ok = false;
+                for (uint32_t k = 0; k < levels[q].count && ok; k++) {
+                    const uint32_t i = li[levels[q].first + k];
+                    const uint32_t *rec = prg.data() + off[i];
+                    if (rec[0] != OP_R1C || (rec[5] != 0 && rec[5] != 3) || rec[2] + rec[3] + rec[4] > 96 || (rec[5] == 3 && rec[6] == 0)) ok = false;      // (wire 0 stays a constant)
+                    ins.push_back(i);
+                }
+            }
+            if (!ok || ins.empty()) continue;
+            // components: an instruction joins the producers (inside the run) of the wires it reads
+            std::vector<uint32_t> parent(ins.size());
+            for (uint32_t k = 0; k < ins.size(); k++) parent[k] = k;
+            auto find = [&](uint32_t x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+            std::map<uint32_t, uint32_t> producer;               // wire -> position in ins
+            for (uint32_t k = 0; k < ins.size(); k++) {
+                const uint32_t *rec = prg.data() + off[ins[k]];
+                const uint32_t nt = rec[2] + rec[3] + rec[4];
+                for (uint32_t t2 = 0; t2 < nt; t2++) {
+                    auto it = producer.find(rec[8 + 2 * t2 + 1]);
+                    if (it != producer.end()) { const uint32_t ra = find(k), rb = find(it->second); if (ra != rb) parent[ra] = rb; }
+                }
+                if (rec[5] == 3) producer[rec[6]] = k;
+            }
+            std::map<uint32_t, std::vector<uint32_t>> comp;      // root -> members (level order, as ins is)
+            for (uint32_t k = 0; k < ins.size(); k++) comp[find(k)].push_back(k);
+            std::vector<const std::vector<uint32_t> *> by_size;
+            for (auto &kv : comp) by_size.push_back(&kv.second);
+            std::stable_sort(by_size.begin(), by_size.end(), [](const std::vector<uint32_t> *x, const std::vector<uint32_t> *y) { return x->size() > y->size(); });
+            const uint32_t W = (uint32_t)std::min<size_t>(CHAIN_MAX_WAVES, by_size.size());
+            std::vector<std::vector<uint32_t>> wave(W);
+            for (const auto *m : by_size) {                      // largest first, each to the least loaded wavefront
+                uint32_t best = 0;
+                for (uint32_t w = 1; w < W; w++) if (wave[w].size() < wave[best].size()) best = w;
+                wave[best].insert(wave[best].end(), m->begin(), m->end());
+            }
+            ChainRun cr;
+            cr.l0 = (uint32_t)l0; cr.l1 = (uint32_t)e; cr.waves = W; cr.first = (uint32_t)c_first.size();
+            for (uint32_t w = 0; w < W; w++) {
+                c_first.push_back((uint32_t)(c_rec.size() / 16));
+                for (uint32_t k : wave[w]) emit(ins[k]);
+            }
+            c_first.push_back((uint32_t)(c_rec.size() / 16));
+            chain_runs.push_back(cr);
+        }
+        c_rec.resize(c_rec.size() + 16, 0);
+        if (c_first.empty()) c_first.push_back(0);
+        chain_recs.upload(c_rec.data(), c_rec.size(), s);
+        chain_wave_first.upload(c_first.data(), c_first.size(), s);
+        chain_consts.alloc(c_const.size());
+        ZK_HIP(hipMemcpyAsync(chain_consts.p, c_const.data(), c_const.size() * sizeof(Fr), hipMemcpyHostToDevice, s));
+        ZK_HIP(hipStreamSynchronize(s));                            // (c_const is a local)
     }
     // ---- lane program (k_solve_lanes): the same instructions, regrouped per level by SHAPE -- everything of an instruction but its
     // wire / constraint numbers.  A shape is stored once (opcode, term counts, (coefficient id, is-constant) per term); the
@@ -945,6 +1061,120 @@ __global__ __launch_bounds__(LX * SL) void k_solve_narrow_run(SolveCtx cx, const
     }
 }
 
+// ---------------------------------------------------------------------------------------- chain runs: a wavefront per component, no barrier
+// The run of narrow levels that ends the AES programs is five permutations of 321 dependent multiplications ( (x + k)^2, x^2, x * (y + k),
+// 107 rounds ) plus a few check rows: k_solve_narrow_run pays a workgroup barrier, the chain of scalar loads to the instruction and a
+// store -> L2 -> load round trip of the wire per LEVEL (5.9 us, 1.9 ms of a single Prove() call and of every batch up to 128).
+// SolverProgram::build splits such a run into components that read none of each other's wires; here ONE wavefront walks each component
+// from the first level to the last.  No barrier: a lane reads only wires of its own proof, written by itself (program order) or before
+// the launch.  The last four solved wires stay in registers (the permutations read the wires of the previous one to three levels), so
+// the multiplications follow each other at register speed; the stores to a / b / c / wires drain beside them.  Same evaluation code
+// as solve_instruction (term_apply, mul_fast, finish_r1c's arithmetic): same wires, same rows.
+struct ChainFwd {
+    Fr v0, v1, v2, v3;               // the last four wires this wavefront solved
+    uint32_t i0, i1, i2, i3;
+};
+__device__ __forceinline__ Fr chain_wire(const SolveCtx &cx, const ChainFwd &f, uint32_t w, size_t b) {
+    if (w == f.i0) return f.v0;
+    if (w == f.i1) return f.v1;
+    if (w == f.i2) return f.v2;
+    if (w == f.i3) return f.v3;
+    return cx.wires[(size_t)w * cx.B + b];
+}
+// What a step needs beside the wires is the same for every lane -- constraint and wire numbers, the folded constants, the terms -- but
+// inside this loop the compiler cannot prove that the loop's own stores leave the program alone and fetches it with VECTOR loads: four
+// dependent ~1 us round trips per step (offset -> header -> terms -> coefficient) in the first version of this kernel (4 us a step).
+// Scalar loads by hand: the step's 16-word record (SolverProgram::build: constraint, location and number of the solved wire, its
+// coefficient, the sides' dynamic term counts, the sides' constants, four dynamic terms) in one, the three constants in a second.
+// Measured per step after that (one proof, wall_clock64 stamps): record 0.12 us, a term 0.4-0.5 us (the selections of term_apply /
+// mul_fast, hence the constants folded at build time), the multiplication 1.2 us (issue-bound: 128 quarter-rate multiply-adds of ONE wavefront).
+typedef uint32_t chain_u32x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t chain_u32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ Fr chain_fr(const chain_u32x8 &k) {
+    Fr r;
+#pragma unroll
+    for (int j = 0; j < 8; j++) r.l[j] = k[j];
+    return r;
+}
+__global__ __launch_bounds__(64 * CHAIN_MAX_WAVES) void k_solve_chains(SolveCtx cx, const uint32_t *__restrict__ chain_recs, const uint32_t *__restrict__ wave_first,
+                                                                      const Fr *__restrict__ consts) {
+    const size_t B = cx.B;
+    const size_t b_raw = (size_t)blockIdx.x * 64 + threadIdx.x;
+    const bool live = b_raw < B;
+    const size_t b = live ? b_raw : B - 1;               // dead lanes shadow the last instance and store nothing
+    const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const uint32_t k0 = __builtin_amdgcn_readfirstlane(wave_first[w]), k1 = __builtin_amdgcn_readfirstlane(wave_first[w + 1]);
+    ChainFwd f;
+    f.v0 = f.v1 = f.v2 = f.v3 = Fr::zero();
+    f.i0 = f.i1 = f.i2 = f.i3 = 0xFFFFFFFEu;             // no wire has this number (WIRE_CONST is 0xFFFFFFFF)
+    // (the loops stay rolled and the multiplication is a call: a single wavefront per SIMD has nobody to hide an instruction-cache miss behind)
+#pragma unroll 1
+    for (uint32_t k = k0; k < k1; k++) {
+        chain_u32x16 r;
+        asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(r) : "s"(chain_recs + 16 * (size_t)k));
+        uint32_t cons, loc, sw, sc;
+        Fr vL, vR, vO;
+        if (r[4] == 0xFFFFFFFFu) {                       // a long row: the program's own record, every wire from memory (a lane's own stores are visible to it)
+            const uint32_t *p = cx.prog + r[5];
+            cons = p[1]; loc = p[5]; sw = p[6]; sc = p[7];
+            const uint32_t nL = p[2], nR = p[3], nO = p[4];
+            p += 8;
+            auto side = [&](uint32_t n) {
+                Fr a = Fr::zero();
+#pragma unroll 1
+                for (uint32_t q = 0; q < n; q++, p += 2) a = a + term_val(cx, p[0], p[1], b);
+                return a;
+            };
+            vL = side(nL); vR = side(nR); vO = side(nO);
+        } else {
+            cons = r[0]; loc = r[1]; sw = r[2]; sc = r[3];
+            const uint32_t nL = r[4] & 0xFF, nLR = nL + ((r[4] >> 8) & 0xFF), nT = nLR + (r[4] >> 16);
+            chain_u32x8 qL, qR, qO;
+            asm volatile("s_load_dwordx8 %0, %3, 0x0\n\ts_load_dwordx8 %1, %4, 0x0\n\ts_load_dwordx8 %2, %5, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&s"(qL), "=&s"(qR), "=&s"(qO) : "s"(consts + r[5]), "s"(consts + r[6]), "s"(consts + r[7]));
+            vL = chain_fr(qL); vR = chain_fr(qR); vO = chain_fr(qO);
+#pragma unroll 1
+            for (uint32_t t = 0; t < nT; t++) {
+                uint32_t cid, wid;
+                switch (t) {
+                    case 0: cid = r[8]; wid = r[9]; break;
+                    case 1: cid = r[10]; wid = r[11]; break;
+                    case 2: cid = r[12]; wid = r[13]; break;
+                    default: cid = r[14]; wid = r[15]; break;
+                }
+                Fr cval = Fr::zero();
+                if (cid > 4) {                           // the coefficient's value: the same for every lane
+                    chain_u32x8 q;
+                    asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(q) : "s"(cx.coeffs + cid));
+                    cval = chain_fr(q);
+                }
+                const Fr v = term_apply_pre(cid, wid, chain_wire(cx, f, wid, b), cval);
+                if (t < nL) vL = vL + v;
+                else if (t < nLR) vR = vR + v;
+                else vO = vO + v;
+            }
+        }
+        if (loc == 0) {
+            if (live && mul_fast(vL, vR) != vO) report(cx, b, SERR_UNSATISFIED, cons);
+        } else {                                         // loc == 3 (SolverProgram::build admits nothing else)
+            Fr x = vL * vR - vO;                         // (mul_fast's shortcuts for 0 / +-1 give the same canonical product)
+            vO = vO + x;
+            if (sc == 3) x = x.neg();
+            else if (sc != 1) x = x * cx.coeff_inv[sc];
+            if (live) cx.wires[(size_t)sw * B + b] = x;
+            f.v3 = f.v2; f.i3 = f.i2;
+            f.v2 = f.v1; f.i2 = f.i1;
+            f.v1 = f.v0; f.i1 = f.i0;
+            f.v0 = x; f.i0 = sw;
+        }
+        if (live) {
+            cx.a[(size_t)cons * B + b] = vL;
+            cx.b[(size_t)cons * B + b] = vR;
+            cx.c[(size_t)cons * B + b] = vO;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------- one-call batches: runs of WIDE levels in one launch
 // A single AES Prove() call (B <= 8; VERDICT r4 task 5): its 118 wide levels -- up to ~100 instructions each, long rows and countHints --
 // cost 2.5 ms as 118 dependent launches (21 us each: the launch gap plus, inside every launch, the chain  level -> instruction number
@@ -1444,6 +1674,16 @@ void solver_run_levels(const SolverProgram &p, SolverBuffers &buf, size_t first_
             // a run of narrow levels: one launch (a single narrow level takes the ordinary launch)
             size_t e = l;
             while (e < last_level && e < p.levels.size() && p.levels[e].narrow) e++;
+            static const bool chains = [] { const char *e2 = getenv("ZKPROVE_SOLVER_CHAINS"); return !(e2 && e2[0] == '0'); }();      // A/B knob; tests run both
+            const SolverProgram::ChainRun *cr = nullptr;
+            if (chains)
+                for (const auto &r : p.chain_runs)
+                    if (r.l0 == l && r.l1 == e) cr = &r;
+            if (cr) {
+                hipLaunchKernelGGL(k_solve_chains, dim3(ceil_div(buf.B, 64)), dim3(64, cr->waves), 0, s, cx, p.chain_recs.p, p.chain_wave_first.p + cr->first, p.chain_consts.p);
+                l = e - 1;
+                continue;
+            }
             if (e - l >= 2) {
                 static const int sl_env = [] { const char *e2 = ZK_AB_ENV("ZKPROVE_SOLVER_RUN_WAVES"); return e2 ? atoi(e2) : 16; }();
                 if (sl_env == 4)

@@ -881,6 +881,13 @@ int request_decode_both(const char *p, size_t n);
 int host_stage_bench(const char *data, size_t len, int iters, double *out);
 void debug_leftovers(int id, long *out3);
 void debug_fetch(int id, const uint32_t *instances, size_t n, uint8_t *wires, uint8_t *h);
+void debug_solver_plan(int id, long *out4);
+}
+extern "C" int zkp_debug_solver_plan(int id, long *out4) {
+    ZKP_TRY
+    zk::debug_solver_plan(id, out4);
+    return 0;
+    ZKP_CATCH(-1)
 }
 // ---- parity-test views of the current resident batch (state of THIS library: the batch must have been uploaded and stepped through it)
 extern "C" int zkp_debug_leftovers(int id, long *out3) {
