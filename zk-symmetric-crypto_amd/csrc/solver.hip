@@ -546,9 +546,22 @@ void SolverBuffers::reserve(const SolverProgram &p, size_t B_, size_t c_B) {
 }
 
 // ----------------------------------------------------------------------------------- kernels
+// The program, the coefficient tables and the lookup tables are written before a launch and never inside one.  Reached through a plain
+// pointer in a by-value struct the compiler cannot know that: every uniform read of a program word became a VECTOR load (~1 us per
+// dependent round trip: offset -> header -> terms -> coefficient, in front of every instruction), and inside loops that store it must.
+// The CONSTANT address space says it: uniform addresses get scalar loads (s_load_dwordx2..x16 through the scalar cache), divergent ones
+// (the lane program's per-lane coefficients, table entries) ordinary loads.
+typedef const uint32_t __attribute__((address_space(4))) *ProgPtr;
+typedef const Fr __attribute__((address_space(4))) *FrTab;
+__device__ __forceinline__ Fr tab_load(FrTab p) {
+    Fr r;
+#pragma unroll
+    for (int j = 0; j < 8; j++) r.l[j] = p->l[j];
+    return r;
+}
 struct SolveCtx {
-    const uint32_t *prog;
-    const Fr *coeffs, *coeff_inv, *tables, *count_tables;
+    ProgPtr prog;
+    FrTab coeffs, coeff_inv, tables, count_tables;
     Fr *wires, *a, *b, *c;
     const Fr *randomize, *challenge;
     uint32_t *err, *count_scratch;
@@ -570,7 +583,7 @@ __device__ __forceinline__ Fr mul_fast(const Fr &a, const Fr &b) {
     return a * b;
 }
 __device__ __forceinline__ Fr term_val(const SolveCtx &cx, uint32_t cid, uint32_t wid, size_t b) {
-    if (wid == WIRE_CONST) return cx.coeffs[cid];
+    if (wid == WIRE_CONST) return tab_load(cx.coeffs + cid);
     const Fr w = cx.wires[(size_t)wid * cx.B + b];
     switch (cid) {
         case 0: return Fr::zero();
@@ -578,21 +591,21 @@ __device__ __forceinline__ Fr term_val(const SolveCtx &cx, uint32_t cid, uint32_
         case 2: return w.dbl();
         case 3: return w.neg();
         case 4: return w.dbl().neg();
-        default: return mul_fast(w, cx.coeffs[cid]);
+        default: return mul_fast(w, tab_load(cx.coeffs + cid));
     }
 }
 // p is wave-uniform (one instruction per workgroup row): the (cid, wid) words come from scalar loads, and the
 // wire loads of four terms are issued together so that a 100-term linear expression costs ~25 memory round
 // trips instead of 100 (the long add32 constraints used to set every level's latency).
 __device__ __forceinline__ Fr term_apply(const SolveCtx &cx, uint32_t cid, uint32_t wid, const Fr &w) {
-    if (wid == WIRE_CONST) return cx.coeffs[cid];
+    if (wid == WIRE_CONST) return tab_load(cx.coeffs + cid);
     switch (cid) {
         case 0: return Fr::zero();
         case 1: return w;
         case 2: return w.dbl();
         case 3: return w.neg();
         case 4: return w.dbl().neg();
-        default: return mul_fast(w, cx.coeffs[cid]);
+        default: return mul_fast(w, tab_load(cx.coeffs + cid));
     }
 }
 // the same with the coefficient's value already in registers
@@ -607,7 +620,7 @@ __device__ __forceinline__ Fr term_apply_pre(uint32_t cid, uint32_t wid, const F
         default: return mul_fast(w, cval);
     }
 }
-__device__ __forceinline__ Fr eval_terms(const SolveCtx &cx, const uint32_t *&p, uint32_t n, size_t b) {
+__device__ __forceinline__ Fr eval_terms(const SolveCtx &cx, ProgPtr &p, uint32_t n, size_t b) {
     Fr acc = Fr::zero();
     uint32_t k = 0;
     for (; k + 8 <= n; k += 8, p += 16) {
@@ -632,7 +645,7 @@ __device__ __forceinline__ Fr eval_terms(const SolveCtx &cx, const uint32_t *&p,
     for (; k < n; k++, p += 2) acc = acc + term_val(cx, p[0], p[1], b);
     return acc;
 }
-__device__ __forceinline__ Fr eval_linexp(const SolveCtx &cx, const uint32_t *&p, size_t b) {
+__device__ __forceinline__ Fr eval_linexp(const SolveCtx &cx, ProgPtr &p, size_t b) {
     uint32_t n = *p++;
     return eval_terms(cx, p, n, b);
 }
@@ -642,7 +655,7 @@ __device__ __forceinline__ Fr eval_linexp(const SolveCtx &cx, const uint32_t *&p
 // Workgroup shapes (instances x slices = 256 threads): 64 x 4 for real batches; 16 x 16 and 8 x 32 for the small batches of
 // single Prove() calls, where spare lanes are better spent on the terms of an expression than on instances that do not exist.
 template <int LX, int SL>
-__device__ __forceinline__ Fr eval_terms_coop(const SolveCtx &cx, const uint32_t *&p, uint32_t n, size_t b, Fr *red) {
+__device__ __forceinline__ Fr eval_terms_coop(const SolveCtx &cx, ProgPtr &p, uint32_t n, size_t b, Fr *red) {
     const int slice = threadIdx.y, lane = threadIdx.x;
     if (n < COOP_MIN_TERMS) {
         if (slice == 0) return eval_terms(cx, p, n, b);
@@ -651,7 +664,7 @@ __device__ __forceinline__ Fr eval_terms_coop(const SolveCtx &cx, const uint32_t
     }
     const uint32_t chunk = (n + SL - 1) / SL;
     const uint32_t lo = slice * chunk, hi = lo + chunk < n ? lo + chunk : n;
-    const uint32_t *q = p + 2 * lo;
+    ProgPtr q = p + 2 * lo;
     Fr part = lo < hi ? eval_terms(cx, q, hi - lo, b) : Fr::zero();
     p += 2 * n;
     red[slice * LX + lane] = part;
@@ -665,7 +678,7 @@ __device__ __forceinline__ Fr eval_terms_coop(const SolveCtx &cx, const uint32_t
     return acc;
 }
 template <int LX, int SL>
-__device__ __forceinline__ Fr eval_linexp_coop(const SolveCtx &cx, const uint32_t *&p, size_t b, Fr *red) {
+__device__ __forceinline__ Fr eval_linexp_coop(const SolveCtx &cx, ProgPtr &p, size_t b, Fr *red) {
     uint32_t n = *p++;
     return eval_terms_coop<LX, SL>(cx, p, n, b, red);
 }
@@ -716,7 +729,7 @@ __device__ __forceinline__ void finish_r1c(const SolveCtx &cx, size_t b, uint32_
             return;
         }
         if (sc == 3) x = x.neg();
-        else if (sc != 1) x = x * cx.coeff_inv[sc];
+        else if (sc != 1) x = x * tab_load(cx.coeff_inv + sc);
         cx.wires[(size_t)sw * B + b] = x;
     }
     cx.a[(size_t)cons * B + b] = vL;
@@ -735,7 +748,7 @@ __device__ __forceinline__ void finish_nbits(const SolveCtx &cx, size_t b, uint3
 template <int LX, int SL, bool COOP, bool INLINE_DIV = false>
 __device__ __forceinline__ void solve_instruction(const SolveCtx &cx, const uint32_t *__restrict__ instr_off, uint32_t instr, size_t b, bool live, bool lead, Fr *red) {
     const size_t B = cx.B;
-    const uint32_t *p = cx.prog + instr_off[instr];
+    ProgPtr p = cx.prog + instr_off[instr];
     const uint32_t op = p[0];
     if (op == OP_R1C) {
         const uint32_t cons = p[1], nL = p[2], nR = p[3], nO = p[4], loc = p[5], sw = p[6], sc = p[7];
@@ -766,23 +779,23 @@ __device__ __forceinline__ void solve_instruction(const SolveCtx &cx, const uint
         // The slices take every SL-th query (one lane used to walk all of them: the three longest levels of the AES circuits,
         // 3-4 ms each); counters live in global memory, hence atomics.
         const uint32_t ntab = p[1], ncol = p[2], nq = p[3], out0 = p[4], slot = p[5], toff = p[6];
-        const uint32_t *row_start = p + 8 + p[7];
+        ProgPtr row_start = p + 8 + p[7];
         p += 8;
         const uint32_t slice = threadIdx.y;
         uint32_t *cnt = cx.count_scratch + (size_t)slot * cx.count_rows * B;
         if (live)
             for (uint32_t r = slice; r < ntab; r += SL) cnt[(size_t)r * B + b] = 0;
         __syncthreads();
-        const Fr *tab = cx.count_tables + toff;
+        FrTab tab = cx.count_tables + toff;
         for (uint32_t j = slice; j < nq; j += SL) {
-            const uint32_t *pq = p + row_start[j];
+            ProgPtr pq = p + row_start[j];
             // first column of a logderivlookup table row is the row index: O(1) candidate, then full-row compare
             uint32_t row = 0;
             bool ok = true;
             for (uint32_t col = 0; col < ncol; col++) {
                 const Fr qv = eval_linexp(cx, pq, b);
                 if (col == 0) ok = small_index(qv, ntab, row);
-                if (ok && tab[(size_t)row * ncol + col] != qv) ok = false;
+                if (ok && tab_load(tab + ((size_t)row * ncol + col)) != qv) ok = false;
             }
             if (!live) continue;
             if (ok) atomicAdd(&cnt[(size_t)row * B + b], 1u);
@@ -800,7 +813,7 @@ __device__ __forceinline__ void solve_instruction(const SolveCtx &cx, const uint
             Fr v = eval_linexp(cx, p, b);
             uint32_t idx;
             if (!small_index(v, nent, idx)) { report(cx, b, SERR_LOOKUP_RANGE, instr); idx = 0; }
-            cx.wires[(size_t)(w0 + q) * B + b] = cx.tables[(size_t)tb * nent + idx];
+            cx.wires[(size_t)(w0 + q) * B + b] = tab_load(cx.tables + ((size_t)tb * nent + idx));
         }
     } else if (op == OP_RANDOMIZE) {
         cx.wires[(size_t)p[1] * B + b] = cx.randomize[b];
@@ -862,7 +875,7 @@ __global__ __launch_bounds__(LX * SL, MINB) void k_solve_level(SolveCtx cx, cons
 // Same arithmetic, same case analysis, hence the same wires and a / b / c rows as k_solve_level + k_solve_divisions (parity tests:
 // batches of 1, 7, 12 against the oracle's wire vectors).  grid = B workgroups; used up to PERSIST_MAX_B instances.
 template <int G>
-__device__ __forceinline__ Fr eval_terms_slice(const SolveCtx &cx, const uint32_t *p, uint32_t n, size_t b, int gl) {
+__device__ __forceinline__ Fr eval_terms_slice(const SolveCtx &cx, ProgPtr p, uint32_t n, size_t b, int gl) {
     if (n < (uint32_t)COOP_MIN_TERMS) {
         if (gl != 0) return Fr::zero();
         return eval_terms(cx, p, n, b);
@@ -870,7 +883,7 @@ __device__ __forceinline__ Fr eval_terms_slice(const SolveCtx &cx, const uint32_
     const uint32_t chunk = (n + G - 1) / G;
     const uint32_t lo = gl * chunk, hi = lo + chunk < n ? lo + chunk : n;
     if (lo >= hi) return Fr::zero();
-    const uint32_t *q = p + 2 * lo;
+    ProgPtr q = p + 2 * lo;
     return eval_terms(cx, q, hi - lo, b);
 }
 template <int NT>
@@ -894,7 +907,7 @@ __global__ __launch_bounds__(NT) void k_solve_persistent(SolveCtx cx, const uint
             Fr pL = Fr::zero(), pR = Fr::zero(), pO = Fr::zero();
             uint32_t op = 0, h1 = 0, h2 = 0, h5 = 0, h6 = 0, h7 = 0;
             if (mine) {
-                const uint32_t *p = cx.prog + instr_off[li[idx]];
+                ProgPtr p = cx.prog + instr_off[li[idx]];
                 op = p[0];
                 if (op == OP_R1C) {
                     const uint32_t nL = p[2], nR = p[3], nO = p[4];
@@ -929,22 +942,22 @@ __global__ __launch_bounds__(NT) void k_solve_persistent(SolveCtx cx, const uint
         const uint32_t nc = wide ? (n_counts < 16u ? n_counts : 16u) : 0u;
         for (uint32_t c = 0; c < nc; c++) {
             const uint32_t instr = li[count_idx[c]];
-            const uint32_t *p = cx.prog + instr_off[instr];
+            ProgPtr p = cx.prog + instr_off[instr];
             const uint32_t ntab = p[1], ncol = p[2], nq = p[3], out0 = p[4], slot = p[5], toff = p[6];
-            const uint32_t *row_start = p + 8 + p[7];
+            ProgPtr row_start = p + 8 + p[7];
             p += 8;
             uint32_t *cnt = cx.count_scratch + (size_t)slot * cx.count_rows * B;
             for (uint32_t r = tid; r < ntab; r += NT) cnt[(size_t)r * B + b] = 0;
             __syncthreads();
-            const Fr *tab = cx.count_tables + toff;
+            FrTab tab = cx.count_tables + toff;
             for (uint32_t j = tid; j < nq; j += NT) {
-                const uint32_t *pq = p + row_start[j];
+                ProgPtr pq = p + row_start[j];
                 uint32_t row = 0;
                 bool ok = true;
                 for (uint32_t col = 0; col < ncol; col++) {
                     const Fr qv = eval_linexp(cx, pq, b);
                     if (col == 0) ok = small_index(qv, ntab, row);
-                    if (ok && tab[(size_t)row * ncol + col] != qv) ok = false;
+                    if (ok && tab_load(tab + ((size_t)row * ncol + col)) != qv) ok = false;
                 }
                 if (ok) atomicAdd(&cnt[(size_t)row * B + b], 1u);
                 else report(cx, b, SERR_COUNT_QUERY, instr);
@@ -998,7 +1011,7 @@ __device__ __forceinline__ void solve_division_group(const SolveCtx &cx, const u
                 report(cx, b, SERR_UNSATISFIED, cons);
             }
             if (sc == 3) x = x.neg();
-            else if (sc != 1) x = x * cx.coeff_inv[sc];
+            else if (sc != 1) x = x * tab_load(cx.coeff_inv + sc);
             cx.wires[(size_t)sw * B + b] = x;
         }
     }
@@ -1041,7 +1054,7 @@ __global__ __launch_bounds__(LX * SL) void k_solve_narrow_run(SolveCtx cx, const
             const uint32_t f2 = level_desc[5 * (l + 1)], c2 = level_desc[5 * (l + 1) + 1];
             uint32_t sink = level_desc[5 * (l + 1) + 2] ^ level_desc[5 * (l + 1) + 3] ^ level_desc[5 * (l + 1) + 4];
             for (uint32_t i = 0; i < c2 && i < NARROW_MAX; i++) {
-                const uint32_t *p = cx.prog + instr_off[level_instr[f2 + i]];
+                ProgPtr p = cx.prog + instr_off[level_instr[f2 + i]];
                 uint32_t words = p[0] == OP_R1C ? 8 + 2 * (p[2] + p[3] + p[4]) : (p[0] == OP_NBITS ? 4 + 2 * p[3] : 16u);
                 if (words > 512) words = 512;
                 for (uint32_t k = 0; k < words; k += 16) sink ^= p[k];
@@ -1115,7 +1128,7 @@ __global__ __launch_bounds__(64 * CHAIN_MAX_WAVES) void k_solve_chains(SolveCtx 
         uint32_t cons, loc, sw, sc;
         Fr vL, vR, vO;
         if (r[4] == 0xFFFFFFFFu) {                       // a long row: the program's own record, every wire from memory (a lane's own stores are visible to it)
-            const uint32_t *p = cx.prog + r[5];
+            ProgPtr p = cx.prog + r[5];
             cons = p[1]; loc = p[5]; sw = p[6]; sc = p[7];
             const uint32_t nL = p[2], nR = p[3], nO = p[4];
             p += 8;
@@ -1160,7 +1173,7 @@ __global__ __launch_bounds__(64 * CHAIN_MAX_WAVES) void k_solve_chains(SolveCtx 
             Fr x = vL * vR - vO;                         // (mul_fast's shortcuts for 0 / +-1 give the same canonical product)
             vO = vO + x;
             if (sc == 3) x = x.neg();
-            else if (sc != 1) x = x * cx.coeff_inv[sc];
+            else if (sc != 1) x = x * tab_load(cx.coeff_inv + sc);
             if (live) cx.wires[(size_t)sw * B + b] = x;
             f.v3 = f.v2; f.i3 = f.i2;
             f.v2 = f.v1; f.i2 = f.i1;
@@ -1234,7 +1247,7 @@ __global__ __launch_bounds__(LX * SL) void k_solve_wide_run(SolveCtx cx, const u
             const uint32_t f2 = level_desc[5 * (l + 1)], c2 = level_desc[5 * (l + 1) + 1];
             uint32_t sink = level_desc[5 * (l + 1) + 2] ^ level_desc[5 * (l + 1) + 3] ^ level_desc[5 * (l + 1) + 4];
             if (w < c2) {
-                const uint32_t *p = cx.prog + instr_off[level_instr[f2 + w]];
+                ProgPtr p = cx.prog + instr_off[level_instr[f2 + w]];
                 uint32_t words = p[0] == OP_R1C ? 8 + 2 * (p[2] + p[3] + p[4]) : (p[0] == OP_NBITS ? 4 + 2 * p[3] : 16u);
                 if (words > 1024) words = 1024;
                 for (uint32_t k = 0; k < words; k += 16) sink ^= p[k];
@@ -1319,7 +1332,7 @@ __device__ __forceinline__ void lp_wave_reduce3(Fr &x, Fr &y, Fr &z, uint32_t wh
     }
 }
 // sum over the wavefront of the terms t = lane, lane + 64, ... of a linear expression in the program encoding; every lane gets it
-__device__ __forceinline__ Fr lp_wave_sum(const SolveCtx &cx, const uint32_t *__restrict__ p, uint32_t n, size_t b, int lane) {
+__device__ __forceinline__ Fr lp_wave_sum(const SolveCtx &cx, ProgPtr p, uint32_t n, size_t b, int lane) {
     Fr acc = Fr::zero();
     for (uint32_t t = lane; t < n; t += 64) acc = acc + term_val(cx, p[2 * t], p[2 * t + 1], b);
 #pragma unroll
@@ -1372,7 +1385,7 @@ __global__ __launch_bounds__(NT) void k_solve_lanes(SolveCtx cx, const uint32_t 
                         ff += (size_t)T * gc;
                         uint32_t idx;
                         if (!small_index(vL, nent, idx)) { report(cx, b, SERR_LOOKUP_RANGE, instr); idx = 0; }
-                        cx.wires[(size_t)(w0 + k) * B + b] = cx.tables[(size_t)tb * nent + idx];
+                        cx.wires[(size_t)(w0 + k) * B + b] = tab_load(cx.tables + ((size_t)tb * nent + idx));
                     }
                 } else if (op == OP_RANDOMIZE) {
                     cx.wires[(size_t)f[0] * B + b] = cx.randomize[b];
@@ -1380,7 +1393,7 @@ __global__ __launch_bounds__(NT) void k_solve_lanes(SolveCtx cx, const uint32_t 
                     cx.wires[(size_t)f[0] * B + b] = cx.challenge[b];
                 }
             } else {       // LP_TASK_WIDE: one instruction, the lanes take its terms
-                const uint32_t *p = cx.prog + w1;
+                ProgPtr p = cx.prog + w1;
                 const uint32_t op = p[0];
                 if (op == OP_R1C || op == OP_NBITS) {
                     // the three expressions as ONE list of terms: all (coefficient, wire) words of this lane's terms are requested together,
@@ -1388,7 +1401,7 @@ __global__ __launch_bounds__(NT) void k_solve_lanes(SolveCtx cx, const uint32_t 
                     // where three loops of  words -> wires -> reduce  followed each other (11.5 us per 130-term add32 row; 7 per nBits)
                     const bool r1c = op == OP_R1C;
                     const uint32_t nL = r1c ? p[2] : p[3], nLR = r1c ? p[2] + p[3] : nL, T = r1c ? nLR + p[4] : nL;
-                    const uint32_t *pt = p + (r1c ? 8 : 4);
+                    ProgPtr pt = p + (r1c ? 8 : 4);
                     uint32_t cw[3][2];
                     Fr wv[3];
 #pragma unroll
@@ -1401,7 +1414,7 @@ __global__ __launch_bounds__(NT) void k_solve_lanes(SolveCtx cx, const uint32_t 
 #pragma unroll
                     for (int k = 0; k < 3; k++) {
                         wv[k] = cx.wires[(size_t)(cw[k][1] == WIRE_CONST ? 0u : cw[k][1]) * B + b];
-                        cv[k] = cx.coeffs[cw[k][0]];
+                        cv[k] = tab_load(cx.coeffs + cw[k][0]);
                     }
                     Fr vL = Fr::zero(), vR = Fr::zero(), vO = Fr::zero();
 #pragma unroll
@@ -1443,7 +1456,7 @@ __global__ __launch_bounds__(NT) void k_solve_lanes(SolveCtx cx, const uint32_t 
                         if (lane == 0) {
                             uint32_t idx;
                             if (!small_index(v, nent, idx)) { report(cx, b, SERR_LOOKUP_RANGE, w2); idx = 0; }
-                            cx.wires[(size_t)(w0 + k) * B + b] = cx.tables[(size_t)tb * nent + idx];
+                            cx.wires[(size_t)(w0 + k) * B + b] = tab_load(cx.tables + ((size_t)tb * nent + idx));
                         }
                     }
                 }
@@ -1454,22 +1467,23 @@ __global__ __launch_bounds__(NT) void k_solve_lanes(SolveCtx cx, const uint32_t 
 #endif
         // countHints of this level: the whole workgroup on each (same code as the slices of k_solve_level)
         for (uint32_t c = 0; c < n_count; c++) {
-            const uint32_t *p = cx.prog + tasks[4 * (size_t)(t_first + n_tasks + c) + 1], instr = tasks[4 * (size_t)(t_first + n_tasks + c) + 2];
+            ProgPtr p = cx.prog + tasks[4 * (size_t)(t_first + n_tasks + c) + 1];
+            const uint32_t instr = tasks[4 * (size_t)(t_first + n_tasks + c) + 2];
             const uint32_t ntab = p[1], ncol = p[2], nq = p[3], out0 = p[4], slot = p[5], toff = p[6];
-            const uint32_t *row_start = p + 8 + p[7];
+            ProgPtr row_start = p + 8 + p[7];
             p += 8;
             uint32_t *cnt = cx.count_scratch + (size_t)slot * cx.count_rows * B;
             for (uint32_t r = tid; r < ntab; r += NT) cnt[(size_t)r * B + b] = 0;
             __syncthreads();
-            const Fr *tab = cx.count_tables + toff;
+            FrTab tab = cx.count_tables + toff;
             for (uint32_t j = tid; j < nq; j += NT) {
-                const uint32_t *pq = p + row_start[j];
+                ProgPtr pq = p + row_start[j];
                 uint32_t row = 0;
                 bool ok = true;
                 for (uint32_t col = 0; col < ncol; col++) {
                     const Fr qv = eval_linexp(cx, pq, b);
                     if (col == 0) ok = small_index(qv, ntab, row);
-                    if (ok && tab[(size_t)row * ncol + col] != qv) ok = false;
+                    if (ok && tab_load(tab + ((size_t)row * ncol + col)) != qv) ok = false;
                 }
                 if (ok) atomicAdd(&cnt[(size_t)row * B + b], 1u);
                 else report(cx, b, SERR_COUNT_QUERY, instr);
@@ -1568,7 +1582,7 @@ static size_t persist_max_b() {
 }
 #endif
 void solver_run_levels(const SolverProgram &p, SolverBuffers &buf, size_t first_level, size_t last_level, hipStream_t s) {
-    SolveCtx cx{p.prog.p, p.coeffs.p, p.coeff_inv.p, p.lookup_tables.p, p.count_tables.p, buf.wires.p, buf.a.p, buf.b.p, buf.c_shared ? buf.c_shared : buf.c.p,
+    SolveCtx cx{(ProgPtr)(uintptr_t)p.prog.p, (FrTab)(uintptr_t)p.coeffs.p, (FrTab)(uintptr_t)p.coeff_inv.p, (FrTab)(uintptr_t)p.lookup_tables.p, (FrTab)(uintptr_t)p.count_tables.p, buf.wires.p, buf.a.p, buf.b.p, buf.c_shared ? buf.c_shared : buf.c.p,
                 buf.randomize.p, buf.challenge.p, buf.err.p, buf.count_scratch.p, buf.B, p.n_count_rows, nullptr};
     if (last_level > p.levels.size()) last_level = p.levels.size();
 #ifdef ZK_EXPERIMENTS
