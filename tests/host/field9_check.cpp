@@ -113,6 +113,17 @@ int main() {
         G1X9 y = b1; G1X9 nb = b1; nb.Y = Fp9::norm(Fp9::neg(b1.Y)); y.add(nb);
         ok &= z.is_inf() && y.is_inf();
         ok &= same(a1.dbl(), b1.dbl());
+        {   // a run of doublings through Jacobian coordinates: another representative of the same point, and one that the record formats take
+            const int m = 1 + trial % 9;
+            G1XYZZ dd = a1;
+            for (int i = 0; i < m; i++) dd = dd.dbl();
+            const G1X9 dm = G1X9::dbl_many(b1, m);
+            const G1Affine want = dd.to_affine(), got = dm.to_xyzz().to_affine(), got2 = G1X9::from_words(dm.to_words()).to_xyzz().to_affine();
+            ok &= dd.is_inf() == dm.is_inf() && (dd.is_inf() || (want.x == got.x && want.y == got.y && want.x == got2.x && want.y == got2.y));
+            G1X9 fm = dm; fm.add(b2);              // ... and one that the addition formulas take as state
+            G1XYZZ fd = dd; fd.add(a2);
+            if (!fd.is_inf() && !dd.is_inf()) { const G1Affine w2 = fd.to_affine(), g2 = fm.to_xyzz().to_affine(); ok &= w2.x == g2.x && w2.y == g2.y; }
+        }
         if (!ok && bad++ < 10) printf("curve mismatch in trial %d\n", trial);
     }
     // the quadratic extension and G2: the formulas are identities in the coordinates, so arbitrary (x, y) pairs exercise them
@@ -160,6 +171,13 @@ int main() {
             G2XYZZ d = a1; d.add(a1);
             G2X9 e = b1; e.add(b1);
             ok &= same2(d, e) && same2(a1.dbl(), b1.dbl());
+            {   // (arbitrary (x, y) pairs are not curve points: compare the cross-multiplied coordinates, which are identities of the formulas)
+                const int m = 1 + trial % 9;
+                G2XYZZ dd = a1;
+                for (int i = 0; i < m; i++) dd = dd.dbl();
+                const G2XYZZ dm = G2X9::dbl_many(b1, m).to_xyzz();
+                ok &= dd.is_inf() == dm.is_inf() && dd.X * dm.ZZ == dm.X * dd.ZZ && dd.Y * dm.ZZZ == dm.Y * dd.ZZZ;
+            }
             if (!ok && bad++ < 10) printf("G2 mismatch in trial %d\n", trial);
         }
     }

@@ -48,6 +48,35 @@ struct alignas(16) XYZZ9 {         // 144 bytes: bucket sums travel between the 
         return r;
     }
     ZK_HD XYZZ9 dbl() const { return dbl_of(*this); }
+    // 2^m * p for a RUN of doublings (the Horner chain of the comb fold: 8 between two additions, 254 dependent ones per proof).
+    // Through Jacobian coordinates: (X, Y, ZZ, ZZZ) = (X ZZ, Y ZZZ, ZZ) since ZZZ^2 = ZZ^3, m times dbl-2009-l with the factors of
+    // two moved INSIDE the products (D = X * 4B, 8C = 4B * 2B, so X3 = E^2 - 2D and Y3 = E (D - X3) - 8C come out of their
+    // reductions in the ranges field9.cuh states for X and Y), back with ZZ = Z^2, ZZZ = Z^3.  Per doubling 6 reductions over 7
+    // products (dbl-2008-s-1 above: 8 over 9) plus 4 products per run.  The same point, another representative of it: callers
+    // compare affine coordinates.  Bounds: A, B, D, F, C8 in (-0.14 M, 1.3 M); E = 3A, B4 = 4B strict after norm, |.| < 4.6 M;
+    // X3 in (-2.8 M, 1.2 M); T = D - X3 1-lazy; Y3 = E T - B4 B2 fused, in (-0.1 M, 1.1 M); Z stays a plain product.
+    static __host__ __device__ __noinline__ XYZZ9 dbl_many(XYZZ9 p, int m) {
+        if (p.is_inf() || m <= 0) return p;
+        F9 X = F9::mul(p.X, p.ZZ), Y = F9::mul(p.Y, p.ZZZ), Z = p.ZZ;
+        for (int i = 0; i < m; i++) {
+            const F9 A = F9::sqr(X), Bv = F9::sqr(Y);
+            const F9 B2 = F9::norm(F9::add(Bv, Bv)), B4 = F9::norm(F9::add(B2, B2));
+            const F9 D = F9::mul(X, B4);
+            const F9 E = F9::norm(F9::add(F9::add(A, A), A));
+            const F9 Fv = F9::sqr(E);
+            const F9 X3 = F9::norm(F9::sub(F9::sub(Fv, D), D));
+            const F9 Y3 = F9::mulsub(E, F9::norm(F9::sub(D, X3)), B4, B2);
+            Z = F9::mul(F9::norm(F9::add(Y, Y)), Z);
+            X = X3;
+            Y = Y3;
+        }
+        XYZZ9 r;
+        r.X = X;
+        r.Y = Y;
+        r.ZZ = F9::sqr(Z);
+        r.ZZZ = F9::mul(r.ZZ, Z);
+        return r;
+    }
     // P == 0 mod M in a mixed addition: doubling (R == 0) or cancellation
     static __host__ __device__ __noinline__ XYZZ9 madd_special(F9 x2, F9 y2, F9 R) {
         if (F9::sqr(R).is_zero_mod()) return dbl_affine(x2, y2);

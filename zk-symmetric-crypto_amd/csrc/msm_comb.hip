@@ -472,8 +472,7 @@ __global__ __launch_bounds__(64, ZK_COMB_BOUNDS(F)) void k_comb_fold2(const type
     X9 r = init ? init[b] : X9::inf();
 #pragma unroll 1
     for (int g = groups - 1; g >= g_lo; g--) {
-#pragma unroll 1
-        for (int i = 0; i < FOLD_BITS; i++) r = X9::dbl_of(r);
+        r = X9::dbl_many(r, FOLD_BITS);                   // the chain's 8 doublings between two additions as one Jacobian run (curve9.cuh)
         r.add(r1[(size_t)g * B + b]);
     }
     if (part) { part[b] = r; return; }
