@@ -39,6 +39,7 @@ static constexpr int COMB_T = 254;              // bit planes of the quotient MS
 static constexpr int COMB_KMAX = 24;
 static constexpr int FOLD_BITS = 8;             // bit planes per thread of the first fold stage
 static inline int fold_groups(int T) { return (T + FOLD_BITS - 1) / FOLD_BITS; }
+static constexpr size_t FOLD_ALL_RANGES_MAX_B = 256;     // batches up to this size fold their clump ranges down to one before the plane chains (comb_fold_impl)
 
 __host__ __device__ static inline size_t zmin(size_t a, size_t b) { return a < b ? a : b; }
 // (r + 1) / 2: halving a point of the order-r group
@@ -593,10 +594,12 @@ static void comb_fold_impl(const CombBasesT<F> &cb, size_t B, CombScratch &sc, X
     static const bool skip_wire_folds = [] { const char *e = getenv("ZKPROVE_DIAG_SKIP_WIRE_FOLDS"); return e && e[0] == '1'; }();
     if (skip_wire_folds && out_stride != 1) return;
 #endif
-    // more than 8 ranges per (plane, proof) pair: 8-way in-place levels first (only small batches have them)
+    // more than 8 ranges per (plane, proof) pair: 8-way in-place levels first (only small batches have them).  Up to FOLD_ALL_RANGES_MAX_B
+    // proofs the levels go on until ONE range is left: the call is latency, and a range that stage 1 (or the narrow fold) adds is an
+    // addition on every plane's step of a dependent chain -- 8 planes x 8 ranges = 64 chained additions where a level does 7
     uint32_t Qr = Q, qstride = 1;
     const size_t TB = (size_t)cb.T * B, tb_tiles = (TB + 63) / 64;
-    while (Qr > 8) {
+    while (Qr > (B <= FOLD_ALL_RANGES_MAX_B ? 1u : 8u)) {
         const uint32_t groups8 = (Qr + 7) / 8;
         hipLaunchKernelGGL(k_comb_fold_ranges<F>, dim3((unsigned)(tb_tiles * groups8)), dim3(64), 0, s, acc, TB, Qr, qstride, (size_t)0, TB);
         Qr = groups8;
@@ -635,7 +638,7 @@ static void comb_msm_split_impl(const CombBasesT<F> &cb, const uint32_t *pat, si
     auto ranges = [&](size_t f0, size_t fc, hipStream_t st, uint32_t &Qr, uint32_t &qstride) {
         Qr = Q; qstride = 1;
         const size_t ft = (fc + 63) / 64;
-        while (Qr > 8) {
+        while (Qr > (B <= FOLD_ALL_RANGES_MAX_B ? 1u : 8u)) {
             const uint32_t groups8 = (Qr + 7) / 8;
             hipLaunchKernelGGL(k_comb_fold_ranges<F>, dim3((unsigned)(ft * groups8)), dim3(64), 0, st, acc, TB, Qr, qstride, f0, fc);
             Qr = groups8;
