@@ -450,11 +450,12 @@ def test_msm_doubling_and_cancellation_inside_a_bucket(zk, oracle, group):
     ({"ZKPROVE_PAT_SLOTS": "2", "ZKPROVE_COMB_FILL": "0", "ZKP_CHILD_FILE": "test_gpu_prove.py"}, "test_pipelined_steps_produce or test_full_size_batch"),
     # ... and the same kernel when its barriers complete (measured slower than the per-level launches: experiments build only)
     ({"ZKPROVE_SOLVER_WIDE_RUN": "1", "ZKP_CHILD_FILE": "test_gpu_prove.py"}, "test_prove_matches_oracle or (test_batch_wires_quotient_and_proofs and (2-4 or 1-3))"),
-    # the run of narrow levels that ends the AES programs level by level (k_solve_narrow_run) instead of a wavefront per component (k_solve_chains)
-    ({"ZKPROVE_SOLVER_CHAINS": "0", "ZKP_CHILD_FILE": "test_gpu_prove.py"}, "test_prove_matches_oracle or test_batch_wires_quotient_and_proofs or test_unsatisfiable"),
+    # the run of narrow levels that ends the AES programs level by level (k_solve_narrow_run) instead of a wavefront per component (k_solve_chains),
+    # and the countHints inside the level kernels, one workgroup per hint and tile, instead of sixteen in a launch of their own (k_solve_counts)
+    ({"ZKPROVE_SOLVER_CHAINS": "0", "ZKPROVE_SOLVER_COUNT_PARTS": "1", "ZKP_CHILD_FILE": "test_gpu_prove.py"}, "test_prove_matches_oracle or test_batch_wires_quotient_and_proofs or test_unsatisfiable"),
 ], ids=["transforms_9limb", "transforms_two_pass_and_unfolded_compute_h", "buckets_8x32", "persistent_solver", "fused_middle_transform_pass",
         "solver_grid_barrier_forced_timeout", "two_pattern_copies_and_fixed_share_budget", "solver_wide_runs_behind_a_grid_barrier",
-        "narrow_runs_level_by_level"])
+        "narrow_runs_and_count_hints_inside_the_level_kernels"])
 def test_alternative_field_paths_stay_bit_exact(env, select):
     """The alternatives that were measured and lost -- the 9-limb butterflies of the transforms (ZKPROVE_NTT_F9=1, csrc/ntt.hip), the
     bucket kernels on the 8 x 32 field (ZKPROVE_MSM_F9=0), the batch-affine tree (ZKPROVE_MSM_TREE=1) and the persistent small-batch

@@ -213,7 +213,7 @@ def test_chain_runs_cover_the_tail_of_the_aes_programs(zk):
     """csrc/solver.hip, k_solve_chains: the 321 narrow levels that end the AES programs (five permutations of dependent multiplications
     and their check rows) are one chain run -- components that read none of each other's wires, a wavefront each; ChaCha20 has no such
     run.  (Its wires are pinned by every parity test of the AES circuits; ZKPROVE_SOLVER_CHAINS=0 keeps the level-by-level walk of the
-    same run bit-exact, test_gpu_kernels.py::test_alternative_field_paths_stay_bit_exact.)"""
+    same run bit-exact, test_gpu_kernels.py::test_alternative_field_paths_stay_bit_exact[narrow_runs_and_count_hints_inside_the_level_kernels].)"""
     import ctypes
     plans = {}
     for alg_id in (0, 1, 2):

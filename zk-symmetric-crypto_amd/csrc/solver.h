@@ -19,6 +19,7 @@ enum SolverErr : uint32_t { SERR_NONE = 0, SERR_UNSATISFIED = 1, SERR_LOOKUP_RAN
 struct SolverLevel {
     uint32_t first = 0, count = 0;   // range in level_instr
     uint32_t wide = 0;               // the first `wide` of them need a whole workgroup (k_solve_level); the rest are packed four to one
+    uint32_t n_count = 0;            // the first n_count of the wide ones are countHints (k_solve_counts)
     bool has_commit = false;         // a BSB22 hint sits in this level: commitment must be ready before launch
     bool narrow = false;             // at most 16 instructions, no countHint, no commitment: runs of such levels are one launch (k_solve_narrow_run)
     uint32_t div_first = 0, div_count = 0;   // deferred divisions of this level (records in div_list)
@@ -72,6 +73,7 @@ struct SolverBuffers {
     DevBuf<Fr> challenge;      // [B] Montgomery (commitment challenge)
     DevBuf<uint32_t> err;      // [B] (code | constraint<<8)
     DevBuf<uint32_t> count_scratch;
+    DevBuf<uint32_t> count_ticket;      // [slot][instance tile]: k_solve_counts' finished workgroups (cleared by solver_begin)
     DevBuf<uint32_t> sync;     // [0] arrival counter, [1] abort word of k_solve_wide_run's grid barrier (cleared by solver_begin)
     uint32_t sync_arrivals = 0;      // what the counter holds after the wide-run launches enqueued since solver_begin
     bool allow_wide_run = false;     // set by the one entry that can repeat a call after SERR_RETRY (Algorithm::resident_prove); the pipelined entries keep per-level launches

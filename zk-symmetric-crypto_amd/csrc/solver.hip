@@ -286,6 +286,10 @@ void SolverProgram::build(const R1cs &cs, hipStream_t s) {
         }
         lv.wide = 0;
         for (uint32_t i : l) lv.wide += is_wide_instr[i];
+        // countHints in front of the other wide instructions: solver_run_levels gives them a launch of their own (k_solve_counts)
+        std::stable_partition(ordered.begin(), ordered.begin() + lv.wide, [&](uint32_t i) { return prg[off[i]] == OP_COUNT; });
+        lv.n_count = 0;
+        for (uint32_t i : l) lv.n_count += prg[off[i]] == OP_COUNT ? 1u : 0u;
         for (uint32_t i : ordered) {
             li.push_back(i);
             if (is_commit_instr[i]) lv.has_commit = true;
@@ -542,6 +546,7 @@ void SolverBuffers::reserve(const SolverProgram &p, size_t B_, size_t c_B) {
     raw.ensure(SOLVER_RAW_STRIDE * B);
     randomize.ensure(B); challenge.ensure(B); err.ensure(B);
     count_scratch.ensure((p.n_count_rows ? p.n_count_rows : 1) * (p.n_count_slots ? p.n_count_slots : 1) * B);
+    count_ticket.ensure((p.n_count_slots ? p.n_count_slots : 1) * (B / 8 + 1));      // tiles of at least 8 instances
     sync.ensure(2);
 }
 
@@ -566,6 +571,7 @@ struct SolveCtx {
     const Fr *randomize, *challenge;
     uint32_t *err, *count_scratch;
     size_t B, count_rows;
+    uint32_t *count_ticket;       // per (countHint slot, instance tile): workgroups of k_solve_counts that have finished their share of the queries
     unsigned long long *dbg;      // experiments build: per (level, wavefront) time stamps of k_solve_lanes (ZKPROVE_SOLVER_DBG=1), else null
 };
 
@@ -820,6 +826,50 @@ __device__ __forceinline__ void solve_instruction(const SolveCtx &cx, const uint
     } else if (op == OP_BSB22) {
         cx.wires[(size_t)p[1] * B + b] = cx.challenge[b];
     }
+}
+
+// The countHints of a level in a launch of their own.  One workgroup per hint and instance tile walked the ~3 600 queries of an AES S-box
+// lookup with its SL slices -- 112 (8 x 32) to 900 (64 x 4) queries one after the other per slice: the four longest levels of the AES
+// programs, 0.14-0.17 ms each for a single proof and 0.16-0.55 ms at 64 (1.65 of the 6.3 ms its 134 level launches take).  Here G
+// workgroups share a hint: workgroup `part` takes the queries part * SL + slice, + G * SL, ...; the counters live in global memory
+// (zeroed by solver_begin) and are incremented with agent-scope atomics as before; the workgroup that draws the LAST ticket of the
+// (hint, tile) pair -- every workgroup fences its increments, then takes one -- writes the output wires.  No workgroup waits for another.
+template <int LX, int SL>
+__global__ __launch_bounds__(LX * SL) void k_solve_counts(SolveCtx cx, const uint32_t *__restrict__ instr_off, const uint32_t *__restrict__ level_instr, uint32_t G) {
+    __shared__ uint32_t last_s;
+    const size_t B = cx.B;
+    const size_t b_raw = (size_t)blockIdx.x * LX + threadIdx.x;
+    const bool live = b_raw < B;
+    const size_t b = live ? b_raw : B - 1;
+    const uint32_t which = blockIdx.y / G, part = blockIdx.y % G, slice = threadIdx.y;
+    const uint32_t instr = level_instr[which];
+    ProgPtr p = cx.prog + instr_off[instr];            // an OP_COUNT record (SolverProgram::build puts them in front of their level)
+    const uint32_t ntab = p[1], ncol = p[2], nq = p[3], out0 = p[4], slot = p[5], toff = p[6];
+    ProgPtr row_start = p + 8 + p[7];
+    p += 8;
+    uint32_t *cnt = cx.count_scratch + (size_t)slot * cx.count_rows * B;
+    FrTab tab = cx.count_tables + toff;
+    for (uint32_t j = part * SL + slice; j < nq; j += G * SL) {
+        ProgPtr pq = p + row_start[j];
+        uint32_t row = 0;
+        bool ok = true;
+        for (uint32_t col = 0; col < ncol; col++) {
+            const Fr qv = eval_linexp(cx, pq, b);
+            if (col == 0) ok = small_index(qv, ntab, row);
+            if (ok && tab_load(tab + ((size_t)row * ncol + col)) != qv) ok = false;
+        }
+        if (!live) continue;
+        if (ok) atomicAdd(&cnt[(size_t)row * B + b], 1u);
+        else report(cx, b, SERR_COUNT_QUERY, instr);
+    }
+    __threadfence();                                   // this thread's increments are performed before the workgroup's ticket is drawn
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0)
+        last_s = __hip_atomic_fetch_add(&cx.count_ticket[(size_t)slot * gridDim.x + blockIdx.x], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == G - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!last_s || !live) return;
+    for (uint32_t r = slice; r < ntab; r += SL)
+        cx.wires[(size_t)(out0 + r) * B + b] = Fr::from_u32(__hip_atomic_load(&cnt[(size_t)r * B + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
 // grid = (ceil(B / LX), workgroups of the level), block = (LX instances, SL slices).  The first `nwide` workgroup rows take one
@@ -1565,6 +1615,10 @@ void solver_begin(const SolverProgram &p, SolverBuffers &buf, hipStream_t s) {
     ZK_HIP(hipMemsetAsync(buf.err.p, 0, B * sizeof(uint32_t), s));
     ZK_HIP(hipMemsetAsync(buf.sync.p, 0, 2 * sizeof(uint32_t), s));
     buf.sync_arrivals = 0;
+    if (p.n_count_slots) {      // the counters of the countHints (every slot is counted into once per solve) and the tickets of k_solve_counts
+        ZK_HIP(hipMemsetAsync(buf.count_scratch.p, 0, p.n_count_rows * p.n_count_slots * B * sizeof(uint32_t), s));
+        ZK_HIP(hipMemsetAsync(buf.count_ticket.p, 0, p.n_count_slots * (B / 8 + 1) * sizeof(uint32_t), s));
+    }
     if (buf.raw_alg >= 0) {
         const size_t want = buf.raw_alg == 0 ? 2560 : (buf.raw_alg == 1 ? 241 : 257);
         if (p.n_inputs != want) throw ZkError("solver: raw witness records do not match the circuit");
@@ -1583,7 +1637,7 @@ static size_t persist_max_b() {
 #endif
 void solver_run_levels(const SolverProgram &p, SolverBuffers &buf, size_t first_level, size_t last_level, hipStream_t s) {
     SolveCtx cx{(ProgPtr)(uintptr_t)p.prog.p, (FrTab)(uintptr_t)p.coeffs.p, (FrTab)(uintptr_t)p.coeff_inv.p, (FrTab)(uintptr_t)p.lookup_tables.p, (FrTab)(uintptr_t)p.count_tables.p, buf.wires.p, buf.a.p, buf.b.p, buf.c_shared ? buf.c_shared : buf.c.p,
-                buf.randomize.p, buf.challenge.p, buf.err.p, buf.count_scratch.p, buf.B, p.n_count_rows, nullptr};
+                buf.randomize.p, buf.challenge.p, buf.err.p, buf.count_scratch.p, buf.B, p.n_count_rows, buf.count_ticket.p, nullptr};
     if (last_level > p.levels.size()) last_level = p.levels.size();
 #ifdef ZK_EXPERIMENTS
     if (buf.B <= persist_max_b() && first_level < last_level) {
@@ -1710,26 +1764,40 @@ void solver_run_levels(const SolverProgram &p, SolverBuffers &buf, size_t first_
                 continue;
             }
         }
-        const uint32_t packed_rows = lv.wide + (lv.count - lv.wide + 3) / 4;
+        // the level's countHints first, G workgroups each (k_solve_counts); the level kernels below take the rest of the level
+        static const uint32_t count_parts = [] { const char *e2 = getenv("ZKPROVE_SOLVER_COUNT_PARTS"); return e2 ? (uint32_t)atoi(e2) : 16u; }();      // 1: inside the level kernels, as before
+        uint32_t skip = 0;
+        if (count_parts > 1 && lv.n_count && (size_t)lv.n_count * count_parts <= 65535) {
+            const dim3 gy(1, lv.n_count * count_parts);
+            if (buf.B <= 8) hipLaunchKernelGGL((k_solve_counts<8, 32>), dim3(ceil_div(buf.B, 8), gy.y), dim3(8, 32), 0, s, cx, p.instr_off.p, p.level_instr.p + lv.first, count_parts);
+            else if (buf.B <= 16) hipLaunchKernelGGL((k_solve_counts<16, 16>), dim3(ceil_div(buf.B, 16), gy.y), dim3(16, 16), 0, s, cx, p.instr_off.p, p.level_instr.p + lv.first, count_parts);
+            else if (buf.B <= 128) hipLaunchKernelGGL((k_solve_counts<64, 16>), dim3(ceil_div(buf.B, 64), gy.y), dim3(64, 16), 0, s, cx, p.instr_off.p, p.level_instr.p + lv.first, count_parts);
+            else hipLaunchKernelGGL((k_solve_counts<64, 4>), dim3(ceil_div(buf.B, 64), gy.y), dim3(64, 4), 0, s, cx, p.instr_off.p, p.level_instr.p + lv.first, count_parts);
+            skip = lv.n_count;
+        }
+        const uint32_t l_first = lv.first + skip, l_count = lv.count - skip, l_wide = lv.wide - skip;
+        const uint32_t packed_rows = l_wide + (l_count - l_wide + 3) / 4;
         const bool four = occ_env ? occ_env >= 4 : p.levels.size() <= 256;
-        const uint32_t packed_rows16 = lv.wide + (lv.count - lv.wide + 15) / 16;
-        if (pack && !four && buf.B > 16 && buf.B <= 128 && packed_rows16 <= 65535) {
+        const uint32_t packed_rows16 = l_wide + (l_count - l_wide + 15) / 16;
+        if (!l_count) {
+            // (a level of countHints only)
+        } else if (pack && !four && buf.B > 16 && buf.B <= 128 && packed_rows16 <= 65535) {
             // mid-size batches of the long programs (AES): one or two instance tiles cannot hide a level's longest instruction -- the ~3 600
             // queries of a countHint, a 130-term row -- behind other workgroups, so the instruction gets 16 slices instead of 4 (and the
             // short instructions sixteen to a workgroup).  AES-256, 64 proofs: the 118 wide levels 6.1 -> ... ms (profiles/r05*)
-            hipLaunchKernelGGL((k_solve_level<64, 16, 1>), dim3(ceil_div(buf.B, 64), packed_rows16), dim3(64, 16), 0, s, cx, p.instr_off.p, p.level_instr.p + lv.first, lv.count, lv.wide);
+            hipLaunchKernelGGL((k_solve_level<64, 16, 1>), dim3(ceil_div(buf.B, 64), packed_rows16), dim3(64, 16), 0, s, cx, p.instr_off.p, p.level_instr.p + l_first, l_count, l_wide);
         } else if (pack && buf.B > 16 && packed_rows <= 65535) {
-            if (four) hipLaunchKernelGGL((k_solve_level<64, 4, 4>), dim3(ceil_div(buf.B, 64), packed_rows), dim3(64, 4), 0, s, cx, p.instr_off.p, p.level_instr.p + lv.first, lv.count, lv.wide);
-            else hipLaunchKernelGGL((k_solve_level<64, 4, 1>), dim3(ceil_div(buf.B, 64), packed_rows), dim3(64, 4), 0, s, cx, p.instr_off.p, p.level_instr.p + lv.first, lv.count, lv.wide);
+            if (four) hipLaunchKernelGGL((k_solve_level<64, 4, 4>), dim3(ceil_div(buf.B, 64), packed_rows), dim3(64, 4), 0, s, cx, p.instr_off.p, p.level_instr.p + l_first, l_count, l_wide);
+            else hipLaunchKernelGGL((k_solve_level<64, 4, 1>), dim3(ceil_div(buf.B, 64), packed_rows), dim3(64, 4), 0, s, cx, p.instr_off.p, p.level_instr.p + l_first, l_count, l_wide);
         } else {
-            for (uint32_t off = 0; off < lv.count; off += 65535) {       // grid.y limit; every row cooperative (correct for any instruction)
-                const uint32_t cnt = lv.count - off < 65535 ? lv.count - off : 65535;
+            for (uint32_t off = 0; off < l_count; off += 65535) {       // grid.y limit; every row cooperative (correct for any instruction)
+                const uint32_t cnt = l_count - off < 65535 ? l_count - off : 65535;
                 if (buf.B <= 8)
-                    hipLaunchKernelGGL((k_solve_level<8, 32>), dim3(ceil_div(buf.B, 8), cnt), dim3(8, 32), 0, s, cx, p.instr_off.p, p.level_instr.p + lv.first + off, cnt, cnt);
+                    hipLaunchKernelGGL((k_solve_level<8, 32>), dim3(ceil_div(buf.B, 8), cnt), dim3(8, 32), 0, s, cx, p.instr_off.p, p.level_instr.p + l_first + off, cnt, cnt);
                 else if (buf.B <= 16)
-                    hipLaunchKernelGGL((k_solve_level<16, 16>), dim3(ceil_div(buf.B, 16), cnt), dim3(16, 16), 0, s, cx, p.instr_off.p, p.level_instr.p + lv.first + off, cnt, cnt);
+                    hipLaunchKernelGGL((k_solve_level<16, 16>), dim3(ceil_div(buf.B, 16), cnt), dim3(16, 16), 0, s, cx, p.instr_off.p, p.level_instr.p + l_first + off, cnt, cnt);
                 else
-                    hipLaunchKernelGGL((k_solve_level<64, 4>), dim3(ceil_div(buf.B, 64), cnt), dim3(64, 4), 0, s, cx, p.instr_off.p, p.level_instr.p + lv.first + off, cnt, cnt);
+                    hipLaunchKernelGGL((k_solve_level<64, 4>), dim3(ceil_div(buf.B, 64), cnt), dim3(64, 4), 0, s, cx, p.instr_off.p, p.level_instr.p + l_first + off, cnt, cnt);
             }
         }
         if (lv.div_count) {
