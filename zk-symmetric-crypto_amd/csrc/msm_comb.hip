@@ -513,7 +513,12 @@ static uint32_t comb_ranges(size_t B, size_t nclumps, int T) {
     // (batches below 512 proofs: two residency rounds instead of four -- their call is latency, and every doubling of Q is a range more
     // for the fold to add; the 1 024-batch keeps the shape it was tuned at)
     const size_t want = B >= 512 ? ((size_t)1 << 20) : ((size_t)1 << 19);
-    while (!forced && (size_t)Q * T * B < want && Q < 256) Q *= 2;
+    // (up to FOLD_ALL_RANGES_MAX_B proofs the fold brings any number of ranges down to one in parallel levels, so ranges are cheap and short
+    // walk wavefronts leave the device to the other chains sooner: 128 everywhere.  Same box against the thread-count rule below, which
+    // gave 256 / 64 / 32 ranges at 16 / 64 / 128 proofs (profiles/r05zy_*): 128 proofs ChaCha20 15.34 / 15.50 -> 15.04 / 15.03 ms, AES-256
+    // 41.22 / 41.31 -> 40.43 / 40.92; 16 and 64 proofs unchanged; 256 ranges: the same as 128)
+    if (!forced && B <= FOLD_ALL_RANGES_MAX_B) Q = 128;
+    while (!forced && B > FOLD_ALL_RANGES_MAX_B && (size_t)Q * T * B < want && Q < 256) Q *= 2;
     const uint32_t cap = (uint32_t)(nclumps / 24);
     if (Q > cap) Q = cap;
     return Q < 1 ? 1 : Q;
